@@ -1,0 +1,119 @@
+/*
+ * kornia_amd - C ABI of the MI355X (gfx950) native warp + filter path.
+ *
+ * One shared library, `kornia_amd/lib/libkornia_amd.so`, built by `python -m kornia_amd.build`
+ * (hipcc --offload-arch=gfx950).  The reference (kornia, pure Python on PyTorch) has no FFI for
+ * this path: the interface each entry point replaces is the Python call site cited next to it
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a Kornia
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer into memory owned by the caller (PyTorch's caching
+ *     allocator in the shipped binding) unless the argument is named *_host;
+ *   - tensors are dense, contiguous, NCHW; sizes are element counts;
+ *   - `dtype`: 0 = float32, 1 = float64, 2 = bfloat16, 3 = float16.  Matrices, filter taps and
+ *     gradient accumulators use the COMPUTE dtype: float32 for dtype 0/2/3, float64 for dtype 1;
+ *   - `stream` is a hipStream_t; launches are asynchronous on it; nothing synchronises the device,
+ *     allocates, frees, or retains pointers after returning;
+ *   - return value: 0 = ok, < 0 = invalid argument, > 0 = hipError_t; `km_last_error()` returns a
+ *     thread-local message.  No C++ exception crosses the boundary.
+ */
+#ifndef KORNIA_AMD_H
+#define KORNIA_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { KM_DTYPE_F32 = 0, KM_DTYPE_F64 = 1, KM_DTYPE_BF16 = 2, KM_DTYPE_F16 = 3 };
+/* warp coordinate generators */
+enum { KM_WARP_PERSPECTIVE = 0, KM_WARP_AFFINE = 1, KM_WARP_HOMOGRAPHY = 2 };
+/* interpolation / padding of the sampler (F.grid_sample modes; 3 = kornia's 'fill') */
+enum { KM_NEAREST = 0, KM_BILINEAR = 1, KM_BICUBIC = 2 };
+enum { KM_ZEROS = 0, KM_BORDER = 1, KM_REFLECTION = 2, KM_FILL = 3 };
+/* filter border modes (F.pad modes) */
+enum { KM_CONSTANT = 0, KM_REFLECT = 1, KM_REPLICATE = 2, KM_CIRCULAR = 3 };
+
+int km_abi_version(void);
+const char* km_last_error(void);
+/* gcnArchName of the current device into name[n]; returns the CU count or < 0 */
+int km_device_info(char* name, int n);
+
+/* ---- batched 3x3 homography chain -----------------------------------------------------------
+ * Replaces normalize_homography (kornia/geometry/conversions.py:1691-1726),
+ * normal_transform_pixel (:1729-1763), convert_affinematrix_to_homography (:342-378) and
+ * _inverse_3x3_closed_form (kornia/core/utils.py:137-166) as called from
+ * kornia/geometry/transform/imgwarp.py:146-153 and :249-254.
+ *   M      (B, rows, 3)  pixel src->dst matrix, rows = 3 (homography) or 2 (affine)
+ *   A_out  (B, 9)        normalised src->dst  = N_dst @ (M @ inv(N_src))          (nullable)
+ *   m_out  (B, 9)        normalised dst->src  = inv(A)                            (nullable)
+ * dtype: 0 | 1. */
+int km_homography_chain_fwd(const void* M, int rows, void* A_out, void* m_out, int B, int src_h, int src_w, int dst_h,
+                            int dst_w, int dtype, void* stream);
+/* gm (B,9) float64 gradient wrt m_out  ->  gM (B, rows, 3) in dtype. */
+int km_homography_chain_bwd(const void* M, int rows, const double* gm, void* gM, int B, int src_h, int src_w, int dst_h,
+                            int dst_w, int dtype, void* stream);
+
+/* ---- warps ---------------------------------------------------------------------------------
+ * Replaces the eager grid construction + F.grid_sample of warp_perspective
+ * (kornia/geometry/transform/imgwarp.py:157-174), warp_affine (:271-290), homography_warp with a
+ * normalised homography (:1539-1546 -> warp_grid :323-353 -> transform_points,
+ * kornia/geometry/linalg.py:219-239) and _fill_and_warp (:293-320).  The (B,h,w,2) grid is never
+ * materialised.
+ *   src   (B,C,H,W) dtype      mat (B_M,9) compute dtype, B_M in {1,B}: the matrix applied to the
+ *   dst   (B,C,h,w) dtype          base grid (m_out of the chain, or the user's normalised H)
+ *   coord_mode  KM_WARP_*      norm_coords: homography mode only (normalized_coordinates flag)
+ *   fill  (C) compute dtype, only read when pad == KM_FILL */
+int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int H, int W, int h, int w, int B_M,
+                  int coord_mode, int norm_coords, int interp, int pad, int align_corners, const void* fill, int dtype,
+                  void* stream);
+/* Replaces autograd's aten::grid_sampler_2d_backward + the reverse of the grid chain.
+ *   gout  (B,C,h,w) dtype
+ *   gsrc  (B,C,H,W) COMPUTE dtype accumulators, zeroed by the caller, nullable
+ *   gmat  (B_M,9) float64 accumulators, zeroed by the caller, nullable */
+int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
+                  int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align_corners,
+                  const void* fill, int dtype, void* stream);
+
+/* ---- filters -------------------------------------------------------------------------------
+ * Replaces F.pad + F.conv2d(groups = Bk*C) of filter2d (kornia/filters/filter.py:131-150).
+ *   x (B,C,H,W) dtype; k (Bk,kH,kW) prepared taps (flipped for 'conv', normalised, rounded to the
+ *   input dtype) stored in the compute dtype; sample b uses kernel b % Bk (filter.py:141-142);
+ *   same = 1: output (B,C,H,W) with `border`; same = 0 ('valid'): (B,C,H-kH+1,W-kW+1). */
+int km_filter2d_fwd(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int kH, int kW, int border,
+                    int same, int dtype, void* stream);
+int km_filter2d_bwd_input(const void* gy, const void* k, void* gx, int B, int C, int H, int W, int Bk, int kH, int kW,
+                          int border, int same, int dtype, void* stream);
+/* gk (Bk,kH,kW) float64 accumulators, zeroed by the caller */
+int km_filter2d_bwd_kernel(const void* gy, const void* x, void* gk, int B, int C, int H, int W, int Bk, int kH, int kW,
+                           int border, int same, int dtype, void* stream);
+/* Replaces filter2d_separable (filter.py:155-207) = GaussianBlur2d's path (gaussian.py:109-115):
+ * both passes in one launch, intermediate kept in LDS.  kx (Bk,kW), ky (Bk,kH) compute dtype. */
+int km_filter2d_sep_fwd(const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk, int kH,
+                        int kW, int border, int same, int dtype, void* stream);
+int km_filter2d_sep_bwd_input(const void* gy, const void* kx, const void* ky, void* gx, int B, int C, int H, int W, int Bk,
+                              int kH, int kW, int border, int same, int dtype, void* stream);
+/* 1 if the fused separable kernels accept this kernel size (LDS budget), else 0 */
+int km_filter2d_sep_supported(int kH, int kW, int same, int dtype);
+
+/* ---- spatial gradient / sobel --------------------------------------------------------------
+ * Replaces spatial_gradient (kornia/filters/sobel.py:59-72) and the magnitude of sobel (:164-171).
+ *   kern_host: HOST pointer, (n_out,kS,kS) derivative stack in the compute dtype (by-value kernel arg)
+ *   out (B,C,n_out,H,W) nullable; mag (B,C,H,W) nullable = sqrt(gx*gx + gy*gy + eps), n_out == 2 */
+int km_spatial_gradient_fwd(const void* x, const void* kern_host, void* out, void* mag, int B, int C, int H, int W,
+                            int n_out, int kS, double eps, int dtype, void* stream);
+int km_spatial_gradient_bwd(const void* gout, const void* kern_host, void* gx, int B, int C, int H, int W, int n_out,
+                            int kS, int dtype, void* stream);
+
+/* ---- transform_points ----------------------------------------------------------------------
+ * Replaces kornia/geometry/linalg.py:183-239 (+ conversions.py:247-339).  T (B_T,D+1,D+1),
+ * pts/out (B,N,D), D in {2,3}, B_T in {1,B}; dtype 0 | 1. */
+int km_transform_points_fwd(const void* T, const void* pts, void* out, int B, int N, int D, int B_T, int dtype, void* stream);
+/* gpts (B,N,D) nullable; gT (B_T,(D+1)^2) float64 accumulators, zeroed by the caller, nullable */
+int km_transform_points_bwd(const void* gout, const void* T, const void* pts, void* gpts, void* gT, int B, int N, int D,
+                            int B_T, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KORNIA_AMD_H */

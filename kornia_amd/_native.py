@@ -1,0 +1,126 @@
+"""ctypes binding of the C-ABI library (``include/kornia_amd.h``).
+
+The product path has NO fallback: if the shared library is missing or cannot be loaded, or a
+tensor does not live on a HIP device, the ops raise.  PyTorch is used for device memory, streams
+and autograd only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_void_p
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libkornia_amd.so")
+ABI_VERSION = 1
+
+KM_F32, KM_F64, KM_BF16, KM_F16 = 0, 1, 2, 3
+_DTYPE_CODES = {torch.float32: KM_F32, torch.float64: KM_F64, torch.bfloat16: KM_BF16, torch.float16: KM_F16}
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP extension is missing, stale, or reported an error."""
+
+
+_P = c_void_p
+_I = c_int
+# name -> argtypes; every entry point returns int (0 ok, <0 bad argument, >0 hipError_t)
+_PROTOTYPES = {
+    "km_homography_chain_fwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "km_homography_chain_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "km_warp2d_fwd": [_P, _P, _P] + [_I] * 12 + [_P, _I, _P],
+    "km_warp2d_bwd": [_P, _P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],
+    "km_filter2d_fwd": [_P, _P, _P] + [_I] * 10 + [_P],
+    "km_filter2d_bwd_input": [_P, _P, _P] + [_I] * 10 + [_P],
+    "km_filter2d_bwd_kernel": [_P, _P, _P] + [_I] * 10 + [_P],
+    "km_filter2d_sep_fwd": [_P, _P, _P, _P] + [_I] * 10 + [_P],
+    "km_filter2d_sep_bwd_input": [_P, _P, _P, _P] + [_I] * 10 + [_P],
+    "km_spatial_gradient_fwd": [_P, _P, _P, _P] + [_I] * 6 + [c_double, _I, _P],
+    "km_spatial_gradient_bwd": [_P, _P, _P] + [_I] * 6 + [_I, _P],
+    "km_filter2d_sep_supported": [_I, _I, _I, _I],
+    "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
+    "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def library_path() -> str:
+    return LIB_PATH
+
+
+def is_built() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the C-ABI library; raises NativeLibraryError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"kornia_amd native library not found at {LIB_PATH}. Build it with `python -m kornia_amd.build` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU/PyTorch fallback."
+        )
+    try:
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover - depends on the runtime environment
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    handle.km_abi_version.restype = c_int
+    handle.km_last_error.restype = c_char_p
+    got = handle.km_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryError(f"{LIB_PATH} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    for name, argtypes in _PROTOTYPES.items():
+        fn = getattr(handle, name, None)
+        if fn is None:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it")
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    handle.km_device_info.argtypes = [c_char_p, c_int]
+    handle.km_device_info.restype = c_int
+    _lib = handle
+    return handle
+
+
+def exported_symbols() -> list[str]:
+    return ["km_abi_version", "km_last_error", "km_device_info", *_PROTOTYPES.keys()]
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().km_last_error().decode("utf-8", "replace")
+        raise NativeLibraryError(f"{what} failed (rc={rc}): {msg}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODES[dtype]
+    except KeyError:
+        raise TypeError(f"kornia_amd supports float32/float64/bfloat16/float16 tensors, got {dtype}") from None
+
+
+def compute_dtype(dtype: torch.dtype) -> torch.dtype:
+    """fp64 data is processed in fp64, everything else in fp32."""
+    return torch.float64 if dtype == torch.float64 else torch.float32
+
+
+def require_device(t: torch.Tensor, name: str) -> None:
+    """The native path only runs on HIP tensors - fail loudly otherwise (no silent fallback)."""
+    if not t.is_cuda:
+        raise NativeLibraryError(
+            f"kornia_amd: `{name}` must be a tensor on a HIP (cuda) device, got device={t.device}. "
+            "The MI355X-native path has no CPU fallback."
+        )
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,194 @@
+// kornia_amd - the batched 3x3 homography chain (normalise + invert) as one tiny launch.
+//
+// Replaces ~25 PyTorch launches per warp call:
+//   normalize_homography      kornia/geometry/conversions.py:1691-1726
+//   normal_transform_pixel    kornia/geometry/conversions.py:1729-1763
+//   _inverse_3x3_closed_form  kornia/core/utils.py:137-166 (eager branch; called at imgwarp.py:153,254)
+//   convert_affinematrix_to_homography  kornia/geometry/conversions.py:342-378 (rows == 2)
+// B x ~150 flop: far below anything MFMA could help with - one thread per
+// matrix, rounding sequence identical to the reference's CPU ops (oracle/ko_impl.h ko_inv3 /
+// ko_mm3, pinned bit-exactly by tests/golden/chain_*.npz).
+#include "km_common.h"
+
+template <typename R>
+__device__ __forceinline__ void km_cross3(const R (&a)[3], const R (&b)[3], R (&o)[3]) {
+    // torch.linalg.cross's kernel contracts a1*b2 - a2*b1 into fma(a1, b2, -(a2*b1))
+    R t;
+    t = a[2] * b[1];
+    o[0] = km_fma(a[1], b[2], -t);
+    t = a[0] * b[2];
+    o[1] = km_fma(a[2], b[0], -t);
+    t = a[1] * b[0];
+    o[2] = km_fma(a[0], b[1], -t);
+}
+
+template <typename R>
+__device__ __forceinline__ void km_inv3(const R (&m)[9], R (&o)[9]) {
+    const R a[3] = {m[0], m[3], m[6]}, b[3] = {m[1], m[4], m[7]}, c[3] = {m[2], m[5], m[8]};
+    R r0[3], r1[3], r2[3];
+    km_cross3(b, c, r0);
+    km_cross3(c, a, r1);
+    km_cross3(a, b, r2);
+    const R p0 = a[0] * r0[0], p1 = a[1] * r0[1], p2 = a[2] * r0[2];
+    const R det = (p0 + p1) + p2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = r0[k] / det;
+        o[3 + k] = r1[k] / det;
+        o[6 + k] = r2[k] / det;
+    }
+}
+
+template <typename R>
+__device__ __forceinline__ void km_mm3(const R (&a)[9], const R (&b)[9], R (&o)[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            R acc = (R)0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc = acc + a[3 * i + k] * b[3 * k + j];
+            o[3 * i + j] = acc;
+        }
+}
+
+template <typename R>
+struct KmChainArgs {
+    const R* M;    // (B, rows, 3)
+    R* A;          // (B,9) normalised src->dst, nullable
+    R* m;          // (B,9) normalised dst->src, nullable
+    const double* gm;  // bwd: (B,9) fp64
+    R* gM;         // bwd: (B, rows, 3)
+    int B, rows;
+    float sx_s, sy_s, sx_d, sy_d;  // float32-rounded 2/(W-1), 2/(H-1) of source / destination
+};
+
+template <typename R>
+__device__ __forceinline__ void km_chain_setup(const KmChainArgs<R>& a, int b, R (&M)[9], R (&Nsi)[9], R (&Nd)[9]) {
+    const R* mp = a.M + (size_t)b * a.rows * 3;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) M[k] = mp[k];
+    if (a.rows == 3) {
+        M[6] = mp[6]; M[7] = mp[7]; M[8] = mp[8];
+    } else {
+        M[6] = 0; M[7] = 0; M[8] = 1;
+    }
+    const R Ns[9] = {(R)a.sx_s, 0, -1, 0, (R)a.sy_s, -1, 0, 0, 1};
+    km_inv3(Ns, Nsi);
+    const R nd[9] = {(R)a.sx_d, 0, -1, 0, (R)a.sy_d, -1, 0, 0, 1};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Nd[k] = nd[k];
+}
+
+template <typename R>
+__global__ void km_chain_fwd_kernel(const KmChainArgs<R> a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    R M[9], Nsi[9], Nd[9], t[9], A[9], mi[9];
+    km_chain_setup(a, b, M, Nsi, Nd);
+    km_mm3(M, Nsi, t);
+    km_mm3(Nd, t, A);
+    if (a.A) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.A[(size_t)b * 9 + k] = A[k];
+    }
+    if (a.m) {
+        km_inv3(A, mi);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.m[(size_t)b * 9 + k] = mi[k];
+    }
+}
+
+// adjoint wrt M in fp64: m = inv(A), A = Nd M Nsi ; gA = -m^T gm m^T ; gM = Nd^T gA Nsi^T
+template <typename R>
+__global__ void km_chain_bwd_kernel(const KmChainArgs<R> a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    R M[9], Nsi[9], Nd[9], t[9], A[9], mi[9];
+    km_chain_setup(a, b, M, Nsi, Nd);
+    km_mm3(M, Nsi, t);
+    km_mm3(Nd, t, A);
+    km_inv3(A, mi);
+    double g[9], t1[9], gA[9], t2[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = a.gm[(size_t)b * 9 + k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += (double)mi[3 * k + i] * g[3 * k + j];
+            t1[3 * i + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += t1[3 * i + k] * (double)mi[3 * j + k];
+            gA[3 * i + j] = -s;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += (double)Nd[3 * k + i] * gA[3 * k + j];
+            t2[3 * i + j] = s;
+        }
+    R* out = a.gM + (size_t)b * a.rows * 3;
+    for (int i = 0; i < a.rows; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += t2[3 * i + k] * (double)Nsi[3 * j + k];
+            out[3 * i + j] = (R)s;
+        }
+}
+
+static inline float km_norm_scale(int size) {
+    // conversions.py:1750-1755: eps=1e-14 when size == 1; value rounded to float32 by torch.tensor()
+    const double d = (size == 1) ? 1e-14 : (double)size - 1.0;
+    return (float)(2.0 / d);
+}
+
+template <typename R>
+static int km_chain_run(bool bwd, const void* M, int rows, void* A, void* m, const double* gm, void* gM, int B, int Hs,
+                        int Ws, int hd, int wd, hipStream_t s) {
+    KmChainArgs<R> a;
+    a.M = (const R*)M; a.A = (R*)A; a.m = (R*)m; a.gm = gm; a.gM = (R*)gM; a.B = B; a.rows = rows;
+    a.sx_s = km_norm_scale(Ws); a.sy_s = km_norm_scale(Hs); a.sx_d = km_norm_scale(wd); a.sy_d = km_norm_scale(hd);
+    if (B == 0) return 0;
+    const int threads = 64, blocks = (B + threads - 1) / threads;
+    if (bwd)
+        hipLaunchKernelGGL(km_chain_bwd_kernel<R>, dim3(blocks), dim3(threads), 0, s, a);
+    else
+        hipLaunchKernelGGL(km_chain_fwd_kernel<R>, dim3(blocks), dim3(threads), 0, s, a);
+    return km_check_launch(bwd ? "km_homography_chain_bwd" : "km_homography_chain_fwd");
+}
+
+extern "C" {
+
+// M: (B,rows,3) pixel src->dst matrix, rows in {2,3}; A_out/m_out: (B,9), either may be null.
+// dtype: KM_F32 or KM_F64 (matrices of bf16/f16 images are handled in fp32 by the caller).
+int km_homography_chain_fwd(const void* M, int rows, void* A_out, void* m_out, int B, int Hs, int Ws, int hd, int wd,
+                            int dtype, void* stream) {
+    KM_REQUIRE(M && (A_out || m_out), "km_homography_chain_fwd: null pointer");
+    KM_REQUIRE(rows == 2 || rows == 3, "km_homography_chain_fwd: rows must be 2 or 3, got %d", rows);
+    KM_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && hd > 0 && wd > 0, "km_homography_chain_fwd: bad sizes");
+    KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_homography_chain_fwd: dtype must be f32/f64");
+    if (dtype == KM_F32) return km_chain_run<float>(false, M, rows, A_out, m_out, nullptr, nullptr, B, Hs, Ws, hd, wd, (hipStream_t)stream);
+    return km_chain_run<double>(false, M, rows, A_out, m_out, nullptr, nullptr, B, Hs, Ws, hd, wd, (hipStream_t)stream);
+}
+
+// gm: (B,9) fp64 gradient wrt m_out; gM: (B,rows,3) in dtype.
+int km_homography_chain_bwd(const void* M, int rows, const double* gm, void* gM, int B, int Hs, int Ws, int hd, int wd,
+                            int dtype, void* stream) {
+    KM_REQUIRE(M && gm && gM, "km_homography_chain_bwd: null pointer");
+    KM_REQUIRE(rows == 2 || rows == 3, "km_homography_chain_bwd: rows must be 2 or 3, got %d", rows);
+    KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_homography_chain_bwd: dtype must be f32/f64");
+    if (dtype == KM_F32) return km_chain_run<float>(true, M, rows, nullptr, nullptr, gm, gM, B, Hs, Ws, hd, wd, (hipStream_t)stream);
+    return km_chain_run<double>(true, M, rows, nullptr, nullptr, gm, gM, B, Hs, Ws, hd, wd, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// kornia_amd - shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Numerics contract (see DESIGN.md "Parity"): the whole library is compiled with
+// -ffp-contract=off, so a multiply-add is fused ONLY where the source says km_fma().  The
+// coordinate pipeline reproduces the reference's per-op rounding sequence,
+// which is what makes the fp32 results bit-identical to the CPU oracle in oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KM_ABI_VERSION 1
+
+// dtype codes of the C ABI (include/kornia_amd.h)
+enum { KM_F32 = 0, KM_F64 = 1, KM_BF16 = 2, KM_F16 = 3 };
+
+// ---- error reporting (no exceptions cross the ABI) ------------------------------------------
+void km_set_error(const char* fmt, ...);
+int km_check_launch(const char* what);
+
+#define KM_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            km_set_error(__VA_ARGS__); \
+            return -1;                 \
+        }                              \
+    } while (0)
+
+// ---- storage types ----------------------------------------------------------------------------
+struct km_bf16 {
+    uint16_t bits;
+};
+typedef _Float16 km_f16;
+
+template <typename T>
+struct KmTraits;
+template <>
+struct KmTraits<float> {
+    typedef float R;  // compute type
+    static constexpr int code = KM_F32;
+};
+template <>
+struct KmTraits<double> {
+    typedef double R;
+    static constexpr int code = KM_F64;
+};
+template <>
+struct KmTraits<km_bf16> {
+    typedef float R;
+    static constexpr int code = KM_BF16;
+};
+template <>
+struct KmTraits<km_f16> {
+    typedef float R;
+    static constexpr int code = KM_F16;
+};
+
+__device__ __forceinline__ float km_ld(const float* p) { return *p; }
+__device__ __forceinline__ double km_ld(const double* p) { return *p; }
+__device__ __forceinline__ float km_ld(const km_bf16* p) { return __uint_as_float(((uint32_t)p->bits) << 16); }
+__device__ __forceinline__ float km_ld(const km_f16* p) { return (float)(*p); }
+
+__device__ __forceinline__ uint16_t km_f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void km_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void km_st(double* p, double v) { *p = v; }
+__device__ __forceinline__ void km_st(km_bf16* p, float v) { p->bits = km_f32_to_bf16_bits(v); }
+__device__ __forceinline__ void km_st(km_f16* p, float v) { *p = (km_f16)v; }
+
+// ---- explicitly fused / explicitly rounded arithmetic ---------------------------------------
+__device__ __host__ __forceinline__ float km_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __host__ __forceinline__ double km_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float km_floor(float x) { return __builtin_floorf(x); }
+__device__ __forceinline__ double km_floor(double x) { return __builtin_floor(x); }
+__device__ __forceinline__ float km_fabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double km_fabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float km_rint(float x) { return __builtin_rintf(x); }  // ties-to-even (nearbyint)
+__device__ __forceinline__ double km_rint(double x) { return __builtin_rint(x); }
+__device__ __forceinline__ float km_fmod(float a, float b) { return fmodf(a, b); }
+__device__ __forceinline__ double km_fmod(double a, double b) { return fmod(a, b); }
+__device__ __forceinline__ float km_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE (built with -fhip-fp32-correctly-rounded-divide-sqrt)
+__device__ __forceinline__ double km_sqrt(double x) { return __builtin_sqrt(x); }
+
+// fp32/fp64 global atomic add without return value (hardware global_atomic_add_f32/_f64 on gfx950)
+__device__ __forceinline__ void km_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void km_atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// ---- XCD-aware block index remap ---------------------------------------------------------------
+// MI355X dispatches workgroup b to XCD (b % 8); each XCD has a private 4 MiB L2.  Remap the linear
+// block id so that each XCD works on one contiguous range of logical tiles (= whole images), which
+// keeps the halo rows that neighbouring tiles share inside one L2.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t km_xcd_remap(uint32_t bid, uint32_t nblocks) {
+    const uint32_t NX = 8;
+    const uint32_t q = nblocks / NX, r = nblocks % NX;
+    const uint32_t xcd = bid % NX, k = bid / NX;
+    // XCD x owns q (+1 if x < r) logical blocks, laid out back to back
+    const uint32_t start = xcd * q + (xcd < r ? xcd : r);
+    return start + k;
+}
+
+// wave-level sum (64 lanes) in double precision
+__device__ __forceinline__ double km_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}

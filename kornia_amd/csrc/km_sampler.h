@@ -1,0 +1,200 @@
+// kornia_amd - coordinate generation and sampler primitives shared by the warp kernels.
+//
+// Semantics being reproduced (reference files relative to /root/reference):
+//   * coordinate generators: kornia/geometry/transform/imgwarp.py:157-170 (warp_perspective),
+//     :271-281 (warp_affine), :1541-1546 + kornia/geometry/linalg.py:219-239 +
+//     kornia/geometry/conversions.py:303-307 (homography_warp / transform_points);
+//     kornia/geometry/grid.py:65-77 (create_meshgrid).
+//   * sampler: F.grid_sample as specified by torch/include/ATen/native/GridSampler.h and
+//     UpSample.h:400-423 (the reference calls it at imgwarp.py:174,290,316,320,1546).
+// Every floating-point operation is written in the order the reference performs it; see
+// oracle/ko_impl.h for the CPU restatement these functions are tested against bit for bit.
+#pragma once
+
+#include "km_common.h"
+
+enum { KM_COORD_PERSPECTIVE = 0, KM_COORD_AFFINE = 1, KM_COORD_HOMOGRAPHY = 2 };
+enum { KM_INTERP_NEAREST = 0, KM_INTERP_BILINEAR = 1, KM_INTERP_BICUBIC = 2 };
+enum { KM_PAD_ZEROS = 0, KM_PAD_BORDER = 1, KM_PAD_REFLECTION = 2, KM_PAD_FILL = 3 };
+
+// Per-launch geometry shared by forward and backward.
+template <typename R>
+struct KmWarpGeom {
+    int B, C, H, W, h, w, B_M;
+    int coord_mode, norm_coords, interp, pad, align;
+    // torch.linspace parameters for KM_COORD_AFFINE (imgwarp.py:271-276), evaluated on the host in R
+    R lin_lo_x, lin_hi_x, lin_step_x, lin_lo_y, lin_hi_y, lin_step_y;
+};
+
+template <typename R>
+struct KmCoord {
+    R u, v;    // base coordinates
+    R gx, gy;  // normalised sampling coordinates
+    R den;     // perspective: denominator; homography: scale s
+    R X, Y;    // homography: numerators
+    bool live; // homography: |Z| > eps
+};
+
+// create_meshgrid(normalized_coordinates=True), grid.py:73-75: (i / (n-1) - 0.5) * 2
+__device__ __forceinline__ float km_mesh_f32(int i, int n) { return (((float)i / (float)(n - 1)) - 0.5f) * 2.0f; }
+template <typename R>
+__device__ __forceinline__ R km_mesh(int i, int n) {
+    return (((R)i / (R)(n - 1)) - (R)0.5) * (R)2;
+}
+
+// torch.linspace scalar formula (two-sided, fused multiply-add)
+template <typename R>
+__device__ __forceinline__ R km_linspace(R lo, R hi, R step, int n, int i) {
+    if (n == 1) return lo;
+    if (i < n / 2) return km_fma(step, (R)i, lo);
+    return km_fma(-step, (R)(n - 1 - i), hi);
+}
+
+// base coordinate along x (column j) / y (row i)
+template <typename R, int CM>
+__device__ __forceinline__ R km_base_x(const KmWarpGeom<R>& g, int j) {
+    if (CM == KM_COORD_PERSPECTIVE) return (R)km_mesh_f32(j, g.w);  // always computed in fp32, then cast
+    if (CM == KM_COORD_AFFINE) return km_linspace<R>(g.lin_lo_x, g.lin_hi_x, g.lin_step_x, g.w, j);
+    return g.norm_coords ? km_mesh<R>(j, g.w) : (R)j;
+}
+template <typename R, int CM>
+__device__ __forceinline__ R km_base_y(const KmWarpGeom<R>& g, int i) {
+    if (CM == KM_COORD_PERSPECTIVE) return (R)km_mesh_f32(i, g.h);
+    if (CM == KM_COORD_AFFINE) return km_linspace<R>(g.lin_lo_y, g.lin_hi_y, g.lin_step_y, g.h, i);
+    return g.norm_coords ? km_mesh<R>(i, g.h) : (R)i;
+}
+
+template <typename R, int CM>
+__device__ __forceinline__ void km_gen_coord(const R (&m)[9], R u, R v, KmCoord<R>& c) {
+    c.u = u;
+    c.v = v;
+    if (CM == KM_COORD_PERSPECTIVE) {
+        // imgwarp.py:167-169: ((m20*u) + (m21*v)) + m22 ; ((m00*u) + (m01*v) + m02) / den
+        const R den = (m[6] * u + m[7] * v) + m[8];
+        c.den = den;
+        c.gx = ((m[0] * u + m[1] * v) + m[2]) / den;
+        c.gy = ((m[3] * u + m[4] * v) + m[5]) / den;
+    } else if (CM == KM_COORD_AFFINE) {
+        c.den = (R)1;
+        c.gx = (m[0] * u + m[1] * v) + m[2];
+        c.gy = (m[3] * u + m[4] * v) + m[5];
+    } else {
+        // bmm([u v 1], H^T) as the k-ordered fma chain of the BLAS behind torch.bmm, then
+        // convert_points_from_homogeneous: s = |Z| > eps ? 1/(Z+eps) : 1
+        const R X = km_fma(v, m[1], u * m[0]) + m[2];
+        const R Y = km_fma(v, m[4], u * m[3]) + m[5];
+        const R Z = km_fma(v, m[7], u * m[6]) + m[8];
+        const R eps = (R)1e-8;
+        c.live = km_fabs(Z) > eps;
+        const R s = c.live ? (R)1 / (Z + eps) : (R)1;
+        c.X = X;
+        c.Y = Y;
+        c.den = s;
+        c.gx = s * X;
+        c.gy = s * Y;
+    }
+}
+
+// ---- ATen GridSampler.h primitives ---------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ R km_unnormalize(R g, int size, int align, R& mult) {
+    if (align) {
+        mult = (R)(size - 1) / 2;
+        return ((g + 1) / 2) * (R)(size - 1);
+    }
+    mult = (R)size / 2;
+    return km_fma(g + 1, (R)size / 2, (R)-0.5);  // ((g+1)*size - 1)/2 as one fused op (see oracle)
+}
+
+template <typename R>
+__device__ __forceinline__ R km_clip(R x, int size, R& grad) {
+    if (x <= (R)0) {
+        grad = 0;
+        return 0;
+    }
+    const R mx = (R)(size - 1);
+    if (x >= mx) {
+        grad = 0;
+        return mx;
+    }
+    grad = 1;
+    return x;
+}
+
+template <typename R>
+__device__ __forceinline__ R km_reflect(R x, int twice_low, int twice_high, R& grad) {
+    if (twice_low == twice_high) {
+        grad = 0;
+        return 0;
+    }
+    int sign;
+    const R mn = (R)twice_low / 2;
+    const R span = (R)(twice_high - twice_low) / 2;
+    x = x - mn;
+    if (x < (R)0) {
+        sign = -1;
+        x = -x;
+    } else {
+        sign = 1;
+    }
+    const R extra = km_fmod(x, span);
+    const int flips = (int)km_floor(x / span);
+    if (flips % 2 == 0) {
+        grad = (R)sign;
+        return extra + mn;
+    }
+    grad = (R)(-sign);
+    return span - extra + mn;
+}
+
+// pad: zeros(0)/fill(3) -> identity, border(1) -> clip, reflection(2) -> reflect + clip
+template <typename R>
+__device__ __forceinline__ R km_compute_coord(R x, int size, int pad, int align, R& grad) {
+    grad = 1;
+    if (pad == KM_PAD_BORDER) {
+        x = km_clip(x, size, grad);
+    } else if (pad == KM_PAD_REFLECTION) {
+        R gr, gc;
+        x = align ? km_reflect(x, 0, 2 * (size - 1), gr) : km_reflect(x, -1, 2 * size - 1, gr);
+        x = km_clip(x, size, gc);
+        grad = gr * gc;
+    }
+    return x;
+}
+
+template <typename R>
+__device__ __forceinline__ void km_cubic_coeffs(R t, R (&c)[4]) {
+    const R A = (R)-0.75;
+    R x = t + (R)1.0;
+    c[0] = ((A * x - 5 * A) * x + 8 * A) * x - 4 * A;
+    x = t;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    x = (R)1.0 - t;
+    c[2] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    x = x + (R)1.0;
+    c[3] = ((A * x - 5 * A) * x + 8 * A) * x - 4 * A;
+}
+
+template <typename R>
+__device__ __forceinline__ void km_cubic_coeffs_grad(R t, R (&c)[4]) {
+    const R A = (R)-0.75;
+    R x = -1 - t;
+    c[0] = (-3 * A * x - 10 * A) * x - 8 * A;
+    x = -t;
+    c[1] = (-3 * (A + 2) * x - 2 * (A + 3)) * x;
+    x = 1 - t;
+    c[2] = (3 * (A + 2) * x - 2 * (A + 3)) * x;
+    x = 2 - t;
+    c[3] = (3 * A * x - 10 * A) * x + 8 * A;
+}
+
+// integer tap for bicubic: the tap position itself goes through the padding transform
+// (get_value_bounded / add_value_bounded).  Returns the linear index or -1.
+template <typename R>
+__device__ __forceinline__ int km_tap_index(R x, R y, int W, int H, int pad, int align) {
+    R g;
+    x = km_compute_coord(x, W, pad, align, g);
+    y = km_compute_coord(y, H, pad, align, g);
+    const int ix = (int)x, iy = (int)y;
+    return (ix >= 0 && ix < W && iy >= 0 && iy < H) ? iy * W + ix : -1;
+}

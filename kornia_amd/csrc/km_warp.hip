@@ -1,0 +1,471 @@
+// kornia_amd - warp kernels (warp_perspective / warp_affine / homography_warp) for gfx950.
+//
+// One launch does what the reference does with ~25 elementwise launches + grid_sample
+// (kornia/geometry/transform/imgwarp.py:157-174, :271-290, :1541-1546): the sampling grid is
+// generated in registers from the (B,3,3) matrix and never touches HBM.
+//
+// Work decomposition (forward and generic backward):
+//   * block = 4 waves; a wave owns a 64-wide x KM_ROWS-tall strip of the OUTPUT image; lane l
+//     owns column x0+l, so every tap load / store instruction of a wave touches a contiguous run
+//     of ~64 pixels (coalesced NCHW reads; consecutive rows of the strip re-use the same source
+//     rows out of L1).
+//   * the per-pixel coordinate (two IEEE divisions for the projective case) is computed once and
+//     shared by all C channels.
+//   * blockIdx is remapped so that one XCD (private L2) processes whole images.
+// HBM roofline: forward moves 2e bytes / element (read src once, write dst once), backward 3e
+// (read grad_out, read src, write grad_src) - see DESIGN.md.
+#include "km_sampler.h"
+
+#define KM_ROWS 4   // output rows per thread
+#define KM_TILE_W 64
+#define KM_TILE_H (4 * KM_ROWS)
+
+template <typename T>
+struct KmWarpArgs {
+    typedef typename KmTraits<T>::R R;
+    const T* src;     // (B,C,H,W)
+    const R* mat;     // (B_M,9) row-major, compute dtype
+    T* dst;           // fwd: (B,C,h,w)
+    const T* gout;    // bwd: (B,C,h,w)
+    R* gsrc;          // bwd: (B,C,H,W) accumulators in compute dtype, pre-zeroed (nullable)
+    double* gmat;     // bwd: (B_M,9) fp64 accumulators, pre-zeroed (nullable)
+    const R* fill;    // (C) compute dtype, pad == fill only
+    KmWarpGeom<R> g;
+    uint32_t tiles_x, tiles_y, nblocks;
+};
+
+// ------------------------------------------------------------------------------------------------
+// bilinear tap set for one output pixel
+template <typename R>
+struct KmBilin {
+    int i00, i01, i10, i11;  // clamped linear indices (always valid addresses)
+    R w00, w01, w10, w11;    // weights, zeroed for out-of-bounds taps in forward use
+    bool b00, b01, b10, b11;
+    R wx0, wx1, wy0, wy1;    // (x - x0), (x1 - x), (y - y0), (y1 - y)
+};
+
+template <typename R>
+__device__ __forceinline__ void km_bilinear_setup(R x, R y, int W, int H, KmBilin<R>& t) {
+    const R xf = km_floor(x), yf = km_floor(y);
+    // bounds decided in floating point so that NaN / huge coordinates are simply out of bounds
+    const bool bx0 = (xf >= (R)0) && (xf <= (R)(W - 1));
+    const bool bx1 = (xf >= (R)-1) && (xf <= (R)(W - 2));
+    const bool by0 = (yf >= (R)0) && (yf <= (R)(H - 1));
+    const bool by1 = (yf >= (R)-1) && (yf <= (R)(H - 2));
+    const R x1f = xf + 1, y1f = yf + 1;
+    t.wx1 = x1f - x;
+    t.wx0 = x - xf;
+    t.wy1 = y1f - y;
+    t.wy0 = y - yf;
+    t.w00 = t.wx1 * t.wy1;
+    t.w01 = t.wx0 * t.wy1;
+    t.w10 = t.wx1 * t.wy0;
+    t.w11 = t.wx0 * t.wy0;
+    const int x0 = bx0 ? (int)xf : 0, x1 = bx1 ? (int)x1f : 0;
+    const int y0 = by0 ? (int)yf : 0, y1 = by1 ? (int)y1f : 0;
+    t.b00 = bx0 && by0;
+    t.b01 = bx1 && by0;
+    t.b10 = bx0 && by1;
+    t.b11 = bx1 && by1;
+    t.i00 = y0 * W + x0;
+    t.i01 = y0 * W + x1;
+    t.i10 = y1 * W + x0;
+    t.i11 = y1 * W + x1;
+}
+
+template <typename T, int CM, int INTERP>
+__global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a) {
+    typedef typename KmTraits<T>::R R;
+    const KmWarpGeom<R>& g = a.g;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = (int)tx * KM_TILE_W + lane;
+    const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
+    if (j >= g.w) return;
+
+    R m[9];
+    {
+        const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+    }
+    const int spad = (g.pad == KM_PAD_FILL) ? KM_PAD_ZEROS : g.pad;
+    const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
+    const T* src_b = a.src + (size_t)b * g.C * src_plane;
+    T* dst_b = a.dst + (size_t)b * g.C * dst_plane;
+    const R u = km_base_x<R, CM>(g, j);
+
+#pragma unroll
+    for (int r = 0; r < KM_ROWS; ++r) {
+        const int i = i_base + r;
+        if (i >= g.h) break;
+        const R v = km_base_y<R, CM>(g, i);
+        KmCoord<R> cd;
+        km_gen_coord<R, CM>(m, u, v, cd);
+        R mx, my, gdx, gdy;
+        R x = km_unnormalize(cd.gx, g.W, g.align, mx);
+        R y = km_unnormalize(cd.gy, g.H, g.align, my);
+        T* out_px = dst_b + (size_t)i * g.w + j;
+
+        if (INTERP == KM_INTERP_BILINEAR) {
+            x = km_compute_coord(x, g.W, spad, g.align, gdx);
+            y = km_compute_coord(y, g.H, spad, g.align, gdy);
+            KmBilin<R> t;
+            km_bilinear_setup(x, y, g.W, g.H, t);
+            R inv_mask = 0;
+            if (g.pad == KM_PAD_FILL) {
+                // 1 - grid_sample(ones): imgwarp.py:316
+                R mask = 0;
+                if (t.b00) mask = mask + t.w00;
+                if (t.b01) mask = mask + t.w01;
+                if (t.b10) mask = mask + t.w10;
+                if (t.b11) mask = mask + t.w11;
+                inv_mask = (R)1 - mask;
+            }
+            for (int c = 0; c < g.C; ++c) {
+                const T* img = src_b + (size_t)c * src_plane;
+                const R v00 = km_ld(img + t.i00), v01 = km_ld(img + t.i01);
+                const R v10 = km_ld(img + t.i10), v11 = km_ld(img + t.i11);
+                // fma chain in nw, ne, sw, se order; out-of-bounds taps are skipped
+                R acc = 0;
+                acc = t.b00 ? km_fma(v00, t.w00, acc) : acc;
+                acc = t.b01 ? km_fma(v01, t.w01, acc) : acc;
+                acc = t.b10 ? km_fma(v10, t.w10, acc) : acc;
+                acc = t.b11 ? km_fma(v11, t.w11, acc) : acc;
+                if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
+                km_st(out_px + (size_t)c * dst_plane, acc);
+            }
+        } else if (INTERP == KM_INTERP_NEAREST) {
+            x = km_compute_coord(x, g.W, spad, g.align, gdx);
+            y = km_compute_coord(y, g.H, spad, g.align, gdy);
+            const R xr = km_rint(x), yr = km_rint(y);
+            const bool inb = (xr >= (R)0) && (xr <= (R)(g.W - 1)) && (yr >= (R)0) && (yr <= (R)(g.H - 1));
+            const int idx = inb ? (int)yr * g.W + (int)xr : 0;
+            for (int c = 0; c < g.C; ++c) {
+                R acc = inb ? km_ld(src_b + (size_t)c * src_plane + idx) : (R)0;
+                if (g.pad == KM_PAD_FILL) acc = acc + ((R)1 - (inb ? (R)1 : (R)0)) * a.fill[c];
+                km_st(out_px + (size_t)c * dst_plane, acc);
+            }
+        } else {
+            const R xf = km_floor(x), yf = km_floor(y);
+            R cx[4], cy[4];
+            km_cubic_coeffs(x - xf, cx);
+            km_cubic_coeffs(y - yf, cy);
+            int idx[4][4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) idx[rr][q] = km_tap_index(xf - 1 + q, yf - 1 + rr, g.W, g.H, spad, g.align);
+            R inv_mask = 0;
+            if (g.pad == KM_PAD_FILL) {
+                R rows[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    R tt[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt[q] = idx[rr][q] >= 0 ? (R)1 : (R)0;
+                    rows[rr] = tt[0] * cx[0] + tt[1] * cx[1] + tt[2] * cx[2] + tt[3] * cx[3];
+                }
+                inv_mask = (R)1 - (rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3]);
+            }
+            for (int c = 0; c < g.C; ++c) {
+                const T* img = src_b + (size_t)c * src_plane;
+                R rows[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    R tt[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt[q] = idx[rr][q] >= 0 ? km_ld(img + idx[rr][q]) : (R)0;
+                    rows[rr] = tt[0] * cx[0] + tt[1] * cx[1] + tt[2] * cx[2] + tt[3] * cx[3];
+                }
+                R acc = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+                if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
+                km_st(out_px + (size_t)c * dst_plane, acc);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic backward: scatter-add into grad_src with hardware fp32/fp64 atomics (what ATen's
+// grid_sampler_2d_backward does) + per-image reduction of the matrix gradient.
+// Matrix gradient, r = (u, v, 1):
+//   perspective:  d/dm0k = ggx r_k / den ; d/dm1k = ggy r_k / den ; d/dm2k = -(ggx gx + ggy gy) r_k / den
+//   affine:       d/dm0k = ggx r_k ; d/dm1k = ggy r_k
+//   homography:   d/dH0k = ggx s r_k ; d/dH1k = ggy s r_k ; d/dH2k = -(ggx X + ggy Y) s^2 r_k (live only)
+// Per-thread partial sums are fp32/fp64 (<= KM_ROWS*C terms), the wave/block reduction and the global
+// accumulation are fp64 (the reference's own fp32 result is only ~1e-1 accurate).
+template <typename T, int CM, int INTERP>
+__global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a) {
+    typedef typename KmTraits<T>::R R;
+    const KmWarpGeom<R>& g = a.g;
+    __shared__ double red[4][9];
+
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = (int)tx * KM_TILE_W + lane;
+    const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
+    const bool want_gm = (a.gmat != nullptr) && (INTERP != KM_INTERP_NEAREST);
+    const bool want_gs = (a.gsrc != nullptr);
+
+    R m[9];
+    {
+        const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+    }
+    const int spad = (g.pad == KM_PAD_FILL) ? KM_PAD_ZEROS : g.pad;
+    const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
+    const T* src_b = a.src + (size_t)b * g.C * src_plane;
+    const T* gout_b = a.gout + (size_t)b * g.C * dst_plane;
+    R* gsrc_b = want_gs ? a.gsrc + (size_t)b * g.C * src_plane : nullptr;
+
+    R gm[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gm[k] = 0;
+
+    if (j < g.w) {
+        const R u = km_base_x<R, CM>(g, j);
+#pragma unroll
+        for (int r = 0; r < KM_ROWS; ++r) {
+            const int i = i_base + r;
+            if (i >= g.h) break;
+            const R v = km_base_y<R, CM>(g, i);
+            KmCoord<R> cd;
+            km_gen_coord<R, CM>(m, u, v, cd);
+            R mx, my, gdx = 1, gdy = 1;
+            R x = km_unnormalize(cd.gx, g.W, g.align, mx);
+            R y = km_unnormalize(cd.gy, g.H, g.align, my);
+            const T* go_px = gout_b + (size_t)i * g.w + j;
+            R gix = 0, giy = 0;
+
+            if (INTERP == KM_INTERP_BILINEAR) {
+                x = km_compute_coord(x, g.W, spad, g.align, gdx);
+                y = km_compute_coord(y, g.H, spad, g.align, gdy);
+                KmBilin<R> t;
+                km_bilinear_setup(x, y, g.W, g.H, t);
+                for (int c = 0; c < g.C; ++c) {
+                    const R go = km_ld(go_px + (size_t)c * dst_plane);
+                    if (want_gs) {
+                        R* gi = gsrc_b + (size_t)c * src_plane;
+                        if (t.b00) km_atomic_add(gi + t.i00, t.w00 * go);
+                        if (t.b01) km_atomic_add(gi + t.i01, t.w01 * go);
+                        if (t.b10) km_atomic_add(gi + t.i10, t.w10 * go);
+                        if (t.b11) km_atomic_add(gi + t.i11, t.w11 * go);
+                    }
+                    if (want_gm) {
+                        const T* img = src_b + (size_t)c * src_plane;
+                        const R f = (g.pad == KM_PAD_FILL) ? a.fill[c] : (R)0;
+                        if (t.b00) { const R s = km_ld(img + t.i00) - f; gix -= s * t.wy1 * go; giy -= s * t.wx1 * go; }
+                        if (t.b01) { const R s = km_ld(img + t.i01) - f; gix += s * t.wy1 * go; giy -= s * t.wx0 * go; }
+                        if (t.b10) { const R s = km_ld(img + t.i10) - f; gix -= s * t.wy0 * go; giy += s * t.wx1 * go; }
+                        if (t.b11) { const R s = km_ld(img + t.i11) - f; gix += s * t.wy0 * go; giy += s * t.wx0 * go; }
+                    }
+                }
+                gix = gix * (mx * gdx);
+                giy = giy * (my * gdy);
+            } else if (INTERP == KM_INTERP_NEAREST) {
+                x = km_compute_coord(x, g.W, spad, g.align, gdx);
+                y = km_compute_coord(y, g.H, spad, g.align, gdy);
+                const R xr = km_rint(x), yr = km_rint(y);
+                const bool inb = (xr >= (R)0) && (xr <= (R)(g.W - 1)) && (yr >= (R)0) && (yr <= (R)(g.H - 1));
+                if (want_gs && inb) {
+                    const int idx = (int)yr * g.W + (int)xr;
+                    for (int c = 0; c < g.C; ++c)
+                        km_atomic_add(gsrc_b + (size_t)c * src_plane + idx, (R)km_ld(go_px + (size_t)c * dst_plane));
+                }
+            } else {
+                const R xf = km_floor(x), yf = km_floor(y);
+                R cx[4], cy[4], dx[4], dy[4];
+                km_cubic_coeffs(x - xf, cx);
+                km_cubic_coeffs(y - yf, cy);
+                km_cubic_coeffs_grad(x - xf, dx);
+                km_cubic_coeffs_grad(y - yf, dy);
+                for (int c = 0; c < g.C; ++c) {
+                    const R go = km_ld(go_px + (size_t)c * dst_plane);
+                    const T* img = src_b + (size_t)c * src_plane;
+                    R* gi = want_gs ? gsrc_b + (size_t)c * src_plane : nullptr;
+                    const R f = (g.pad == KM_PAD_FILL) ? a.fill[c] : (R)0;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int idx = km_tap_index(xf - 1 + q, yf - 1 + rr, g.W, g.H, spad, g.align);
+                            if (idx >= 0) {
+                                if (want_gs) km_atomic_add(gi + idx, go * cx[q] * cy[rr]);
+                                if (want_gm) {
+                                    R s = km_ld(img + idx);
+                                    if (g.pad == KM_PAD_FILL) s -= f;  // fill: taps are unpadded, idx >= 0 <=> in bounds
+                                    gix -= s * dx[q] * cy[rr] * go;
+                                    giy -= s * dy[rr] * cx[q] * go;
+                                }
+                            }
+                        }
+                }
+                gix = gix * mx;
+                giy = giy * my;
+            }
+
+            if (want_gm) {
+                if (CM == KM_COORD_PERSPECTIVE) {
+                    const R inv = (R)1 / cd.den;
+                    const R ax = gix * inv, ay = giy * inv;
+                    const R az = -(gix * cd.gx + giy * cd.gy) * inv;
+                    gm[0] += ax * cd.u; gm[1] += ax * cd.v; gm[2] += ax;
+                    gm[3] += ay * cd.u; gm[4] += ay * cd.v; gm[5] += ay;
+                    gm[6] += az * cd.u; gm[7] += az * cd.v; gm[8] += az;
+                } else if (CM == KM_COORD_AFFINE) {
+                    gm[0] += gix * cd.u; gm[1] += gix * cd.v; gm[2] += gix;
+                    gm[3] += giy * cd.u; gm[4] += giy * cd.v; gm[5] += giy;
+                } else {
+                    const R s = cd.den;
+                    const R ax = gix * s, ay = giy * s;
+                    const R az = cd.live ? -(gix * cd.X + giy * cd.Y) * s * s : (R)0;
+                    gm[0] += ax * cd.u; gm[1] += ax * cd.v; gm[2] += ax;
+                    gm[3] += ay * cd.u; gm[4] += ay * cd.v; gm[5] += ay;
+                    gm[6] += az * cd.u; gm[7] += az * cd.v; gm[8] += az;
+                }
+            }
+        }
+    }
+
+    if (want_gm) {  // block-uniform
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double s = km_wave_sum((double)gm[k]);
+            if (lane == 0) red[wave][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + threadIdx.x, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+template <typename R>
+static void km_fill_linspace(KmWarpGeom<R>& g) {
+    // torch.linspace(lo, hi, n, dtype=R): endpoints rounded to R, step = (hi - lo) / (n - 1) in R
+    const int w = g.w, h = g.h;
+    if (g.align) {
+        g.lin_lo_x = (R)-1.0; g.lin_hi_x = (R)1.0; g.lin_lo_y = (R)-1.0; g.lin_hi_y = (R)1.0;
+    } else {
+        g.lin_lo_x = (R)(-1.0 + 1.0 / w); g.lin_hi_x = (R)(1.0 - 1.0 / w);
+        g.lin_lo_y = (R)(-1.0 + 1.0 / h); g.lin_hi_y = (R)(1.0 - 1.0 / h);
+    }
+    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (R)(w - 1) : (R)0;
+    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (R)(h - 1) : (R)0;
+}
+
+template <typename T, int CM, int INTERP>
+static int km_warp_launch(bool bwd, const KmWarpArgs<T>& a, hipStream_t s) {
+    if (bwd)
+        hipLaunchKernelGGL((km_warp_bwd_kernel<T, CM, INTERP>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_fwd_kernel<T, CM, INTERP>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch(bwd ? "km_warp2d_bwd" : "km_warp2d_fwd");
+}
+
+template <typename T, int CM>
+static int km_warp_dispatch_interp(bool bwd, const KmWarpArgs<T>& a, hipStream_t s) {
+    switch (a.g.interp) {
+        case KM_INTERP_NEAREST: return km_warp_launch<T, CM, KM_INTERP_NEAREST>(bwd, a, s);
+        case KM_INTERP_BILINEAR: return km_warp_launch<T, CM, KM_INTERP_BILINEAR>(bwd, a, s);
+        default: return km_warp_launch<T, CM, KM_INTERP_BICUBIC>(bwd, a, s);
+    }
+}
+
+template <typename T>
+static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, const void* gout, void* gsrc, double* gmat,
+                       int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp,
+                       int pad, int align, const void* fill, hipStream_t s) {
+    typedef typename KmTraits<T>::R R;
+    KmWarpArgs<T> a;
+    a.src = (const T*)src;
+    a.mat = (const R*)mat;
+    a.dst = (T*)dst;
+    a.gout = (const T*)gout;
+    a.gsrc = (R*)gsrc;
+    a.gmat = gmat;
+    a.fill = (const R*)fill;
+    KmWarpGeom<R>& g = a.g;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
+    g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = interp; g.pad = pad; g.align = align;
+    km_fill_linspace(g);
+    a.tiles_x = (uint32_t)((w + KM_TILE_W - 1) / KM_TILE_W);
+    a.tiles_y = (uint32_t)((h + KM_TILE_H - 1) / KM_TILE_H);
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
+    KM_REQUIRE(nb < (1ull << 31), "km_warp2d: grid too large (%llu blocks)", (unsigned long long)nb);
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    switch (coord_mode) {
+        case KM_COORD_PERSPECTIVE: return km_warp_dispatch_interp<T, KM_COORD_PERSPECTIVE>(bwd, a, s);
+        case KM_COORD_AFFINE: return km_warp_dispatch_interp<T, KM_COORD_AFFINE>(bwd, a, s);
+        default: return km_warp_dispatch_interp<T, KM_COORD_HOMOGRAPHY>(bwd, a, s);
+    }
+}
+
+static int km_warp_validate(const char* fn, const void* src, const void* mat, int B, int C, int H, int W, int h, int w,
+                            int B_M, int coord_mode, int interp, int pad, const void* fill, int dtype) {
+    KM_REQUIRE(src && mat, "%s: null pointer", fn);
+    KM_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && h >= 0 && w >= 0, "%s: bad shape B=%d C=%d H=%d W=%d h=%d w=%d", fn, B, C, H, W, h, w);
+    KM_REQUIRE((int64_t)H * W < (1ll << 31) && (int64_t)h * w < (1ll << 31), "%s: image plane exceeds 2^31 elements", fn);
+    KM_REQUIRE(B_M == 1 || B_M == B, "%s: matrix batch %d must be 1 or %d", fn, B_M, B);
+    KM_REQUIRE(coord_mode >= 0 && coord_mode <= 2, "%s: bad coord_mode %d", fn, coord_mode);
+    KM_REQUIRE(interp >= 0 && interp <= 2, "%s: bad interp %d", fn, interp);
+    KM_REQUIRE(pad >= 0 && pad <= 3, "%s: bad pad %d", fn, pad);
+    KM_REQUIRE(pad != KM_PAD_FILL || fill, "%s: pad=fill needs fill values", fn);
+    KM_REQUIRE(dtype >= 0 && dtype <= 3, "%s: bad dtype %d", fn, dtype);
+    return 0;
+}
+
+extern "C" {
+
+// Replaces the eager grid construction + F.grid_sample of
+// kornia/geometry/transform/imgwarp.py:157-174 (warp_perspective), :271-290 (warp_affine),
+// :1541-1546 (homography_warp) and _fill_and_warp :293-320.
+int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int H, int W, int h, int w, int B_M,
+                  int coord_mode, int norm_coords, int interp, int pad, int align, const void* fill, int dtype,
+                  void* stream) {
+    if (km_warp_validate("km_warp2d_fwd", src, mat, B, C, H, W, h, w, B_M, coord_mode, interp, pad, fill, dtype)) return -1;
+    KM_REQUIRE(dst, "km_warp2d_fwd: null dst");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return km_warp_run<float>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+        case KM_F64: return km_warp_run<double>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+        case KM_BF16: return km_warp_run<km_bf16>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+        default: return km_warp_run<km_f16>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+    }
+}
+
+// Replaces autograd of the above: aten::grid_sampler_2d_backward + the reverse of the grid chain.
+// gsrc: (B,C,H,W) in the COMPUTE dtype (fp32 for f32/bf16/f16 data, fp64 for f64), pre-zeroed, nullable.
+// gmat: (B_M,9) fp64 accumulators, pre-zeroed, nullable.
+int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
+                  int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align,
+                  const void* fill, int dtype, void* stream) {
+    if (km_warp_validate("km_warp2d_bwd", src, mat, B, C, H, W, h, w, B_M, coord_mode, interp, pad, fill, dtype)) return -1;
+    KM_REQUIRE(gout, "km_warp2d_bwd: null gout");
+    if (!gsrc && !gmat) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return km_warp_run<float>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+        case KM_F64: return km_warp_run<double>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+        case KM_BF16: return km_warp_run<km_bf16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+        default: return km_warp_run<km_f16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+    }
+}
+
+}  // extern "C"

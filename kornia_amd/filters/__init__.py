@@ -1,0 +1,17 @@
+from .filter import filter2d, filter2d_separable
+from .gaussian import GaussianBlur2d, gaussian_blur2d
+from .kernels import (
+    gaussian,
+    get_gaussian_kernel1d,
+    get_gaussian_kernel2d,
+    get_spatial_gradient_kernel2d,
+    normalize_kernel2d,
+)
+from .sobel import Sobel, SpatialGradient, sobel, spatial_gradient
+
+# reference aliases (kornia/filters/filter.py:460-548)
+correlate2d = filter2d
+
+
+def convolve2d(input, kernel, border_type="reflect", normalized=False, padding="same"):
+    return filter2d(input, kernel, border_type, normalized, padding, behaviour="conv")

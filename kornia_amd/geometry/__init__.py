@@ -1,0 +1,11 @@
+from . import conversions, grid, linalg, transform
+from .conversions import (
+    convert_affinematrix_to_homography,
+    convert_points_from_homogeneous,
+    convert_points_to_homogeneous,
+    normal_transform_pixel,
+    normalize_homography,
+)
+from .grid import create_meshgrid
+from .linalg import transform_points
+from .transform import HomographyWarper, homography_warp, warp_affine, warp_grid, warp_perspective

@@ -1,0 +1,244 @@
+"""warp_perspective / warp_affine / homography_warp / warp_grid on the gfx950 kernels.
+
+Same signatures, defaults, argument meaning and error behaviour as the reference
+(kornia/geometry/transform/imgwarp.py:69-174, :177-290, :323-353, :1476-1549).  What differs is the
+execution: one HIP launch for the 3x3 chain and one for coordinate generation + sampling, instead
+of ~25 elementwise launches that build a (B,h,w,2) grid in HBM followed by ``F.grid_sample``; the
+backward is one launch for both gradients plus the tiny chain adjoint.
+
+There is no PyTorch/CPU fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+
+from ... import _native as N
+from ..linalg import transform_points
+
+__all__ = ["homography_warp", "warp_affine", "warp_grid", "warp_perspective"]
+
+COORD_PERSPECTIVE, COORD_AFFINE, COORD_HOMOGRAPHY = 0, 1, 2
+_INTERP = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+_PAD = {"zeros": 0, "border": 1, "reflection": 2, "fill": 3}
+
+
+class _WarpCfg(NamedTuple):
+    dsize: tuple
+    coord_mode: int
+    norm_coords: int
+    interp: int
+    pad: int
+    align: int
+
+
+def _mode_codes(mode: str, padding_mode: str) -> tuple[int, int]:
+    # F.grid_sample's own error messages for unknown modes
+    if mode not in _INTERP:
+        raise ValueError(
+            f"nn.functional.grid_sample(): expected mode to be 'bilinear', 'nearest' or 'bicubic', but got: '{mode}'"
+        )
+    if padding_mode not in _PAD:
+        raise ValueError(
+            "nn.functional.grid_sample(): expected padding_mode to be 'zeros', 'border', or 'reflection', "
+            f"but got: '{padding_mode}'"
+        )
+    return _INTERP[mode], _PAD[padding_mode]
+
+
+class _Warp2dFunction(torch.autograd.Function):
+    """src (B,C,H,W), mat: pixel matrix (B_M,3,3)/(B_M,2,3) [perspective/affine] or normalised
+    dst->src homography (B_M,3,3) [homography]; fill: (C,) compute-dtype tensor or None."""
+
+    @staticmethod
+    def forward(ctx, src: torch.Tensor, mat: torch.Tensor, fill: Optional[torch.Tensor], cfg: _WarpCfg):
+        lib = N.lib()
+        dev = src.device
+        cdt = N.compute_dtype(src.dtype)
+        x = src.detach().contiguous()
+        Mc = mat.detach().to(device=dev, dtype=cdt).contiguous()
+        B, C, H, W = x.shape
+        h, w = cfg.dsize
+        B_M = Mc.shape[0]
+        stream = N.stream_ptr(dev)
+        out = torch.empty(B, C, h, w, device=dev, dtype=src.dtype)
+        with torch.cuda.device(dev):
+            if cfg.coord_mode == COORD_HOMOGRAPHY:
+                m = Mc.view(B_M, 9)
+            else:
+                m = torch.empty(B_M, 9, device=dev, dtype=cdt)
+                N.check(lib.km_homography_chain_fwd(Mc.data_ptr(), Mc.shape[1], None, m.data_ptr(), B_M, H, W, h, w,
+                                                    N.dtype_code(cdt), stream), "km_homography_chain_fwd")
+            N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), out.data_ptr(), B, C, H, W, h, w, B_M, cfg.coord_mode,
+                                      cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill), N.dtype_code(src.dtype),
+                                      stream), "km_warp2d_fwd")
+        ctx.save_for_backward(x, Mc, m, fill)
+        ctx.cfg = cfg
+        ctx.mat_dtype = mat.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: torch.Tensor):
+        x, Mc, m, fill = ctx.saved_tensors
+        cfg: _WarpCfg = ctx.cfg
+        lib = N.lib()
+        dev = x.device
+        cdt = Mc.dtype
+        B, C, H, W = x.shape
+        h, w = cfg.dsize
+        B_M = Mc.shape[0]
+        need_src, need_mat = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = gout.detach().to(x.dtype).contiguous()
+        stream = N.stream_ptr(dev)
+        gsrc = torch.zeros(B, C, H, W, device=dev, dtype=cdt) if need_src else None
+        gm = torch.zeros(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
+        gmat = None
+        with torch.cuda.device(dev):
+            N.check(lib.km_warp2d_bwd(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
+                                      B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),
+                                      N.dtype_code(x.dtype), stream), "km_warp2d_bwd")
+            if need_mat:
+                if cfg.coord_mode == COORD_HOMOGRAPHY:
+                    gmat = gm.view(B_M, 3, 3).to(ctx.mat_dtype)
+                else:
+                    gM = torch.empty_like(Mc)
+                    N.check(lib.km_homography_chain_bwd(Mc.data_ptr(), Mc.shape[1], gm.data_ptr(), gM.data_ptr(), B_M, H,
+                                                        W, h, w, N.dtype_code(cdt), stream), "km_homography_chain_bwd")
+                    gmat = gM.to(ctx.mat_dtype)
+        if gsrc is not None and gsrc.dtype != x.dtype:
+            gsrc = gsrc.to(x.dtype)
+        return gsrc, gmat, None, None
+
+
+def _prepare_fill(fill_value: torch.Tensor, C: int, device, cdt) -> torch.Tensor:
+    """imgwarp.py:308-313: scalar or (1,)/(C,) fill broadcast over channels."""
+    f = fill_value.detach().to(device=device, dtype=cdt).reshape(-1)
+    if f.numel() == 1:
+        f = f.expand(C)
+    elif f.numel() != C:
+        raise RuntimeError(
+            f"The size of tensor a ({C}) must match the size of tensor b ({f.numel()}) at non-singleton dimension 1"
+        )
+    return f.contiguous()
+
+
+def _warp(src, mat, dsize, coord_mode, norm_coords, mode, padding_mode, align_corners, fill_value):
+    N.require_device(src, "src")
+    interp, pad = _mode_codes(mode, padding_mode)
+    B, C = src.shape[0], src.shape[1]
+    B_M = mat.shape[0]
+    if not (B_M == B or (B_M == 1 and coord_mode == COORD_AFFINE)):
+        # what F.grid_sample reports when the (B_M,h,w,2) grid meets a (B,...) input
+        raise RuntimeError(
+            f"grid_sampler(): expected grid and input to have same batch size, but got input with sizes {list(src.shape)} "
+            f"and grid with sizes {[B_M, int(dsize[0]), int(dsize[1]), 2]}"
+        )
+    fill = None
+    if pad == _PAD["fill"]:
+        fill = _prepare_fill(fill_value, C, src.device, N.compute_dtype(src.dtype))
+    cfg = _WarpCfg((int(dsize[0]), int(dsize[1])), coord_mode, int(bool(norm_coords)), interp, pad, int(bool(align_corners)))
+    return _Warp2dFunction.apply(src, mat, fill, cfg)
+
+
+def warp_perspective(
+    src: torch.Tensor,
+    M: torch.Tensor,
+    dsize: tuple[int, int],
+    mode: str = "bilinear",
+    padding_mode: str = "zeros",
+    align_corners: bool = True,
+    fill_value: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    r"""Warp ``src`` (B,C,H,W) with the source->destination **pixel** homography ``M`` (B,3,3):
+    ``dst(x, y) = src(M^-1 (x, y, 1))``, output size ``dsize = (h, w)``.
+
+    ``mode``: ``'bilinear' | 'nearest' | 'bicubic'``; ``padding_mode``: ``'zeros' | 'border' |
+    'reflection' | 'fill'`` (``fill_value``: tensor of shape (3,), RGB only).  Differentiable wrt
+    ``src`` and ``M``.
+    """
+    if not isinstance(src, torch.Tensor):
+        raise TypeError(f"Input src type is not a torch.Tensor. Got {type(src)}")
+    if not isinstance(M, torch.Tensor):
+        raise TypeError(f"Input M type is not a torch.Tensor. Got {type(M)}")
+    if not len(src.shape) == 4:
+        raise ValueError(f"Input src must be a BxCxHxW torch.Tensor. Got {src.shape}")
+    if not (len(M.shape) == 3 and M.shape[-2:] == (3, 3)):
+        raise ValueError(f"Input M must be a Bx3x3 torch.Tensor. Got {M.shape}")
+    if fill_value is None:
+        fill_value = torch.zeros(3)
+    if padding_mode == "fill" and fill_value.shape != torch.Size([3]):
+        raise ValueError(f"Padding_tensor only supported for 3 channels. Got {fill_value.shape}")
+    return _warp(src, M, dsize, COORD_PERSPECTIVE, 1, mode, padding_mode, align_corners, fill_value)
+
+
+def warp_affine(
+    src: torch.Tensor,
+    M: torch.Tensor,
+    dsize: tuple[int, int],
+    mode: str = "bilinear",
+    padding_mode: str = "zeros",
+    align_corners: bool = True,
+    fill_value: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    r"""Warp ``src`` (B,C,H,W) with the source->destination **pixel** affine matrix ``M`` (B,2,3)
+    (a (1,2,3) matrix is shared by the whole batch).  Same modes as :func:`warp_perspective`;
+    ``fill_value`` has shape (C,) or (1,)."""
+    if not isinstance(src, torch.Tensor):
+        raise TypeError(f"Input src type is not a torch.Tensor. Got {type(src)}")
+    if not isinstance(M, torch.Tensor):
+        raise TypeError(f"Input M type is not a torch.Tensor. Got {type(M)}")
+    if not len(src.shape) == 4:
+        raise ValueError(f"Input src must be a BxCxHxW torch.Tensor. Got {src.shape}")
+    if not (len(M.shape) == 3 or M.shape[-2:] == (2, 3)):
+        raise ValueError(f"Input M must be a Bx2x3 torch.Tensor. Got {M.shape}")
+    # the reference's loose check above lets a wrong-shaped M through to
+    # convert_affinematrix_to_homography, which raises this (conversions.py:375-376)
+    if not (len(M.shape) == 3 and M.shape[-2:] == (2, 3)):
+        raise ValueError(f"Input matrix must be a Bx2x3 tensor. Got {M.shape}")
+    if padding_mode == "fill" and fill_value is None:
+        fill_value = torch.zeros(src.shape[1], device=src.device, dtype=src.dtype)
+    return _warp(src, M, dsize, COORD_AFFINE, 1, mode, padding_mode, align_corners, fill_value)
+
+
+def warp_grid(grid: torch.Tensor, src_homo_dst: torch.Tensor) -> torch.Tensor:
+    """Transform a (1,H,W,2) (or (N,H,W,2)) coordinate grid by destination->source homographies
+    (N,3,3) / (N,1,3,3); returns (N,H,W,2)."""
+    batch_size = src_homo_dst.size(0)
+    _, height, width, _ = grid.size()
+    grid = grid.expand(batch_size, -1, -1, -1)
+    if len(src_homo_dst.shape) == 3:
+        src_homo_dst = src_homo_dst.view(batch_size, 1, 3, 3)
+    flow = transform_points(src_homo_dst, grid.to(src_homo_dst))
+    return flow.view(batch_size, height, width, 2)
+
+
+def homography_warp(
+    patch_src: torch.Tensor,
+    src_homo_dst: torch.Tensor,
+    dsize: tuple[int, int],
+    mode: str = "bilinear",
+    padding_mode: str = "zeros",
+    align_corners: bool = False,
+    normalized_coordinates: bool = True,
+    normalized_homography: bool = True,
+) -> torch.Tensor:
+    r"""Warp (N,C,H,W) patches by (N,3,3) homographies.
+
+    ``normalized_homography=True`` (default): ``src_homo_dst`` maps destination->source in
+    normalised [-1, 1] coordinates (pixel indices when ``normalized_coordinates=False``) and is
+    applied to the base grid directly.  ``normalized_homography=False``: it is a source->destination
+    pixel homography handled exactly like :func:`warp_perspective` with ``mode='bilinear'`` and
+    ``align_corners=True``.
+    """
+    if not src_homo_dst.device == patch_src.device:
+        raise TypeError(
+            f"Patch and homography must be on the same device. Got patch.device: {patch_src.device} "
+            f"src_H_dst.device: {src_homo_dst.device}."
+        )
+    if normalized_homography:
+        if not (len(src_homo_dst.shape) == 3 and src_homo_dst.shape[-2:] == (3, 3)):
+            raise ValueError(f"Input src_homo_dst must be a Nx3x3 torch.Tensor. Got {src_homo_dst.shape}")
+        return _warp(patch_src, src_homo_dst, dsize, COORD_HOMOGRAPHY, normalized_coordinates, mode, padding_mode,
+                     align_corners, None)
+    return warp_perspective(patch_src, src_homo_dst, dsize, mode="bilinear", padding_mode=padding_mode, align_corners=True)

@@ -1,0 +1,194 @@
+"""GPU parity of the filter path (filter2d, filter2d_separable, gaussian_blur2d, spatial_gradient,
+sobel, transform_points) against the CPU oracle, through the kornia-compatible API / C ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BORDERS = ["constant", "reflect", "replicate", "circular"]
+
+
+def _x(B=4, C=3, H=41, W=70, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, C, H, W, generator=g), g
+
+
+@pytest.mark.parametrize("behaviour", ["corr", "conv"])
+@pytest.mark.parametrize("padding", ["same", "valid"])
+@pytest.mark.parametrize("kshape", [(1, 3, 3), (1, 5, 6), (1, 2, 2), (4, 3, 5), (2, 4, 3), (1, 1, 7)])
+@pytest.mark.parametrize("border", BORDERS)
+def test_filter2d_forward_bit_exact(oracle, border, kshape, padding, behaviour):
+    import kornia_amd as K
+
+    x, g = _x()
+    k = torch.rand(*kshape, generator=g)
+    ref = oracle.filter2d(x, k, border, False, padding, behaviour)
+    out = K.filter2d(x.cuda(), k.cuda(), border, False, padding, behaviour).cpu()
+    assert out.shape == ref.shape
+    assert torch.equal(out, ref), f"max |d| = {(out - ref).abs().max().item():.3e}"
+    # normalized=True: the L1 norm is a torch reduction evaluated on the device (summation order differs
+    # from the CPU's by an ulp), so the taps - not the filter - differ in the last bit
+    refn = oracle.filter2d(x, k, border, True, padding, behaviour)
+    outn = K.filter2d(x.cuda(), k.cuda(), border, True, padding, behaviour).cpu()
+    assert torch.allclose(outn, refn, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("padding", ["same", "valid"])
+@pytest.mark.parametrize("kshape", [(1, 3, 3), (1, 5, 6), (1, 2, 2), (4, 3, 5), (2, 4, 3)])
+@pytest.mark.parametrize("border", BORDERS)
+def test_filter2d_backward(oracle, border, kshape, padding):
+    import kornia_amd as K
+
+    x, g = _x()
+    k = torch.rand(*kshape, generator=g)
+    xg, kg = x.cuda().requires_grad_(), k.cuda().requires_grad_()
+    y = K.filter2d(xg, kg, border, False, padding)
+    go = torch.rand(y.shape, generator=g)
+    y.backward(go.cuda())
+    gx_o, gk_o = oracle.filter2d_backward(go, x, k, border, False, padding)
+    assert torch.allclose(xg.grad.cpu(), gx_o, atol=1e-5, rtol=1e-5), (xg.grad.cpu() - gx_o).abs().max()
+    assert torch.allclose(kg.grad.cpu(), gk_o, atol=1e-2, rtol=1e-4), (kg.grad.cpu() - gk_o).abs().max()
+
+
+@pytest.mark.parametrize("padding", ["same", "valid"])
+@pytest.mark.parametrize("ks", [(5, 5), (3, 7), (1, 9), (4, 2), (11, 3)])
+@pytest.mark.parametrize("Bk", [1, 4, 2])
+@pytest.mark.parametrize("border", BORDERS)
+def test_filter2d_separable_fused(oracle, border, Bk, ks, padding):
+    import kornia_amd as K
+
+    x, g = _x()
+    kH, kW = ks
+    kx, ky = torch.rand(Bk, kW, generator=g), torch.rand(Bk, kH, generator=g)
+    ref = oracle.filter2d_separable(x, kx, ky, border, False, padding)
+    xg = x.cuda().requires_grad_()
+    out = K.filter2d_separable(xg, kx.cuda(), ky.cuda(), border, False, padding)
+    assert torch.equal(out.detach().cpu(), ref), f"max |d| = {(out.detach().cpu() - ref).abs().max().item():.3e}"
+    go = torch.rand(ref.shape, generator=g)
+    out.backward(go.cuda())
+    gx_o = oracle.filter2d_separable_backward(go, x, kx, ky, border, False, padding)
+    assert torch.allclose(xg.grad.cpu(), gx_o, atol=1e-5, rtol=1e-5), (xg.grad.cpu() - gx_o).abs().max()
+
+
+def test_filter2d_separable_kernel_grads_use_two_pass(oracle):
+    import kornia_amd as K
+
+    x, g = _x(B=2, C=2, H=12, W=15)
+    kx = torch.rand(1, 5, generator=g).cuda().requires_grad_()
+    ky = torch.rand(1, 3, generator=g).cuda().requires_grad_()
+    y = K.filter2d_separable(x.cuda(), kx, ky)
+    y.sum().backward()
+    assert kx.grad is not None and ky.grad is not None and torch.isfinite(kx.grad).all()
+
+
+@pytest.mark.parametrize("border", BORDERS)
+def test_gaussian_blur2d(oracle, border):
+    import kornia_amd as K
+
+    x, g = _x()
+    ref = oracle.gaussian_blur2d(x, (5, 5), (1.5, 1.5), border)
+    assert torch.equal(K.gaussian_blur2d(x.cuda(), (5, 5), (1.5, 1.5), border).cpu(), ref)
+    assert torch.equal(K.GaussianBlur2d(5, (1.5, 1.5), border)(x.cuda()).cpu(), ref)
+    ref2 = oracle.gaussian_blur2d(x, (5, 5), (1.5, 1.5), border, separable=False)
+    out2 = K.gaussian_blur2d(x.cuda(), (5, 5), (1.5, 1.5), border, separable=False).cpu()
+    assert torch.allclose(out2, ref2, atol=2e-7)  # 2-D taps: exp() evaluated on the GPU vs CPU (1 ulp)
+    sig = torch.rand(4, 2, generator=g) + 0.5
+    ref3 = oracle.gaussian_blur2d(x, (3, 7), sig, border)
+    out3 = K.gaussian_blur2d(x.cuda(), (3, 7), sig.cuda(), border).cpu()
+    assert torch.allclose(out3, ref3, atol=3e-7)
+    sig2 = torch.rand(2, 2, generator=g) + 0.5  # Bk = 2 divides B = 4 -> kernel index b % 2
+    assert torch.allclose(K.gaussian_blur2d(x.cuda(), (3, 3), sig2.cuda(), border).cpu(), oracle.gaussian_blur2d(x, (3, 3), sig2, border), atol=3e-7)
+
+
+def test_gaussian_blur2d_backward_and_errors(oracle):
+    import kornia_amd as K
+    from kornia_amd.core import BaseError, ShapeError, TypeCheckError
+
+    x, g = _x()
+    xg = x.cuda().requires_grad_()
+    y = K.gaussian_blur2d(xg, (5, 5), (1.5, 1.5))
+    go = torch.rand(y.shape, generator=g)
+    y.backward(go.cuda())
+    assert torch.allclose(xg.grad.cpu(), oracle.gaussian_blur2d_backward(go, x, (5, 5), (1.5, 1.5)), atol=1e-5)
+    with pytest.raises(BaseError, match="sigma must be positive"):
+        K.gaussian_blur2d(x.cuda(), (5, 5), (0.0, 1.0))
+    with pytest.raises(BaseError, match="sigma must be positive"):
+        K.gaussian_blur2d(x.cuda(), (5, 5), torch.tensor([[1.0, -1.0]]).cuda())
+    with pytest.raises(BaseError, match="Kernel size must be"):
+        K.gaussian_blur2d(x.cuda(), (4, 5), (1.0, 1.0))
+    with pytest.raises(ShapeError):
+        K.gaussian_blur2d(x.cuda()[0], (5, 5), (1.0, 1.0))
+    with pytest.raises(TypeCheckError):
+        K.filter2d([1, 2], torch.ones(1, 3, 3))
+    with pytest.raises(BaseError, match="Invalid border, a. Ex"):
+        K.filter2d(x.cuda(), torch.ones(1, 3, 3).cuda(), border_type="a")
+
+
+@pytest.mark.parametrize("normalized", [True, False])
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("mode", ["sobel", "diff"])
+def test_spatial_gradient(oracle, mode, order, normalized):
+    import kornia_amd as K
+
+    x, g = _x()
+    ref = oracle.spatial_gradient(x, mode, order, normalized)
+    xg = x.cuda().requires_grad_()
+    out = K.spatial_gradient(xg, mode, order, normalized)
+    assert out.shape == ref.shape and out.is_contiguous()
+    assert torch.equal(out.detach().cpu(), ref)
+    go = torch.rand(ref.shape, generator=g)
+    out.backward(go.cuda())
+    assert torch.allclose(xg.grad.cpu(), oracle.spatial_gradient_backward(go, x, mode, order, normalized), atol=1e-4 if not normalized else 1e-5)
+
+
+def test_sobel(oracle):
+    import kornia_amd as K
+
+    x, g = _x()
+    ref = oracle.sobel(x)
+    assert torch.equal(K.sobel(x.cuda()).cpu(), ref)
+    assert torch.equal(K.Sobel()(x.cuda()).cpu(), ref)
+    xg = x.cuda().requires_grad_()
+    out = K.sobel(xg)
+    assert torch.allclose(out.detach().cpu(), ref, atol=1e-6)
+    out.sum().backward()
+    assert torch.isfinite(xg.grad).all()
+
+
+def test_transform_points(oracle):
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(3)
+    for D in (2, 3):
+        P = torch.rand(4, 1000, D, generator=g) * 2 - 1
+        T = torch.eye(D + 1)[None] + 0.1 * torch.randn(4, D + 1, D + 1, generator=g)
+        assert torch.equal(K.transform_points(T.cuda(), P.cuda()).cpu(), oracle.transform_points(T, P))
+        assert torch.equal(K.transform_points(T[:1].cuda(), P.cuda()).cpu(), oracle.transform_points(T[:1], P))
+        Td, Pd = T.double().cuda().requires_grad_(), P[:, :5].double().cuda().requires_grad_()
+        assert torch.autograd.gradcheck(K.transform_points, (Td, Pd), nondet_tol=1e-8)
+    assert K.transform_points(torch.eye(3)[None].cuda(), torch.zeros(1, 0, 2).cuda()).shape == (1, 0, 2)
+    with pytest.raises(ValueError):
+        K.transform_points(torch.eye(3)[None].expand(2, 3, 3).cuda(), torch.zeros(3, 4, 2).cuda())
+
+
+def test_filters_fp64_gradcheck():
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 2, 9, 11, generator=g).double().cuda().requires_grad_()
+    k = torch.rand(1, 3, 4, generator=g).double().cuda().requires_grad_()
+    for border in BORDERS:
+        assert torch.autograd.gradcheck(lambda a, b: K.filter2d(a, b, border), (x, k), nondet_tol=1e-8, fast_mode=True)
+        assert torch.autograd.gradcheck(lambda a: K.gaussian_blur2d(a, (5, 3), (1.2, 0.8), border), (x,), fast_mode=True)
+    assert torch.autograd.gradcheck(lambda a: K.spatial_gradient(a, "sobel", 2), (x,), fast_mode=True)
+    assert torch.autograd.gradcheck(lambda a: K.sobel(a), (x,), fast_mode=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+def test_half_precision_blur(oracle, dtype, tol):
+    import kornia_amd as K
+
+    x, _ = _x()
+    out = K.gaussian_blur2d(x.to(dtype).cuda(), (5, 5), (1.5, 1.5)).float().cpu()
+    ref = oracle.gaussian_blur2d(x.to(dtype).float(), (5, 5), (1.5, 1.5))
+    assert (out - ref).abs().max().item() <= tol

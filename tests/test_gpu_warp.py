@@ -1,0 +1,201 @@
+"""GPU parity of the warp path against the CPU oracle (called through the kornia-compatible API,
+i.e. through the C ABI).  fp32 forward results are required to be BIT-IDENTICAL to the oracle, which
+itself is bit-identical to the reference's CPU path (tests/golden, test_oracle_golden.py)."""
+import pytest
+import torch
+
+from _util import flagship_homographies, rotation_affines
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["bilinear", "nearest", "bicubic"]
+PADS = ["zeros", "border", "reflection", "fill"]
+
+
+def _inputs(B=3, C=3, H=37, W=53, h=29, w=45, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, C, H, W, generator=g)
+    M = flagship_homographies(B, H, W, h, w, g, jitter=4.0)
+    A = rotation_affines(B, H, W, g)
+    Hn = torch.eye(3)[None] + 0.05 * torch.randn(B, 3, 3, generator=g)
+    go = torch.rand(B, C, h, w, generator=g)
+    return x, M, A, Hn, go, (h, w)
+
+
+def _fill(pad, n=3):
+    return torch.tensor([0.1, 0.5, 0.9][:n]) if pad == "fill" else None
+
+
+def test_chain_bit_exact(oracle):
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(1)
+    M = flagship_homographies(64, 512, 512, 384, 640, g)
+    A_o, m_o = oracle.homography_chain(M, (512, 512), (384, 640))
+    A = K.normalize_homography(M.cuda(), (512, 512), (384, 640)).cpu()
+    assert torch.equal(A, A_o)
+    from kornia_amd.geometry.conversions import _ChainFunction
+
+    m = _ChainFunction.apply(M.cuda(), (512, 512), (384, 640), True).cpu()
+    assert torch.equal(m, m_o)
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("pad", PADS)
+@pytest.mark.parametrize("mode", MODES)
+def test_warp_perspective_forward_bit_exact(oracle, mode, pad, align):
+    import kornia_amd as K
+
+    x, M, _, _, _, ds = _inputs()
+    ref = oracle.warp_perspective(x, M, ds, mode, pad, align, _fill(pad))
+    out = K.warp_perspective(x.cuda(), M.cuda(), ds, mode, pad, align, _fill(pad)).cpu()
+    assert out.shape == ref.shape
+    assert torch.equal(out, ref), f"max |d| = {(out - ref).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("pad", PADS)
+@pytest.mark.parametrize("mode", MODES)
+def test_warp_affine_forward_bit_exact(oracle, mode, pad, align):
+    import kornia_amd as K
+
+    x, _, A, _, _, ds = _inputs()
+    ref = oracle.warp_affine(x, A, ds, mode, pad, align, _fill(pad))
+    out = K.warp_affine(x.cuda(), A.cuda(), ds, mode, pad, align, _fill(pad)).cpu()
+    assert torch.equal(out, ref), f"max |d| = {(out - ref).abs().max().item():.3e}"
+
+
+def test_warp_affine_shared_matrix(oracle):
+    import kornia_amd as K
+
+    x, _, A, _, _, ds = _inputs()
+    ref = oracle.warp_affine(x, A[:1], ds)
+    out = K.warp_affine(x.cuda(), A[:1].cuda(), ds).cpu()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("norm", [True, False])
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("pad", ["zeros", "border", "reflection"])
+@pytest.mark.parametrize("mode", MODES)
+def test_homography_warp_forward_bit_exact(oracle, mode, pad, align, norm):
+    import kornia_amd as K
+
+    x, _, _, Hn, _, ds = _inputs()
+    if not norm:  # pixel-index base grid: use a homography that keeps pixel coordinates in range
+        Hn = torch.eye(3)[None] + 0.01 * (Hn - torch.eye(3)[None])
+        Hn[:, :2, 2] = Hn[:, :2, 2] / 50.0 - 1.0
+        Hn[:, :2, :2] = Hn[:, :2, :2] / 25.0
+    ref = oracle.homography_warp(x, Hn, ds, mode, pad, align, norm)
+    out = K.homography_warp(x.cuda(), Hn.cuda(), ds, mode, pad, align, norm).cpu()
+    assert torch.equal(out, ref), f"max |d| = {(out - ref).abs().max().item():.3e}"
+
+
+def _check_grads(gs, gM, gs_o, gM64, tag):
+    # grad_src: sums of <= a handful of products of O(1) values -> 1e-5 absolute
+    assert torch.allclose(gs, gs_o, atol=1e-5, rtol=1e-5), f"{tag}: grad_src max |d| {(gs - gs_o).abs().max().item():.3e}"
+    # matrix gradient: compared with the fp64 oracle, relative to the largest entry (hard part 3)
+    scale = gM64.abs().max().clamp_min(1e-12)
+    err = ((gM.double() - gM64).abs().max() / scale).item()
+    assert err < 2e-4, f"{tag}: grad_M rel err {err:.3e}"
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("pad", PADS)
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_warp_perspective_backward(oracle, mode, pad, align):
+    import kornia_amd as K
+
+    x, M, _, _, go, ds = _inputs()
+    xg, Mg = x.cuda().requires_grad_(), M.cuda().requires_grad_()
+    K.warp_perspective(xg, Mg, ds, mode, pad, align, _fill(pad)).backward(go.cuda())
+    gs_o, _ = oracle.warp_perspective_backward(go, x, M, ds, mode, pad, align, _fill(pad))
+    f64 = None if pad != "fill" else _fill(pad).double()
+    _, gM64 = oracle.warp_perspective_backward(go.double(), x.double(), M.double(), ds, mode, pad, align, f64)
+    _check_grads(xg.grad.cpu(), Mg.grad.cpu(), gs_o, gM64, f"persp {mode} {pad} {align}")
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("pad", ["zeros", "reflection", "fill"])
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_warp_affine_backward(oracle, mode, pad, align):
+    import kornia_amd as K
+
+    x, _, A, _, go, ds = _inputs()
+    xg, Ag = x.cuda().requires_grad_(), A.cuda().requires_grad_()
+    K.warp_affine(xg, Ag, ds, mode, pad, align, _fill(pad)).backward(go.cuda())
+    gs_o, _ = oracle.warp_affine_backward(go, x, A, ds, mode, pad, align, _fill(pad))
+    f64 = None if pad != "fill" else _fill(pad).double()
+    _, gA64 = oracle.warp_affine_backward(go.double(), x.double(), A.double(), ds, mode, pad, align, f64)
+    _check_grads(xg.grad.cpu(), Ag.grad.cpu(), gs_o, gA64, f"affine {mode} {pad} {align}")
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_homography_warp_backward(oracle, mode, align):
+    import kornia_amd as K
+
+    x, _, _, Hn, go, ds = _inputs()
+    xg, Hg = x.cuda().requires_grad_(), Hn.cuda().requires_grad_()
+    K.homography_warp(xg, Hg, ds, mode, "zeros", align).backward(go.cuda())
+    gs_o, _ = oracle.homography_warp_backward(go, x, Hn, ds, mode, "zeros", align)
+    _, gH64 = oracle.homography_warp_backward(go.double(), x.double(), Hn.double(), ds, mode, "zeros", align)
+    _check_grads(xg.grad.cpu(), Hg.grad.cpu(), gs_o, gH64, f"homog {mode} {align}")
+
+
+def test_nearest_backward(oracle):
+    import kornia_amd as K
+
+    x, M, _, _, go, ds = _inputs()
+    xg = x.cuda().requires_grad_()
+    K.warp_perspective(xg, M.cuda(), ds, "nearest").backward(go.cuda())
+    gs_o, _ = oracle.warp_perspective_backward(go, x, M, ds, "nearest")
+    assert torch.allclose(xg.grad.cpu(), gs_o, atol=1e-5)
+
+
+def test_fp64_matches_oracle_and_gradcheck(oracle):
+    import kornia_amd as K
+
+    x, M, A, Hn, go, ds = _inputs(B=2, C=2, H=9, W=11, h=7, w=8)
+    out = K.warp_perspective(x.double().cuda(), M.double().cuda(), ds).cpu()
+    ref = oracle.warp_perspective(x.double(), M.double(), ds)
+    assert torch.allclose(out, ref, atol=1e-13)
+    xd = x.double().cuda().requires_grad_()
+    Md = M.double().cuda().requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b: K.warp_perspective(a, b, ds), (xd, Md), nondet_tol=1e-8, fast_mode=True)
+    Ad = A[:2].double().cuda().requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b: K.warp_affine(a, b, ds, "bicubic", "border"), (xd, Ad), nondet_tol=1e-8, fast_mode=True)
+    Hd = Hn[:2].double().cuda().requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b: K.homography_warp(a, b, ds), (xd, Hd), nondet_tol=1e-8, fast_mode=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+def test_half_precision_against_fp32_oracle(oracle, dtype, tol):
+    """bf16/f16 parity is defined against the fp32 oracle on the SAME (rounded) inputs, result rounded to
+    the storage dtype (the reference computes its grid in bf16, which is not a usable pin)."""
+    import kornia_amd as K
+
+    x, M, _, _, _, ds = _inputs()
+    xr = x.to(dtype).float()
+    ref = oracle.warp_perspective(xr, M, ds)
+    out = K.warp_perspective(x.to(dtype).cuda(), M.cuda(), ds).float().cpu()
+    assert (out - ref).abs().max().item() <= tol
+    assert torch.equal(out, ref.to(dtype).float())  # in fact: exactly the rounded fp32 result
+
+
+def test_identity_is_exact_and_errors():
+    import kornia_amd as K
+
+    x = torch.rand(2, 3, 16, 20).cuda()
+    eye = torch.eye(3)[None].expand(2, 3, 3).contiguous().cuda()
+    assert torch.allclose(K.warp_perspective(x, eye, (16, 20)), x, atol=1e-6)
+    with pytest.raises(TypeError):
+        K.warp_perspective(x, [1, 2, 3], (4, 4))
+    with pytest.raises(ValueError):
+        K.warp_perspective(x[0], eye, (4, 4))
+    with pytest.raises(ValueError):
+        K.warp_perspective(x, eye[:, :2], (4, 4))
+    with pytest.raises(ValueError):
+        K.warp_affine(x, eye, (4, 4))
+    with pytest.raises(K.NativeLibraryError):
+        K.warp_perspective(x.cpu(), eye.cpu(), (4, 4))
