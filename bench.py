@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mpix/s of one fwd+bwd step of
+
+    y = gaussian_blur2d(warp_perspective(x, M, (512, 512)), (5, 5), (1.5, 1.5));  y.backward(grad_out)
+
+with x (B,3,512,512) fp32 requiring grad and M (B,3,3) requiring grad - BASELINE.json configs[1]
+(B = 256 per GPU; inputs follow benchmarks/geometry/flagship.py:89-107 of the reference:
+uniform-noise images, image quad perturbed by 8*randn).  Batches shard across GPUs with no
+data-path collective (weak scaling: every rank owns B images).
+
+    python bench.py                      # 1 GPU, prints ONE JSON line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+The JSON line carries `roofline` (dominant kernel, HIP-event timed on the launch stream, algorithmic
+bytes from SURVEY.md 8(d)) and `cpu_baseline` (the reference's op sequence on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=256, help="images per GPU")
+    p.add_argument("--size", type=int, default=512)
+    p.add_argument("--channels", type=int, default=3)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-batch", type=int, default=16, help="images in the CPU baseline sample")
+    p.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the outputs (reported separately)")
+    return p.parse_args()
+
+
+def flagship_homographies(B, H, W, gen):
+    """benchmarks/geometry/flagship.py:89-107: M = get_perspective_transform(quad, quad + 8*randn)."""
+    src = torch.tensor([[0.0, 0.0], [W - 1.0, 0.0], [W - 1.0, H - 1.0], [0.0, H - 1.0]]).expand(B, 4, 2).double()
+    dst = src + 8.0 * torch.randn(B, 4, 2, generator=gen).double()
+    A = torch.zeros(B, 8, 8, dtype=torch.float64)
+    b = torch.zeros(B, 8, dtype=torch.float64)
+    for k in range(4):
+        x, y, u, v = src[:, k, 0], src[:, k, 1], dst[:, k, 0], dst[:, k, 1]
+        A[:, 2 * k, 0], A[:, 2 * k, 1], A[:, 2 * k, 2] = x, y, 1.0
+        A[:, 2 * k, 6], A[:, 2 * k, 7] = -u * x, -u * y
+        A[:, 2 * k + 1, 3], A[:, 2 * k + 1, 4], A[:, 2 * k + 1, 5] = x, y, 1.0
+        A[:, 2 * k + 1, 6], A[:, 2 * k + 1, 7] = -v * x, -v * y
+        b[:, 2 * k], b[:, 2 * k + 1] = u, v
+    h = torch.linalg.solve(A, b)
+    return torch.cat([h, torch.ones(B, 1, dtype=torch.float64)], dim=1).view(B, 3, 3).float()
+
+
+def event_time_ms(fn, iters):
+    """Average duration of `fn` (launches on torch's current stream) measured with HIP events on that stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_roofline(x, M, go, size, iters):
+    """Times each of the four hot kernels by calling the C ABI directly (pre-allocated buffers, no
+    allocator / autograd in the timed loop) and returns per-kernel stats."""
+    from kornia_amd import _native as N
+    from kornia_amd.filters.gaussian import _cached_taps
+
+    lib = N.lib()
+    dev = x.device
+    B, C, H, W = x.shape
+    h = w = size
+    stream = N.stream_ptr(dev)
+    m = torch.empty(B, 9, device=dev)
+    N.check(lib.km_homography_chain_fwd(M.data_ptr(), 3, None, m.data_ptr(), B, H, W, h, w, 0, stream), "chain")
+    warped = torch.empty(B, C, h, w, device=dev)
+    blurred = torch.empty_like(warped)
+    gw = torch.empty_like(warped)
+    gsrc = torch.zeros_like(x)
+    gm = torch.zeros(B, 9, device=dev, dtype=torch.float64)
+    kx, ky = _cached_taps(5, 5, (1.5, 1.5), torch.float32, dev)
+    n_el = B * C * h * w
+    e = 4
+
+    def warp_fwd():
+        N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), warped.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wf")
+
+    def blur_fwd():
+        N.check(lib.km_filter2d_sep_fwd(warped.data_ptr(), kx.data_ptr(), ky.data_ptr(), blurred.data_ptr(), B, C, h, w, 1, 5, 5, 1, 1, 0, stream), "bf")
+
+    def blur_bwd():
+        N.check(lib.km_filter2d_sep_bwd_input(go.data_ptr(), kx.data_ptr(), ky.data_ptr(), gw.data_ptr(), B, C, h, w, 1, 5, 5, 1, 1, 0, stream), "bb")
+
+    def warp_bwd():
+        N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
+
+    stats = {}
+    for name, fn, nbytes in (
+        ("km_warp_fwd_kernel", warp_fwd, 2 * e * n_el),
+        ("km_filter_sep_fwd_kernel", blur_fwd, 2 * e * n_el),
+        ("km_filter_sep_bwd_kernel", blur_bwd, 2 * e * n_el),
+        ("km_warp_bwd_kernel", warp_bwd, 3 * e * n_el),
+    ):
+        ms = event_time_ms(fn, iters)
+        stats[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1)}
+    return stats
+
+
+def cpu_baseline(size, channels, cpu_batch):
+    """The reference's CPU path (its torch op sequence, oracle/torch_ref.py) on the host cores, on a
+    bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_ref  # test infrastructure: baseline leg only
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(cpu_batch, channels, size, size, generator=g)
+    M = flagship_homographies(cpu_batch, size, size, g)
+    go = torch.rand(cpu_batch, channels, size, size, generator=g)
+    torch_ref.headline_step(x, M, go, (size, size))  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        torch_ref.headline_step(x, M, go, (size, size))
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 20:
+            break
+    mpix = cpu_batch * size * size * reps / dt / 1e6
+    return {
+        "value": round(mpix, 3),
+        "unit": "Mpix/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{reps} fwd+bwd steps of B={cpu_batch}x{channels}x{size}x{size} fp32 through the reference's PyTorch-CPU op sequence (oracle/torch_ref.py), {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import kornia_amd as K
+
+    B, C, S = args.batch, args.channels, args.size
+    gen = torch.Generator().manual_seed(1000 * rank)
+    ggen = torch.Generator(device=dev).manual_seed(1000 * rank)
+    x = torch.rand(B, C, S, S, device=dev, generator=ggen).requires_grad_()
+    M = flagship_homographies(B, S, S, gen).to(dev).requires_grad_()
+    go = torch.rand(B, C, S, S, device=dev, generator=ggen)
+
+    def step():
+        x.grad = None
+        M.grad = None
+        y = K.gaussian_blur2d(K.warp_perspective(x, M, (S, S)), (5, 5), (1.5, 1.5))
+        y.backward(go)
+        return y
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gather_ms = None
+    if args.gather and dist is not None:
+        outs = torch.empty(world * B, C, S, S, device=dev)
+        dist.all_gather_into_tensor(outs, y.detach())
+        barrier()
+        t1 = time.perf_counter()
+        dist.all_gather_into_tensor(outs, y.detach())
+        barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        del outs
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * S * S * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        with torch.no_grad():
+            kstats = kernel_roofline(x.detach(), M.detach(), go, S, max(5, min(args.steps, 20)))
+        dom = max(kstats, key=lambda k: kstats[k]["ms"])
+        achieved = kstats[dom]["GBps"]
+        roofline = {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "kernel_ms": kstats[dom]["ms"],
+            "alg_bytes_per_launch": kstats[dom]["alg_bytes"],
+        }
+        alg_step_bytes = 36 * B * C * S * S
+        result = {
+            "metric": "Mpix/s fwd+bwd warp_perspective+GaussianBlur2d Bx3x512x512",
+            "value": round(value, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: warp_perspective bilinear + GaussianBlur2d k=5 sigma=1.5, B={B}x{C}x{S}x{S} fp32 fwd+bwd (grad wrt image and homography), per GPU",
+                "global_batch": world * B,
+                "parallelism": f"batch-shard x{world}, no data-path collective",
+            },
+            "step_GBps_algorithmic": round(alg_step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(alg_step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roofline,
+            "kernels": kstats,
+        }
+        if gather_ms is not None:
+            result["all_gather_ms"] = round(gather_ms, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(S, C, args.cpu_batch)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
