@@ -1,0 +1,293 @@
+// kornia_amd - register-tiled separable filter for small odd kernels (the GaussianBlur2d hot path).
+//
+// Why not LDS here: a K-tap separable blur re-uses each input K times in x and K times in y.  With
+// 16-byte loads per lane the x re-use happens in registers (each lane owns 4 adjacent columns and
+// reads the two neighbouring float4s, which are L1 hits because its neighbour lanes load them too)
+// and the y re-use is a rolling window of K row-pass results held in registers while the lane walks
+// down its strip.  No LDS traffic, no __syncthreads, full 16-byte coalesced NCHW reads and writes.
+// HBM traffic = read x once (halo rows/columns come out of L1/L2) + write y once = 2e bytes/element.
+//
+//   forward  (BWD = false): taps constant, border = index map (rows: address select; columns: the two
+//            edge lanes of a row rebuild their out-of-image float4 by a static register swizzle).
+//            fma chain in tap order from 0 - bit-identical to oracle/ko_impl.h ko_filter2d_fwd.
+//   adjoint  (BWD = true): gx = A^T gy with A = A_y (x) A_x.  Each 1-D adjoint is a correlation of the
+//            ZERO-extended gradient with position-dependent taps  W[p][i] = sum_t k[t] [map(i+t-l) == p]
+//            which differ from the flipped taps only within K-1 pixels of a border (the pad fold).
+//            Circular is periodic: unmodified flipped taps on periodic indexing.
+//
+// Requirements checked by the host: K odd, 3 <= K <= 9, kW == kH == K, 'same' padding, W % 4 == 0,
+// W >= 8, H >= K, 16-byte aligned planes.  Everything else takes the generic LDS kernel.
+#include "km_common.h"
+
+enum { KMB_CONSTANT = 0, KMB_REFLECT = 1, KMB_REPLICATE = 2, KMB_CIRCULAR = 3 };
+
+#define KMB_ROWS 16  // output rows per thread (strip height)
+
+template <typename T>
+struct KmVec4;
+template <>
+struct KmVec4<float> {
+    typedef float4 V;
+};
+template <>
+struct KmVec4<km_bf16> {
+    typedef uint2 V;
+};
+template <>
+struct KmVec4<km_f16> {
+    typedef uint2 V;
+};
+
+__device__ __forceinline__ void km_ld4(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void km_ld4(const km_bf16* p, float (&o)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void km_ld4(const km_f16* p, float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
+}
+__device__ __forceinline__ void km_st4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void km_st4(km_bf16* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
+    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 v;
+    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    *reinterpret_cast<h4*>(p) = v;
+}
+__device__ __forceinline__ float km_round_store(float v, const float*) { return v; }
+__device__ __forceinline__ float km_round_store(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
+__device__ __forceinline__ float km_round_store(float v, const km_f16*) { return (float)(_Float16)v; }
+
+__device__ __forceinline__ int kmb_map(int s, int n, int border) {
+    if (s >= 0 && s < n) return s;
+    switch (border) {
+        case KMB_REFLECT:
+            if (s < 0) s = -s;
+            if (s >= n) s = 2 * (n - 1) - s;
+            return (s >= 0 && s < n) ? s : -1;
+        case KMB_REPLICATE: return s < 0 ? 0 : n - 1;
+        case KMB_CIRCULAR: { int r = s % n; return r < 0 ? r + n : r; }
+        default: return -1;
+    }
+}
+
+template <typename T>
+struct KmBlurArgs {
+    const T* x;       // fwd: input ; bwd: grad_out      (B*C, H, W)
+    T* y;             // fwd: output ; bwd: grad_in
+    const float* kx;  // (Bk, K)
+    const float* ky;  // (Bk, K)
+    int C, H, W, Bk, border;
+    uint32_t groups_x;   // W / 4
+    uint32_t bx, by;     // blocks per plane in x / y
+    uint32_t nblocks;
+};
+
+// Adjoint taps along one axis for output position p:  w[d] multiplies the (zero-extended) gradient at
+// p - R + d, d in [0,K), R = K - 1 - L = rear pad, L = front pad = (K-1)/2:
+//   w[d] = sum_t k[t] * [ map(i + t - L) == p ],  i = p - R + d
+template <int K>
+__device__ __forceinline__ void kmb_adjoint_taps(const float (&k)[K], int p, int n, int border, float (&w)[K]) {
+    constexpr int L = (K - 1) / 2, R = K - 1 - L;
+    const bool interior = (border == KMB_CIRCULAR) || (border == KMB_CONSTANT) || (p >= K - 1 && p <= n - K);
+#pragma unroll
+    for (int d = 0; d < K; ++d) w[d] = k[K - 1 - d];  // interior: i + t - L == p  <=>  t = p - i + L = R + L - d
+    if (interior) return;
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        const int i = p - R + d;
+        float acc = 0.f;
+        if (i >= 0 && i < n) {
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+                if (kmb_map(i + t - L, n, border) == p) acc += k[t];
+        }
+        w[d] = acc;
+    }
+}
+
+template <typename T, int K, bool BWD>
+__global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a) {
+    constexpr int L = (K - 1) / 2, R = K - 1 - L;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.bx;
+    bid /= a.bx;
+    const uint32_t tby = bid % a.by;
+    const uint32_t bc = bid / a.by;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = (int)tbx * 64 + lane;                      // column group (4 px)
+    const int r0 = ((int)tby * 4 + wave) * KMB_ROWS;          // first output row of this thread's strip
+    if (gx >= (int)a.groups_x || r0 >= a.H) return;
+    const int H = a.H, W = a.W, border = a.border;
+    const int c0 = gx * 4;
+    const bool left = (c0 == 0), right = (c0 == W - 4);
+    const T* img = a.x + (size_t)bc * H * W;
+    T* out = a.y + (size_t)bc * H * W;
+    const int b = (int)(bc / a.C);
+
+    float kx[K], ky[K];
+    {
+        const float* px = a.kx + (size_t)(b % a.Bk) * K;
+        const float* py = a.ky + (size_t)(b % a.Bk) * K;
+#pragma unroll
+        for (int t = 0; t < K; ++t) { kx[t] = px[t]; ky[t] = py[t]; }
+    }
+    // horizontal taps: forward uses kx as is; the adjoint uses per-output position-dependent taps
+    float wx[4][K];
+    if (BWD) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) kmb_adjoint_taps<K>(kx, c0 + o, W, border, wx[o]);
+    }
+
+    // column offsets of the three float4 loads; edge lanes clamp (or wrap, for circular) the outer ones
+    int offL = c0 - 4, offR = c0 + 4;
+    if (left) offL = (border == KMB_CIRCULAR) ? W - 4 : c0;
+    if (right) offR = (border == KMB_CIRCULAR) ? 0 : c0;
+
+    float ring[K][4];  // rolling window of row-pass results
+    const int n_rows = (r0 + KMB_ROWS <= H ? KMB_ROWS : H - r0);
+    const int total = n_rows + K - 1;
+
+    for (int it0 = 0; it0 < total; it0 += K) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int it = it0 + kk;
+            if (it < total) {
+                // ---- row pass for input row (r0 - L + it) [fwd] / (r0 - R + it) [bwd] ----
+                const int rin = r0 + it - (BWD ? R : L);
+                int srow;
+                if (BWD) srow = (border == KMB_CIRCULAR) ? kmb_map(rin, H, KMB_CIRCULAR) : ((rin >= 0 && rin < H) ? rin : -1);
+                else srow = kmb_map(rin, H, border);
+                float v[12];
+                if (srow >= 0) {
+                    const T* rowp = img + (size_t)srow * W;
+                    float l4[4], o4[4], r4[4];
+                    km_ld4(rowp + offL, l4);
+                    km_ld4(rowp + c0, o4);
+                    km_ld4(rowp + offR, r4);
+                    if (border != KMB_CIRCULAR) {
+                        if (BWD || border == KMB_CONSTANT) {
+                            if (left) { l4[0] = l4[1] = l4[2] = l4[3] = 0.f; }
+                            if (right) { r4[0] = r4[1] = r4[2] = r4[3] = 0.f; }
+                        } else if (border == KMB_REFLECT) {
+                            // positions -4..-1 -> x[4], x[3], x[2], x[1] ; W..W+3 -> x[W-2], x[W-3], x[W-4], x[W-5]
+                            if (left) { l4[0] = r4[0]; l4[1] = o4[3]; l4[2] = o4[2]; l4[3] = o4[1]; }
+                            if (right) { const float t3 = l4[3]; r4[0] = o4[2]; r4[1] = o4[1]; r4[2] = o4[0]; r4[3] = t3; }
+                        } else {  // replicate
+                            if (left) { l4[0] = l4[1] = l4[2] = l4[3] = o4[0]; }
+                            if (right) { r4[0] = r4[1] = r4[2] = r4[3] = o4[3]; }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = l4[q]; v[4 + q] = o4[q]; v[8 + q] = r4[q]; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) v[q] = 0.f;
+                }
+                // v[i] holds column c0 - 4 + i
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc = 0.f;
+                    if (BWD) {
+                        // taps wx[o][d] multiply column (c0+o) - R + d
+#pragma unroll
+                        for (int d = 0; d < K; ++d) acc = km_fma(wx[o][d], v[4 + o - R + d], acc);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < K; ++q) acc = km_fma(kx[q], v[4 + o - L + q], acc);
+                    }
+                    ring[kk][o] = km_round_store(acc, (const T*)nullptr);
+                }
+                // ---- column pass: emits output row r = r0 + it - (K-1) once K rows are in the window ----
+                if (it >= K - 1) {
+                    const int r = r0 + it - (K - 1);
+                    float res[4];
+                    if (BWD) {
+                        float wy[K];
+                        kmb_adjoint_taps<K>(ky, r, H, border, wy);
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int d = 0; d < K; ++d) acc = km_fma(wy[d], ring[(kk + 1 + d) % K][o], acc);
+                            res[o] = acc;
+                        }
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int p = 0; p < K; ++p) acc = km_fma(ky[p], ring[(kk + 1 + p) % K][o], acc);
+                            res[o] = acc;
+                        }
+                    }
+                    km_st4(out + (size_t)r * W + c0, res);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int K>
+static int km_blur_launch(bool bwd, const KmBlurArgs<T>& a, hipStream_t s) {
+    if (bwd)
+        hipLaunchKernelGGL((km_blur_reg_kernel<T, K, true>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_blur_reg_kernel<T, K, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch(bwd ? "km_blur_reg_bwd" : "km_blur_reg_fwd");
+}
+
+template <typename T>
+static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk,
+                       int K, int border, hipStream_t s) {
+    KmBlurArgs<T> a;
+    a.x = (const T*)x; a.y = (T*)y; a.kx = (const float*)kx; a.ky = (const float*)ky;
+    a.C = C; a.H = H; a.W = W; a.Bk = Bk; a.border = border;
+    a.groups_x = (uint32_t)(W / 4);
+    a.bx = (a.groups_x + 63) / 64;
+    a.by = (uint32_t)((H + 4 * KMB_ROWS - 1) / (4 * KMB_ROWS));
+    const uint64_t nb = (uint64_t)a.bx * a.by * (uint64_t)B * C;
+    KM_REQUIRE(nb < (1ull << 31), "km_blur: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    switch (K) {
+        case 3: return km_blur_launch<T, 3>(bwd, a, s);
+        case 5: return km_blur_launch<T, 5>(bwd, a, s);
+        case 7: return km_blur_launch<T, 7>(bwd, a, s);
+        default: return km_blur_launch<T, 9>(bwd, a, s);
+    }
+}
+
+// 1 if the register-tiled kernel handles this problem
+int km_blur_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype) {
+    if (!same || kH != kW || (kH & 1) == 0 || kH < 3 || kH > 9) return 0;
+    if (dtype == KM_F64) return 0;
+    if ((W & 3) != 0 || W < 8 || H < kH) return 0;
+    if (border == KMB_REFLECT && (kH - 1) / 2 >= (H < W ? H : W)) return 0;
+    const size_t esz = (dtype == KM_F32) ? 4 : 2;
+    if (((uintptr_t)x % (4 * esz)) != 0 || ((uintptr_t)y % (4 * esz)) != 0) return 0;
+    if ((((size_t)H * W * esz) % (4 * esz)) != 0) return 0;
+    return 1;
+}
+
+int km_blur_fast_run(bool bwd, const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk, int K,
+                     int border, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case KM_F32: return km_blur_run<float>(bwd, x, kx, ky, y, B, C, H, W, Bk, K, border, s);
+        case KM_BF16: return km_blur_run<km_bf16>(bwd, x, kx, ky, y, B, C, H, W, Bk, K, border, s);
+        default: return km_blur_run<km_f16>(bwd, x, kx, ky, y, B, C, H, W, Bk, K, border, s);
+    }
+}

@@ -17,6 +17,8 @@
 //   km_filter2d_fwd_kernel        generic kH x kW (any size / border / Bk), direct loads.
 //   km_filter2d_bwd_input_kernel  generic adjoint, gather form (no atomics, deterministic).
 //   km_filter2d_bwd_kernel_kernel gradient wrt the taps (fp64 accumulation).
+#include <stdlib.h>
+
 #include "km_common.h"
 
 enum { KM_BORDER_CONSTANT = 0, KM_BORDER_REFLECT = 1, KM_BORDER_REPLICATE = 2, KM_BORDER_CIRCULAR = 3 };
@@ -500,6 +502,20 @@ static int km_full_run(int which, const void* x, const void* gy, const void* k, 
     return km_check_launch(which == 0 ? "km_filter2d_fwd" : "km_filter2d_bwd_input");
 }
 
+// register-tiled fast path for small square odd kernels (km_blur_fast.hip)
+int km_blur_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype);
+int km_blur_fast_run(bool bwd, const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk, int K,
+                     int border, int dtype, hipStream_t s);
+static int km_sep_algo() {
+    // KM_SEP_ALGO=lds forces the generic LDS-tiled kernels (debugging / A-B timing)
+    static int algo = -1;
+    if (algo < 0) {
+        const char* e = getenv("KM_SEP_ALGO");
+        algo = (e && e[0] == 'l') ? 1 : 0;
+    }
+    return algo;
+}
+
 #define KM_DISPATCH_DTYPE(dtype, CALL)                      \
     switch (dtype) {                                        \
         case KM_F32: return CALL(float);                    \
@@ -550,6 +566,8 @@ int km_filter2d_sep_fwd(const void* x, const void* kx, const void* ky, void* y, 
                         int kW, int border, int same, int dtype, void* stream) {
     if (km_filter_validate("km_filter2d_sep_fwd", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(x && kx && ky && y, "km_filter2d_sep_fwd: null pointer");
+    if (km_sep_algo() == 0 && km_blur_fast_supported(x, y, H, W, kH, kW, border, same, dtype))
+        return km_blur_fast_run(false, x, kx, ky, y, B, C, H, W, Bk, kH, border, dtype, (hipStream_t)stream);
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
 #define CALL(T) km_sep_run<T>(false, x, kx, ky, y, g, (hipStream_t)stream)
     KM_DISPATCH_DTYPE(dtype, CALL)
@@ -560,6 +578,8 @@ int km_filter2d_sep_bwd_input(const void* gy, const void* kx, const void* ky, vo
                               int kH, int kW, int border, int same, int dtype, void* stream) {
     if (km_filter_validate("km_filter2d_sep_bwd_input", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(gy && kx && ky && gx, "km_filter2d_sep_bwd_input: null pointer");
+    if (km_sep_algo() == 0 && km_blur_fast_supported(gy, gx, H, W, kH, kW, border, same, dtype))
+        return km_blur_fast_run(true, gy, kx, ky, gx, B, C, H, W, Bk, kH, border, dtype, (hipStream_t)stream);
     KM_REQUIRE(kH - 1 <= KM_FS_TH && kW - 1 <= KM_FS_TW, "km_filter2d_sep_bwd_input: kernel larger than the tile; use the generic path");
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
 #define CALL(T) km_sep_run<T>(true, gy, kx, ky, gx, g, (hipStream_t)stream)

@@ -192,3 +192,46 @@ def test_half_precision_blur(oracle, dtype, tol):
     out = K.gaussian_blur2d(x.to(dtype).cuda(), (5, 5), (1.5, 1.5)).float().cpu()
     ref = oracle.gaussian_blur2d(x.to(dtype).float(), (5, 5), (1.5, 1.5))
     assert (out - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 72), (3, 1, 37, 128), (4, 2, 16, 264)])
+@pytest.mark.parametrize("K", [3, 5, 7, 9])
+@pytest.mark.parametrize("Bk", [1, "B"])
+@pytest.mark.parametrize("border", BORDERS)
+def test_register_tiled_blur_fast_path(oracle, border, Bk, K, shape):
+    """W % 4 == 0, square odd K <= 9: served by csrc/km_blur_fast.hip (no LDS). Forward bit-exact;
+    the adjoint against the oracle's scatter-form adjoint."""
+    import kornia_amd as K_
+
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(B, C, H, W, generator=g)
+    nb = 1 if Bk == 1 else B
+    kx, ky = torch.rand(nb, K, generator=g), torch.rand(nb, K, generator=g)
+    ref = oracle.filter2d_separable(x, kx, ky, border)
+    xg = x.cuda().requires_grad_()
+    out = K_.filter2d_separable(xg, kx.cuda(), ky.cuda(), border)
+    assert torch.equal(out.detach().cpu(), ref), f"max |d| = {(out.detach().cpu() - ref).abs().max().item():.3e}"
+    go = torch.rand(ref.shape, generator=g)
+    out.backward(go.cuda())
+    gx_o = oracle.filter2d_separable_backward(go, x, kx, ky, border)
+    assert torch.allclose(xg.grad.cpu(), gx_o, atol=2e-5, rtol=1e-5), (xg.grad.cpu() - gx_o).abs().max()
+
+
+def test_blur_adjoint_identity_at_full_size():
+    """Config-2 sized blur: adjoint identity <A x, y> == <x, A^T y> (size-independent property)."""
+    import kornia_amd as K_
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(8, 3, 512, 512, device="cuda", generator=g, dtype=torch.float32).requires_grad_()
+    y = torch.rand(8, 3, 512, 512, device="cuda", generator=g)
+    for border in BORDERS:
+        x.grad = None
+        Ax = K_.gaussian_blur2d(x, (5, 5), (1.5, 1.5), border)
+        Ax.backward(y)
+        lhs = (Ax.detach().double() * y.double()).sum()
+        rhs = (x.detach().double() * x.grad.double()).sum()
+        assert abs(lhs - rhs).item() / abs(lhs).item() < 1e-6
+        ones = torch.ones(1, 1, 512, 512, device="cuda")
+        if border != "constant":  # blur of a constant image is the same constant (taps sum to 1)
+            assert torch.allclose(K_.gaussian_blur2d(ones, (5, 5), (1.5, 1.5), border), ones, atol=1e-6)
