@@ -69,11 +69,15 @@ int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int
                   void* stream);
 /* Replaces autograd's aten::grid_sampler_2d_backward + the reverse of the grid chain.
  *   gout  (B,C,h,w) dtype
- *   gsrc  (B,C,H,W) COMPUTE dtype accumulators, zeroed by the caller, nullable
+ *   gsrc  (B,C,H,W) COMPUTE dtype, nullable; zeroed by the caller iff km_warp2d_bwd_needs_zero_init()
  *   gmat  (B_M,9) float64 accumulators, zeroed by the caller, nullable */
 int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
                   int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align_corners,
                   const void* fill, int dtype, void* stream);
+
+/* 1 if km_warp2d_bwd with these modes accumulates with atomics and needs gsrc zeroed by the caller,
+ * 0 if it overwrites gsrc completely (tile-owner path: bilinear, zeros/fill padding, dtype != f64). */
+int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype);
 
 /* ---- filters -------------------------------------------------------------------------------
  * Replaces F.pad + F.conv2d(groups = Bk*C) of filter2d (kornia/filters/filter.py:131-150).

@@ -198,3 +198,42 @@ __device__ __forceinline__ int km_tap_index(R x, R y, int W, int H, int pad, int
     const int ix = (int)x, iy = (int)y;
     return (ix >= 0 && ix < W && iy >= 0 && iy < H) ? iy * W + ix : -1;
 }
+
+// bilinear tap set for one output pixel
+template <typename R>
+struct KmBilin {
+    int i00, i01, i10, i11;  // clamped linear indices (always valid addresses)
+    R w00, w01, w10, w11;    // weights, zeroed for out-of-bounds taps in forward use
+    bool b00, b01, b10, b11;
+    R wx0, wx1, wy0, wy1;    // (x - x0), (x1 - x), (y - y0), (y1 - y)
+};
+
+template <typename R>
+__device__ __forceinline__ void km_bilinear_setup(R x, R y, int W, int H, KmBilin<R>& t) {
+    const R xf = km_floor(x), yf = km_floor(y);
+    // bounds decided in floating point so that NaN / huge coordinates are simply out of bounds
+    const bool bx0 = (xf >= (R)0) && (xf <= (R)(W - 1));
+    const bool bx1 = (xf >= (R)-1) && (xf <= (R)(W - 2));
+    const bool by0 = (yf >= (R)0) && (yf <= (R)(H - 1));
+    const bool by1 = (yf >= (R)-1) && (yf <= (R)(H - 2));
+    const R x1f = xf + 1, y1f = yf + 1;
+    t.wx1 = x1f - x;
+    t.wx0 = x - xf;
+    t.wy1 = y1f - y;
+    t.wy0 = y - yf;
+    t.w00 = t.wx1 * t.wy1;
+    t.w01 = t.wx0 * t.wy1;
+    t.w10 = t.wx1 * t.wy0;
+    t.w11 = t.wx0 * t.wy0;
+    const int x0 = bx0 ? (int)xf : 0, x1 = bx1 ? (int)x1f : 0;
+    const int y0 = by0 ? (int)yf : 0, y1 = by1 ? (int)y1f : 0;
+    t.b00 = bx0 && by0;
+    t.b01 = bx1 && by0;
+    t.b10 = bx0 && by1;
+    t.b11 = bx1 && by1;
+    t.i00 = y0 * W + x0;
+    t.i01 = y0 * W + x1;
+    t.i10 = y1 * W + x0;
+    t.i11 = y1 * W + x1;
+}
+

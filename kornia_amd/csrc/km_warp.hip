@@ -34,45 +34,6 @@ struct KmWarpArgs {
     uint32_t tiles_x, tiles_y, nblocks;
 };
 
-// ------------------------------------------------------------------------------------------------
-// bilinear tap set for one output pixel
-template <typename R>
-struct KmBilin {
-    int i00, i01, i10, i11;  // clamped linear indices (always valid addresses)
-    R w00, w01, w10, w11;    // weights, zeroed for out-of-bounds taps in forward use
-    bool b00, b01, b10, b11;
-    R wx0, wx1, wy0, wy1;    // (x - x0), (x1 - x), (y - y0), (y1 - y)
-};
-
-template <typename R>
-__device__ __forceinline__ void km_bilinear_setup(R x, R y, int W, int H, KmBilin<R>& t) {
-    const R xf = km_floor(x), yf = km_floor(y);
-    // bounds decided in floating point so that NaN / huge coordinates are simply out of bounds
-    const bool bx0 = (xf >= (R)0) && (xf <= (R)(W - 1));
-    const bool bx1 = (xf >= (R)-1) && (xf <= (R)(W - 2));
-    const bool by0 = (yf >= (R)0) && (yf <= (R)(H - 1));
-    const bool by1 = (yf >= (R)-1) && (yf <= (R)(H - 2));
-    const R x1f = xf + 1, y1f = yf + 1;
-    t.wx1 = x1f - x;
-    t.wx0 = x - xf;
-    t.wy1 = y1f - y;
-    t.wy0 = y - yf;
-    t.w00 = t.wx1 * t.wy1;
-    t.w01 = t.wx0 * t.wy1;
-    t.w10 = t.wx1 * t.wy0;
-    t.w11 = t.wx0 * t.wy0;
-    const int x0 = bx0 ? (int)xf : 0, x1 = bx1 ? (int)x1f : 0;
-    const int y0 = by0 ? (int)yf : 0, y1 = by1 ? (int)y1f : 0;
-    t.b00 = bx0 && by0;
-    t.b01 = bx1 && by0;
-    t.b10 = bx0 && by1;
-    t.b11 = bx1 && by1;
-    t.i00 = y0 * W + x0;
-    t.i01 = y0 * W + x1;
-    t.i10 = y1 * W + x0;
-    t.i11 = y1 * W + x1;
-}
-
 template <typename T, int CM, int INTERP>
 __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a) {
     typedef typename KmTraits<T>::R R;
@@ -431,6 +392,12 @@ static int km_warp_validate(const char* fn, const void* src, const void* mat, in
     return 0;
 }
 
+// owner-computes backward for bilinear + zeros/fill (km_warp_bwd_tiled.hip)
+int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc);
+int km_warp_bwd_tiled_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H, int W,
+                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype,
+                          hipStream_t s);
+
 extern "C" {
 
 // Replaces the eager grid construction + F.grid_sample of
@@ -460,12 +427,21 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
     KM_REQUIRE(gout, "km_warp2d_bwd: null gout");
     if (!gsrc && !gmat) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc))
+        return km_warp_bwd_tiled_run(gout, src, mat, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
     switch (dtype) {
         case KM_F32: return km_warp_run<float>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         case KM_F64: return km_warp_run<double>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         case KM_BF16: return km_warp_run<km_bf16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         default: return km_warp_run<km_f16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
     }
+}
+
+// 1 if km_warp2d_bwd with these modes accumulates with atomics and therefore needs gsrc zeroed by the
+// caller; 0 if it overwrites gsrc completely (owner-computes path).
+int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype) {
+    int dummy = 0;
+    return km_warp_bwd_tiled_supported(interp, pad, dtype, &dummy) ? 0 : 1;
 }
 
 }  // extern "C"

@@ -91,7 +91,10 @@ class _Warp2dFunction(torch.autograd.Function):
         need_src, need_mat = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = gout.detach().to(x.dtype).contiguous()
         stream = N.stream_ptr(dev)
-        gsrc = torch.zeros(B, C, H, W, device=dev, dtype=cdt) if need_src else None
+        gsrc = None
+        if need_src:
+            zero = lib.km_warp2d_bwd_needs_zero_init(cfg.interp, cfg.pad, N.dtype_code(x.dtype))
+            gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
         gm = torch.zeros(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
         gmat = None
         with torch.cuda.device(dev):
