@@ -1,0 +1,187 @@
+"""TEST INFRASTRUCTURE ONLY - generates tests/golden/*.npz by running the REAL reference
+(kornia @ /root/reference, imported through oracle/ref_shim.py) on CPU in the build container.
+
+    python oracle/make_golden.py            # rewrites every fixture (deterministic: seeded inputs)
+
+Each .npz stores the inputs AND the reference's outputs / autograd gradients, so the tests that
+consume them (tests/test_oracle_golden.py on CPU, tests/test_gpu_golden.py on the MI355X) need
+neither the reference tree nor the same RNG.  Sizes are small on purpose (whole directory < 3 MB).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+import ref_shim  # noqa: E402
+
+K = ref_shim.import_reference()
+from _util import flagship_homographies, rotation_affines  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+MODES = ["bilinear", "nearest", "bicubic"]
+PADS = ["zeros", "border", "reflection", "fill"]
+BORDERS = ["constant", "reflect", "replicate", "circular"]
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"wrote {name}.npz ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB)")
+
+
+def main():
+    T = K.geometry.transform
+    F = K.filters
+    g = torch.Generator().manual_seed(2024)
+
+    # ---- 3x3 chain ---------------------------------------------------------------------------
+    from kornia.core.utils import _inverse_3x3_closed_form
+    from kornia.geometry.conversions import normalize_homography
+
+    M = flagship_homographies(32, 512, 512, 384, 640, g)
+    A = normalize_homography(M, (512, 512), (384, 640))
+    save("chain", M=M, A=A, m=_inverse_3x3_closed_form(A), src_size=[512, 512], dst_size=[384, 640])
+
+    # ---- warps ---------------------------------------------------------------------------------
+    B, C, H, W, h, w = 2, 3, 24, 32, 20, 28
+    x = torch.rand(B, C, H, W, generator=g)
+    Mp = flagship_homographies(B, H, W, h, w, g, jitter=3.0)
+    Aa = rotation_affines(B, H, W, g)
+    Hn = torch.eye(3)[None] + 0.05 * torch.randn(B, 3, 3, generator=g)
+    go = torch.rand(B, C, h, w, generator=g)
+    fill = torch.tensor([0.1, 0.5, 0.9])
+    d = dict(x=x, Mp=Mp, Aa=Aa, Hn=Hn, go=go, fill=fill, dsize=[h, w])
+    for mode in MODES:
+        for pad in PADS:
+            for ac in (True, False):
+                tag = f"{mode}_{pad}_{int(ac)}"
+                fv = fill if pad == "fill" else None
+                xg, Mg = x.clone().requires_grad_(), Mp.clone().requires_grad_()
+                y = T.warp_perspective(xg, Mg, (h, w), mode, pad, ac, fv)
+                d["persp_" + tag] = y
+                if mode != "nearest":
+                    y.backward(go)
+                    d["persp_gx_" + tag], d["persp_gM_" + tag] = xg.grad, Mg.grad
+                xg, Ag = x.clone().requires_grad_(), Aa.clone().requires_grad_()
+                y = T.warp_affine(xg, Ag, (h, w), mode, pad, ac, fv)
+                d["affine_" + tag] = y
+                if mode == "bilinear":
+                    y.backward(go)
+                    d["affine_gx_" + tag], d["affine_gM_" + tag] = xg.grad, Ag.grad
+                if pad != "fill":
+                    xg, Hg = x.clone().requires_grad_(), Hn.clone().requires_grad_()
+                    y = T.homography_warp(xg, Hg, (h, w), mode, pad, ac)
+                    d["homog_" + tag] = y
+                    if mode == "bilinear":
+                        y.backward(go)
+                        d["homog_gx_" + tag], d["homog_gH_" + tag] = xg.grad, Hg.grad
+    d["affine_shared"] = T.warp_affine(x, Aa[:1], (h, w))
+    save("warps", **d)
+
+    # fp64 gradients wrt the matrices for the bilinear cases (the loose-tolerance truth)
+    d64 = {}
+    for pad in PADS:
+        for ac in (True, False):
+            tag = f"bilinear_{pad}_{int(ac)}"
+            fv = fill.double() if pad == "fill" else None
+            xg, Mg = x.double().requires_grad_(), Mp.double().requires_grad_()
+            T.warp_perspective(xg, Mg, (h, w), "bilinear", pad, ac, fv).backward(go.double())
+            d64["persp_gM_" + tag] = Mg.grad
+    save("warps_f64", **d64)
+
+    # ---- known-answer literals of the reference's own tests (re-evaluated, not retyped) -------------
+    lit = {}
+    img = torch.arange(12.0).view(1, 1, 3, 4)
+    aff = torch.eye(2, 3)[None].clone()
+    aff[..., -1] += 1.0
+    lit["affine_translation_in"], lit["affine_translation_M"] = img, aff
+    lit["affine_translation_out"] = T.warp_affine(img, aff, (3, 4))  # tests/geometry/transform/test_imgwarp.py:251-264
+    x46 = torch.arange(24.0).view(1, 1, 4, 6)
+    H46 = torch.tensor([[[1.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]])
+    lit["persp_4x6_in"], lit["persp_4x6_H"] = x46, H46
+    lit["persp_4x6_out"] = T.warp_perspective(x46, H46, (3, 5), align_corners=True)  # test_imgwarp.py:416-440
+    p45 = torch.arange(20.0).view(1, 1, 4, 5)
+    lit["hw_4x5_in"] = p45
+    lit["hw_4x5_out"] = T.HomographyWarper(4, 5)(p45, torch.eye(3)[None])  # test_homography_warper.py:181-221
+    save("literals", **lit)
+
+    # ---- filters --------------------------------------------------------------------------------
+    xf = torch.rand(4, 3, 18, 24, generator=g)
+    df = dict(x=xf)
+    kshapes = [(1, 3, 3), (1, 5, 6), (1, 2, 2), (4, 3, 5), (2, 4, 3)]
+    for ki, ks in enumerate(kshapes):
+        k = torch.rand(*ks, generator=g)
+        df[f"k{ki}"] = k
+        for border in BORDERS:
+            for padding in ("same", "valid"):
+                for beh in ("corr", "conv"):
+                    xg, kg = xf.clone().requires_grad_(), k.clone().requires_grad_()
+                    y = F.filter2d(xg, kg, border, False, padding, beh)
+                    tag = f"{ki}_{border}_{padding}_{beh}"
+                    df["f2d_" + tag] = y
+                    if beh == "corr":
+                        gy = torch.rand(y.shape, generator=g)
+                        y.backward(gy)
+                        df["f2d_gy_" + tag], df["f2d_gx_" + tag], df["f2d_gk_" + tag] = gy, xg.grad, kg.grad
+    save("filter2d", **df)
+
+    dg = {}
+    x1 = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(0))  # BASELINE.json configs[0]
+    dg["cfg1_x"] = x1
+    dg["cfg1_y"] = F.GaussianBlur2d((5, 5), (1.5, 1.5))(x1)
+    dg["cfg1_kernel"] = F.get_gaussian_kernel1d(5, 1.5)
+    sig = torch.rand(4, 2, generator=g) + 0.5
+    sig2 = torch.rand(2, 2, generator=g) + 0.5
+    dg["x"], dg["sig"], dg["sig2"] = xf, sig, sig2
+    for border in BORDERS:
+        xg = xf.clone().requires_grad_()
+        y = F.gaussian_blur2d(xg, (5, 5), (1.5, 1.5), border)
+        gy = torch.rand(y.shape, generator=g)
+        y.backward(gy)
+        dg[f"g5_{border}"], dg[f"g5_gy_{border}"], dg[f"g5_gx_{border}"] = y, gy, xg.grad
+        dg[f"g5ns_{border}"] = F.gaussian_blur2d(xf, (5, 5), (1.5, 1.5), border, separable=False)
+        dg[f"g37_{border}"] = F.gaussian_blur2d(xf, (3, 7), sig, border)
+        dg[f"g33b2_{border}"] = F.gaussian_blur2d(xf, (3, 3), sig2, border)
+    for mode in ("sobel", "diff"):
+        for order in (1, 2):
+            for nrm in (True, False):
+                xg = xf.clone().requires_grad_()
+                y = F.spatial_gradient(xg, mode, order, nrm)
+                gy = torch.rand(y.shape, generator=g)
+                y.backward(gy)
+                tag = f"{mode}_{order}_{int(nrm)}"
+                dg["sg_" + tag], dg["sg_gy_" + tag], dg["sg_gx_" + tag] = y, gy, xg.grad
+    dg["sobel"] = F.sobel(xf)
+    save("gaussian_sobel", **dg)
+
+    # ---- transform_points ------------------------------------------------------------------------
+    from kornia.geometry.linalg import transform_points
+
+    dp = {}
+    for D in (2, 3):
+        P = torch.rand(3, 200, D, generator=g) * 2 - 1
+        Tm = torch.eye(D + 1)[None] + 0.1 * torch.randn(3, D + 1, D + 1, generator=g)
+        dp[f"P{D}"], dp[f"T{D}"] = P, Tm
+        dp[f"out{D}"] = transform_points(Tm, P)
+        dp[f"out{D}_shared"] = transform_points(Tm[:1], P)
+    save("transform_points", **dp)
+
+    # ---- the headline pipeline, small ----------------------------------------------------------------
+    xh = torch.rand(2, 3, 64, 64, generator=g)
+    Mh = flagship_homographies(2, 64, 64, 64, 64, g, jitter=2.0)
+    gh = torch.rand(2, 3, 64, 64, generator=g)
+    xg, Mg = xh.clone().requires_grad_(), Mh.clone().requires_grad_()
+    y = F.gaussian_blur2d(T.warp_perspective(xg, Mg, (64, 64)), (5, 5), (1.5, 1.5))
+    y.backward(gh)
+    save("headline_small", x=xh, M=Mh, go=gh, y=y, gx=xg.grad, gM=Mg.grad)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    main()

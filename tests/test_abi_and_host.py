@@ -1,0 +1,141 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/kornia_amd.h declares; the
+host-side mirror validates arguments like the reference and refuses to run without a HIP device
+(no CPU fallback).  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "kornia_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(km_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from kornia_amd import _native, build
+
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/kornia_amd.h but not exported"
+    # the Python binding covers the whole header too
+    assert sorted(_native.exported_symbols()) == declared
+    lib.km_abi_version.restype = ctypes.c_int
+    assert lib.km_abi_version() == _native.ABI_VERSION
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu():
+    from kornia_amd import _native
+
+    lib = _native.lib()
+    rc = lib.km_warp2d_fwd(None, None, None, 1, 3, 8, 8, 8, 8, 1, 0, 1, 1, 0, 1, None, 0, None)
+    assert rc < 0 and b"null pointer" in lib.km_last_error()
+    buf = ctypes.create_string_buffer(64)
+    rc = lib.km_filter2d_fwd(buf, buf, buf, 2, 3, 8, 8, 3, 3, 3, 1, 1, 0, None)  # Bk=3 does not divide B=2
+    assert rc < 0 and b"must divide" in lib.km_last_error()
+    rc = lib.km_homography_chain_fwd(buf, 4, buf, buf, 1, 8, 8, 8, 8, 0, None)
+    assert rc < 0 and b"rows must be 2 or 3" in lib.km_last_error()
+    assert lib.km_filter2d_sep_supported(5, 5, 1, 0) == 1 and lib.km_filter2d_sep_supported(99, 5, 1, 0) == 0
+    assert lib.km_warp2d_bwd_needs_zero_init(1, 0, 0) == 0 and lib.km_warp2d_bwd_needs_zero_init(2, 0, 0) == 1
+
+
+def test_no_cpu_fallback():
+    import kornia_amd as K
+
+    x = torch.rand(1, 3, 8, 8)
+    with pytest.raises(K.NativeLibraryError, match="no CPU fallback"):
+        K.warp_perspective(x, torch.eye(3)[None], (8, 8))
+    with pytest.raises(K.NativeLibraryError):
+        K.gaussian_blur2d(x, (3, 3), (1.0, 1.0))
+    with pytest.raises(K.NativeLibraryError):
+        K.spatial_gradient(x)
+    with pytest.raises(K.NativeLibraryError):
+        K.transform_points(torch.eye(3)[None], torch.rand(1, 4, 2))
+
+
+def test_validation_matches_reference_conventions():
+    """Error types / message fragments pinned by the reference's tests: tests/geometry/transform/
+    test_imgwarp.py:232-249, tests/filters/test_filters.py:104-133, tests/filters/test_gaussian.py:356-390."""
+    import kornia_amd as K
+    from kornia_amd.core import BaseError, ShapeError, TypeCheckError
+
+    x = torch.rand(1, 3, 8, 8)
+    with pytest.raises(TypeError, match="Input src type is not a torch.Tensor"):
+        K.warp_perspective(1, torch.eye(3)[None], (4, 4))
+    with pytest.raises(TypeError, match="Input M type is not a torch.Tensor"):
+        K.warp_affine(x, 1, (4, 4))
+    with pytest.raises(ValueError, match="BxCxHxW"):
+        K.warp_perspective(x[0], torch.eye(3)[None], (4, 4))
+    with pytest.raises(ValueError, match="Bx3x3"):
+        K.warp_perspective(x, torch.eye(2, 3)[None], (4, 4))
+    with pytest.raises(ValueError):
+        K.warp_affine(x, torch.eye(3)[None], (4, 4))
+    with pytest.raises(ValueError, match="Padding_tensor only supported for 3 channels"):
+        K.warp_perspective(x, torch.eye(3)[None], (4, 4), padding_mode="fill", fill_value=torch.zeros(2))
+    with pytest.raises(TypeCheckError):
+        K.filter2d(1, torch.ones(1, 3, 3))
+    with pytest.raises(ShapeError):
+        K.filter2d(x[0], torch.ones(1, 3, 3))
+    with pytest.raises(ShapeError):
+        K.filter2d(x, torch.ones(3, 3))
+    with pytest.raises(BaseError, match="Invalid border, a. Ex"):
+        K.filter2d(x, torch.ones(1, 3, 3), border_type="a")
+    with pytest.raises(BaseError, match="Invalid padding mode, a. Ex"):
+        K.filter2d(x, torch.ones(1, 3, 3), padding="a")
+    with pytest.raises(BaseError, match="sigma must be positive"):
+        K.gaussian_blur2d(x, (3, 3), (0.0, 1.0))
+    with pytest.raises(BaseError, match="Kernel size must be"):
+        K.gaussian_blur2d(x, (4, 3), (1.0, 1.0))
+    with pytest.raises(ShapeError):
+        K.gaussian_blur2d(x, (3, 3), torch.ones(1, 3))
+    with pytest.raises(ValueError, match="batch size must be the same"):
+        K.transform_points(torch.eye(3)[None].expand(2, 3, 3), torch.rand(3, 4, 2))
+    with pytest.raises(TypeError, match="same device"):
+        K.homography_warp(x, torch.eye(3, device="meta")[None], (4, 4))
+
+
+def test_check_switch_and_kernel_builders():
+    from kornia_amd.core import KORNIA_CHECK, are_checks_enabled, disable_checks, enable_checks
+    from kornia_amd.core.exceptions import BaseError
+    from kornia_amd.filters import get_gaussian_kernel1d, get_gaussian_kernel2d, get_spatial_gradient_kernel2d, normalize_kernel2d
+
+    assert are_checks_enabled()
+    with pytest.raises(BaseError):
+        KORNIA_CHECK(False, "boom")
+    disable_checks()
+    try:
+        assert KORNIA_CHECK(False, "boom") is True
+    finally:
+        enable_checks()
+    k = get_gaussian_kernel1d(5, 1.5)
+    assert torch.allclose(k, torch.tensor([[0.1201, 0.2339, 0.2921, 0.2339, 0.1201]]), atol=1e-4)
+    k2 = get_gaussian_kernel2d((3, 5), (1.0, 2.0))
+    assert k2.shape == (1, 3, 5) and abs(k2.sum().item() - 1.0) < 1e-6
+    s = get_spatial_gradient_kernel2d("sobel", 1)
+    assert s.shape == (2, 3, 3) and torch.equal(s[1], s[0].t())
+    assert torch.allclose(normalize_kernel2d(s).abs().sum((-1, -2)), torch.ones(2))
+    assert get_spatial_gradient_kernel2d("diff", 2).shape == (3, 3, 3)
+    assert get_spatial_gradient_kernel2d("sobel", 2).shape == (3, 5, 5)
+
+
+def test_host_side_conventions():
+    from kornia_amd.filters.filter import _compute_padding
+    from kornia_amd.geometry import convert_affinematrix_to_homography, create_meshgrid, normal_transform_pixel
+
+    assert _compute_padding([5, 6]) == [2, 3, 2, 2]  # width pair first; even kernels pad (k-1)//2 in front
+    assert _compute_padding([2, 2]) == [0, 1, 0, 1]
+    n = normal_transform_pixel(3, 5)
+    assert torch.allclose(n, torch.tensor([[[0.5, 0.0, -1.0], [0.0, 1.0, -1.0], [0.0, 0.0, 1.0]]]))
+    h = convert_affinematrix_to_homography(torch.eye(2, 3)[None])
+    assert torch.equal(h, torch.eye(3)[None])
+    g = create_meshgrid(2, 3)
+    assert g.shape == (1, 2, 3, 2) and torch.equal(g[0, 0, :, 0], torch.tensor([-1.0, 0.0, 1.0]))

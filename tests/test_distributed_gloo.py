@@ -1,0 +1,72 @@
+"""CPU, world_size 2, gloo: the batch-shard / all_gather path used for N > 1 GPUs.  The per-rank op is
+the CPU oracle here (tests only) - the sharding logic is op-agnostic."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, batch, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from _util import flagship_homographies
+
+        from kornia_amd.distributed import shard_bounds, sharded_apply
+
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand(batch, 3, 32, 40, generator=g)
+        M = flagship_homographies(batch, 32, 40, 32, 40, g, jitter=2.0)
+        shared_A = torch.tensor([[[1.0, 0.0, 1.5], [0.0, 1.0, -0.5]]])
+
+        def op(xs, Ms):
+            return oracle.gaussian_blur2d(oracle.warp_perspective(xs, Ms, (32, 40)), (5, 5), (1.5, 1.5))
+
+        full = op(x, M)
+        got = sharded_apply(op, x, M)
+        assert got.shape == full.shape and torch.equal(got, full), "gathered result differs from the unsharded one"
+        local = sharded_apply(op, x, M, gather=False)
+        lo, hi = shard_bounds(batch, world, rank)
+        assert torch.equal(local, full[lo:hi])
+        # a shared (1,2,3) matrix is replicated, not sliced
+        got2 = sharded_apply(lambda xs, A: oracle.warp_affine(xs, A, (32, 40)), x, shared_A)
+        assert torch.equal(got2, oracle.warp_affine(x, shared_A, (32, 40)))
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [6, 5])  # even and uneven split
+def test_sharded_apply_world2_gloo(tmp_path, batch):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, batch, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_shard_bounds():
+    from kornia_amd.distributed import shard_batch, shard_bounds
+
+    assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_bounds(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+    x, m = torch.zeros(8, 3), torch.zeros(1, 3, 3)
+    xs, ms, n = shard_batch([x, m, None], 8, 4, 1)
+    assert xs.shape[0] == 2 and ms is m and n is None

@@ -1,0 +1,51 @@
+"""Build-container only (needs /root/reference): kornia_amd.patch() rebinds the hot-path names in every
+kornia module, CPU calls keep flowing to Kornia's own code, unpatch() restores everything; plus a live
+oracle-vs-reference check at a size with no committed fixture."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import ref_shim  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_shim.reference_available(), reason="reference tree not present (GPU box)")
+
+
+def test_patch_and_unpatch():
+    K = ref_shim.import_reference()
+    import kornia.augmentation._2d.geometric.affine as aff_mod
+    import kornia.geometry.transform.affwarp as affwarp
+
+    import kornia_amd.patch as P
+
+    orig = K.geometry.transform.imgwarp.warp_affine
+    n = P.patch()
+    try:
+        assert n > 20 and P.is_patched()
+        assert aff_mod.warp_affine is not orig and aff_mod.warp_affine.__wrapped__ is orig
+        assert affwarp.warp_affine is aff_mod.warp_affine
+        assert K.filters.gaussian_blur2d.__wrapped__ is not None
+        # CPU tensors: Kornia's own implementation runs, results identical
+        x = torch.rand(2, 3, 16, 16)
+        A = torch.tensor([[[1.0, 0.0, 1.0], [0.0, 1.0, 2.0]]]).repeat(2, 1, 1)
+        assert torch.equal(K.geometry.transform.warp_affine(x, A, (16, 16)), orig(x, A, (16, 16)))
+        aug = K.augmentation.RandomAffine(degrees=10.0, p=1.0)
+        assert aug(x).shape == x.shape
+        assert torch.equal(K.filters.sobel(x), K.filters.sobel.__wrapped__(x))
+    finally:
+        assert P.unpatch() == n
+    assert aff_mod.warp_affine is orig and not P.is_patched()
+
+
+def test_oracle_vs_live_reference_config2_like(oracle):
+    K = ref_shim.import_reference()
+    from _util import flagship_homographies
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 512, 512, generator=g)
+    M = flagship_homographies(2, 512, 512, 512, 512, g)
+    ref = K.filters.gaussian_blur2d(K.geometry.transform.warp_perspective(x, M, (512, 512)), (5, 5), (1.5, 1.5))
+    out = oracle.gaussian_blur2d(oracle.warp_perspective(x, M, (512, 512)), (5, 5), (1.5, 1.5))
+    assert torch.equal(out, ref)
