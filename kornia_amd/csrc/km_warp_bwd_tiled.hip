@@ -34,11 +34,11 @@
 
 #include "km_sampler.h"
 
-#define KMT_TW 32
+#define KMT_TW 64
 #define KMT_TH 32
 #define KMT_PX 4            // source pixels per thread (rows ty, ty+8, ty+16, ty+24)
 #define KMT_CC 3            // channels per pass
-#define KMT_LDS_BYTES (40 * 1024)
+#define KMT_LDS_BYTES (2 * 256 * 4 + KMT_CC * KMT_TH * KMT_TW * 4)
 
 template <typename T>
 struct KmWarpTiledArgs {
@@ -92,141 +92,29 @@ __device__ __forceinline__ void kmt_accumulate_gm(float (&gm)[9], const KmCoord<
     }
 }
 
-// ---- phase 1 for one staged slot e (branch-free: invalid slots recompute slot 0 and store nothing) ------
-template <typename T, int CM, bool WANT_GM>
-__device__ __forceinline__ void kmt_stage_q(const KmWarpTiledArgs<T>& a, const float (&m)[9], int e, int nq, int bw, float inv_bw,
-                                           int j0, int ib, const float* s_u, const float* s_v, float2* sxy, float* sg, int NQ,
-                                           int cbase, int cc, const T* src_b, const T* gout_b, size_t src_plane, size_t dst_plane,
-                                           int X0, int X1, int Y0, int Y1, float (&gm)[9]) {
-    typedef float R;
-    const KmWarpGeom<R>& g = a.g;
-    const bool valid = e < nq;
-    const int ec = valid ? e : 0;
-    int qi = (int)(((float)ec + 0.5f) * inv_bw);
-    int qj = ec - qi * bw;
-    if (qj < 0) { qi -= 1; qj += bw; }
-    if (qj >= bw) { qi += 1; qj -= bw; }
-    const int jj = j0 + qj, ii = ib + qi;
-    KmCoord<R> cd;
-    km_gen_coord<R, CM>(m, s_u[qj], s_v[qi], cd);
-    R mx, my;
-    const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
-    const R y = km_unnormalize(cd.gy, g.H, g.align, my);
-    const bool live = (x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H);  // can touch an in-image pixel
-    const T* go_px = gout_b + (size_t)ii * g.w + jj;
-    R go[KMT_CC];
-#pragma unroll
-    for (int c = 0; c < KMT_CC; ++c) go[c] = (c < cc) ? (R)km_ld(go_px + (size_t)(cbase + c) * dst_plane) : (R)0;
-    if (valid) {
-        sxy[e] = live ? make_float2(x, y) : make_float2(-1.0e30f, -1.0e30f);
-#pragma unroll
-        for (int c = 0; c < KMT_CC; ++c)
-            if (c < cc) sg[c * NQ + e] = go[c];
-    }
-    if (WANT_GM) {
-        KmBilin<R> t;
-        km_bilinear_setup(x, y, g.W, g.H, t);
-        // the tile holding the clamped north-west tap owns q's matrix gradient
-        const int x0 = (int)fmaxf(fminf(km_floor(x), (R)g.W), (R)-1), y0 = (int)fmaxf(fminf(km_floor(y), (R)g.H), (R)-1);
-        const int ox = min(max(x0, 0), g.W - 1), oy = min(max(y0, 0), g.H - 1);
-        const bool own = valid && live && (ox >= X0 && ox < X1 && oy >= Y0 && oy < Y1);
-        // all tap loads are unconditional (indices are clamped to valid addresses) so that they can be batched
-        R gix = 0, giy = 0;
-#pragma unroll
-        for (int c = 0; c < KMT_CC; ++c) {
-            if (c < cc) {
-                const T* img = src_b + (size_t)(cbase + c) * src_plane;
-                const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
-                // out-of-bounds taps do not exist in the reference's sum: value 0 after the fill subtraction
-                const R s00 = t.b00 ? (R)km_ld(img + t.i00) - f : (R)0, s01 = t.b01 ? (R)km_ld(img + t.i01) - f : (R)0;
-                const R s10 = t.b10 ? (R)km_ld(img + t.i10) - f : (R)0, s11 = t.b11 ? (R)km_ld(img + t.i11) - f : (R)0;
-                // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
-                gix += go[c] * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
-                giy += go[c] * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
-            }
-        }
-        if (own) kmt_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
-    }
-}
-
-// ---- phase 2 for one owned pixel: gather from the window of staged q's -----------------------------------
-template <bool SMALL>
-__device__ __forceinline__ void kmt_gather_p(const float (&G)[9], float fx, float fy, float ex, float ey, int nwx, int nwy, int j0,
-                                            int j1, int ib, int ie, int bw, const float2* sxy, const float* sg, int NQ, int cc,
-                                            float (&acc)[KMT_CC]) {
-    typedef float R;
-    const R D = G[6] * fx + G[7] * fy + G[8];
-    const R rD = __frcp_rn(D);
-    const R fj = (G[0] * fx + G[1] * fy + G[2]) * rD;
-    const R fi = (G[3] * fx + G[4] * fy + G[5]) * rD;
-    const int jlo = (int)ceilf(fj - ex), ilo = (int)ceilf(fi - ey);
-    if (SMALL) {
-        // window <= 3x3 (near-unit scale): fully unrolled, every LDS read unconditional and independent
-        bool cok[3];
-        int coff[3];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int jc = jlo + dx;
-            cok[dx] = (jc >= j0) && (jc <= j1) && (dx < nwx);
-            coff[dx] = jc - j0;
-        }
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int ic = ilo + dy;
-            const bool rin = (ic >= ib) && (ic <= ie) && (dy < nwy);
-            const int rbase = (ic - ib) * bw;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const bool inb = rin && cok[dx];
-                const int idx = inb ? rbase + coff[dx] : 0;
-                const float2 xy = sxy[idx];
-                const R xf = km_floor(xy.x), yf = km_floor(xy.y);
-                // forward weights: tap x0 -> (x0+1) - x ; tap x0+1 -> x - x0
-                const R ddx = fx - xf, ddy = fy - yf;
-                const R wx = (ddx == 0.f) ? (xf + 1.0f) - xy.x : ((ddx == 1.0f) ? xy.x - xf : 0.f);
-                const R wy = (ddy == 0.f) ? (yf + 1.0f) - xy.y : ((ddy == 1.0f) ? xy.y - yf : 0.f);
-                const R wgt = inb ? wx * wy : 0.f;
-#pragma unroll
-                for (int c = 0; c < KMT_CC; ++c)
-                    if (c < cc) acc[c] += wgt * sg[c * NQ + idx];
-            }
-        }
-    } else {
-        for (int dy = 0; dy < nwy; ++dy) {
-            const int ic = ilo + dy;
-            if (ic < ib || ic > ie) continue;
-            const int rowoff = (ic - ib) * bw - j0;
-            for (int dx = 0; dx < nwx; ++dx) {
-                const int jc = jlo + dx;
-                if (jc < j0 || jc > j1) continue;
-                const int idx = rowoff + jc;
-                const float2 xy = sxy[idx];
-                const R xf = km_floor(xy.x), yf = km_floor(xy.y);
-                R wx = 0.f, wy = 0.f;
-                if (xf == fx) wx = (xf + 1.0f) - xy.x; else if (xf + 1.0f == fx) wx = xy.x - xf;
-                if (yf == fy) wy = (yf + 1.0f) - xy.y; else if (yf + 1.0f == fy) wy = xy.y - yf;
-                const R wgt = wx * wy;
-                if (wgt != 0.f) {
-#pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c)
-                        if (c < cc) acc[c] += wgt * sg[c * NQ + idx];
-                }
-            }
-        }
-    }
-}
-
-#define KMT_TAB 128  // capacity of the per-band base-coordinate tables
+#define KMT_TAB 256  // capacity of the per-band base-coordinate tables
 
 // block-uniform values computed with VALU float math live in VGPRs unless moved to SGPRs explicitly
 __device__ __forceinline__ float kmt_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int kmt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Tile-owner SCATTER with fixed-point LDS accumulators.
+//
+// gfx950 measurements that shape this kernel (scratch micro-benchmark, 2048 blocks x 256 threads):
+//   ds_add_f32 / ds_add_rtn_f32    193 cycles per wave-instruction per CU   (float LDS atomics are ~40x slower
+//   ds_add_u32 / ds_add_rtn_u32      5 cycles per wave-instruction per CU    than integer ones)
+// so the per-tap contributions w * grad_out are accumulated as int32 fixed point: the block first finds
+// M = max |grad_out| over the output pixels it will visit, picks scale = 2^k with
+// k = 30 - hb - ceil(log2 M) (hb = head-room bits for the number of taps that can land on one source pixel,
+// from the Jacobian bound), and adds rint(w * g * scale) with ds_add_u32.  Per-term error <= 2^-(k+1),
+// i.e. <= M * 2^-(27-hb): the same order as one fp32 ulp of M.  Integer addition is associative, so the
+// result is independent of the order in which waves run: bit-reproducible, unlike float atomics.
 template <typename T, int CM, bool WANT_GM>
-__global__ __launch_bounds__(256, 2) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
+__global__ __launch_bounds__(256) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
     typedef float R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ double red[4][9];
+    __shared__ float red_max[4];
 
     const KmWarpGeom<R>& g = a.g;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
@@ -246,8 +134,11 @@ __global__ __launch_bounds__(256, 2) void km_warp_bwd_tiled_kernel(const KmWarpT
     }
 
     // ---- G: source pixel (x, y, 1) -> (Jn, In, D), output index (j, i) = (Jn, In) / D -----------------
-    R G[9];
+    int j0 = 0, j1 = g.w - 1, i0 = 0, i1 = g.h - 1;
+    R mult = 16.f;  // bound on the number of output pixels whose footprint covers one source pixel
+    bool fixed_ok = false;  // fixed-point accumulation is accurate enough (bounded multiplicity)
     {
+        R G[9];
         // adjugate of m (un-normalised inverse: the common scale cancels in the projective divide)
         const R A0 = m[4] * m[8] - m[5] * m[7], A1 = m[2] * m[7] - m[1] * m[8], A2 = m[1] * m[5] - m[2] * m[4];
         const R A3 = m[5] * m[6] - m[3] * m[8], A4 = m[0] * m[8] - m[2] * m[6], A5 = m[2] * m[3] - m[0] * m[5];
@@ -257,26 +148,17 @@ __global__ __launch_bounds__(256, 2) void km_warp_bwd_tiled_kernel(const KmWarpT
         const R bx = g.align ? -1.0f : 1.0f / (R)g.W - 1.0f;
         const R ay = g.align ? (g.H > 1 ? 2.0f / (R)(g.H - 1) : 0.0f) : 2.0f / (R)g.H;
         const R by = g.align ? -1.0f : 1.0f / (R)g.H - 1.0f;
-        // P = A * Knorm
         const R P0 = A0 * ax, P1 = A1 * ay, P2 = A0 * bx + A1 * by + A2;
         const R P3 = A3 * ax, P4 = A4 * ay, P5 = A3 * bx + A4 * by + A5;
         const R P6 = A6 * ax, P7 = A7 * ay, P8 = A6 * bx + A7 * by + A8;
         R sj, oj, si, oi;
         kmt_index_affine<CM>(g, g.w, g.lin_lo_x, g.lin_step_x, sj, oj);
         kmt_index_affine<CM>(g, g.h, g.lin_lo_y, g.lin_step_y, si, oi);
-        // index = scale * (P_row / P_den) + offs  =>  numerator rows: scale * P_row + offs * P_den
         G[0] = sj * P0 + oj * P6; G[1] = sj * P1 + oj * P7; G[2] = sj * P2 + oj * P8;
         G[3] = si * P3 + oi * P6; G[4] = si * P4 + oi * P7; G[5] = si * P5 + oi * P8;
         G[6] = P6; G[7] = P7; G[8] = P8;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) G[k] = kmt_uniform(G[k]);
-    }
 
-    // ---- box of output pixels that can touch the tile, and the per-pixel window half-sizes --------------
-    int j0 = 0, j1 = g.w - 1, i0 = 0, i1 = g.h - 1;
-    R ex = 0.f, ey = 0.f;
-    bool ok;
-    {
+        // box of output pixels that can touch the tile (corners of the tile grown by the bilinear footprint)
         const R xs[2] = {(R)(X0 - 1), (R)X1}, ys[2] = {(R)(Y0 - 1), (R)Y1};
         R jmin = 3.0e38f, jmax = -3.0e38f, imin = 3.0e38f, imax = -3.0e38f, dmin = 3.0e38f, dmax = -3.0e38f, nmax = 0.f;
         R njx = 0.f, njy = 0.f, nix = 0.f, niy = 0.f;
@@ -292,175 +174,186 @@ __global__ __launch_bounds__(256, 2) void km_warp_bwd_tiled_kernel(const KmWarpT
                 const R fj = Jn / D, fi = In / D;
                 jmin = fminf(jmin, fj); jmax = fmaxf(jmax, fj);
                 imin = fminf(imin, fi); imax = fmaxf(imax, fi);
-                // d(Jn/D)/dx = (G0 D - Jn G6) / D^2 : numerators are affine in (x,y) => extreme at corners
                 njx = fmaxf(njx, fabsf(G[0] * D - Jn * G[6])); njy = fmaxf(njy, fabsf(G[1] * D - Jn * G[7]));
                 nix = fmaxf(nix, fabsf(G[3] * D - In * G[6])); niy = fmaxf(niy, fabsf(G[4] * D - In * G[7]));
             }
         const bool same_sign = (dmin > 0.f) || (dmax < 0.f);
         const R dabs_min = fminf(fabsf(dmin), fabsf(dmax)), dabs_max = fmaxf(fabsf(dmin), fabsf(dmax));
-        ok = same_sign && (dabs_min > 1e-6f * fmaxf(nmax, dabs_max)) && (jmin == jmin) && (jmax == jmax) && (imin == imin) && (imax == imax);
+        const bool ok = same_sign && (dabs_min > 1e-6f * fmaxf(nmax, dabs_max)) && (jmin == jmin) && (jmax == jmax) && (imin == imin) && (imax == imax);
         if (ok) {
             const R big = 1.0e9f;
             j0 = max(0, (int)floorf(fmaxf(jmin, -big)) - 1);
             j1 = min(g.w - 1, (int)ceilf(fminf(jmax, big)) + 1);
             i0 = max(0, (int)floorf(fmaxf(imin, -big)) - 1);
             i1 = min(g.h - 1, (int)ceilf(fminf(imax, big)) + 1);
+            // output pixels per source pixel: the 2x2 footprint box maps to at most (2 ex + 1)(2 ey + 1) lattice points
             const R inv_d2 = 1.0f / (dabs_min * dabs_min);
-            // mean-value bound on |j(p') - j(p)| for p' in the 2x2 box around p, plus slack for the
-            // approximate evaluation of G (and of the reciprocal) in phase 2
-            ex = (njx + njy) * inv_d2 * 1.001f + 0.1f;
-            ey = (nix + niy) * inv_d2 * 1.001f + 0.1f;
-            if (!(ex < 24.f && ey < 24.f) || (j1 - j0 + 1) > KMT_TAB) ok = false;  // strong magnification: scanning fallback
+            const R ex = (njx + njy) * inv_d2 + 0.1f, ey = (nix + niy) * inv_d2 + 0.1f;
+            mult = fminf((2.f * ex + 1.f) * (2.f * ey + 1.f), 1.0e6f);
+            fixed_ok = mult <= 256.f;  // beyond ~7x magnification the head-room would eat the mantissa: float path
+        } else {
+            // tile crossed by the vanishing line: visit the whole output (correct, slower); no multiplicity bound
+            mult = (R)g.w * (R)g.h;
         }
-        if (!ok) { j0 = 0; j1 = g.w - 1; i0 = 0; i1 = g.h - 1; }
     }
     j0 = kmt_uniform(j0); j1 = kmt_uniform(j1); i0 = kmt_uniform(i0); i1 = kmt_uniform(i1);
-    ex = kmt_uniform(ex); ey = kmt_uniform(ey);
-    ok = kmt_uniform((int)ok) != 0;
     const int bw = j1 - j0 + 1, bh = i1 - i0 + 1;
     const bool empty = (bw <= 0 || bh <= 0);
     const float inv_bw = kmt_uniform(bw > 0 ? 1.0f / (float)bw : 0.f);
-    const int nwx = (int)floorf(2.0f * ex) + 1, nwy = (int)floorf(2.0f * ey) + 1;
-    const bool small_window = (nwx <= 3 && nwy <= 3);
+    const int hb = kmt_uniform((int)ceilf(log2f(fmaxf(mult, 1.f))) + 1);  // head-room bits
+    fixed_ok = kmt_uniform((int)fixed_ok) != 0;
 
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
     const T* src_b = a.src + (size_t)b * g.C * src_plane;
     const T* gout_b = a.gout + (size_t)b * g.C * dst_plane;
     R* gsrc_b = a.gsrc + (size_t)b * g.C * src_plane;
 
-    // owned pixels of this thread
-    const int px = X0 + (tid & 31);
-    const int py_base = Y0 + (tid >> 5);
-    const bool px_in = px < X1;
-
     R gm[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) gm[k] = 0;
 
-    // LDS carve: base-coordinate tables, then the staging arrays
-    float* s_u = (float*)smem_raw;                  // [KMT_TAB]
-    float* s_v = s_u + KMT_TAB;                      // [KMT_TAB]
-    char* stage_raw = smem_raw + 2 * KMT_TAB * sizeof(float);
-    const int stage_bytes = a.lds_bytes - 2 * KMT_TAB * (int)sizeof(float);
+    // LDS carve: base-coordinate tables, then the int32 accumulators [cc][TH][TW]
+    float* s_u = (float*)smem_raw;  // [KMT_TAB]
+    float* s_v = s_u + KMT_TAB;      // [KMT_TAB]
+    int* s_acc = (int*)(s_v + KMT_TAB);
+    const bool tab_x = bw <= KMT_TAB;
 
     for (int cbase = 0; cbase < g.C; cbase += KMT_CC) {
         const int cc = min(KMT_CC, g.C - cbase);
-        R acc[KMT_PX][KMT_CC];
-#pragma unroll
-        for (int k = 0; k < KMT_PX; ++k)
-#pragma unroll
-            for (int c = 0; c < KMT_CC; ++c) acc[k][c] = 0.f;
+        for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0;
+        if (tab_x && tid < bw) s_u[tid] = km_base_x<R, CM>(g, j0 + tid);
 
-        const int NQ = stage_bytes / (8 + 4 * cc);
-        if (ok && !empty) {
-            float2* sxy = (float2*)stage_raw;
-            float* sg = (float*)(stage_raw + (size_t)NQ * 8);
-            const int band_rows = max(1, min(KMT_TAB, NQ / bw));
-            if (tid < bw) s_u[tid] = km_base_x<R, CM>(g, j0 + tid);
-            for (int ib = i0; ib <= i1; ib += band_rows) {
-                const int ie = min(i1, ib + band_rows - 1);
-                const int nq = bw * (ie - ib + 1);
-                if (tid >= 128 && tid - 128 <= ie - ib) s_v[tid - 128] = km_base_y<R, CM>(g, ib + tid - 128);
-                __syncthreads();
-                // -------- phase 1: stage (x, y, grad_out) of every q of the band; matrix gradient --------
-                int base = 0;
-                for (; base < nq; base += 256)
-                    kmt_stage_q<T, CM, WANT_GM>(a, m, base + tid, nq, bw, inv_bw, j0, ib, s_u, s_v, sxy, sg, NQ, cbase, cc, src_b, gout_b,
-                                                src_plane, dst_plane, X0, X1, Y0, Y1, gm);
-                __syncthreads();
-                // -------- phase 2: every owned pixel gathers from its window of q's --------
-                if (px_in) {
-#pragma unroll
-                    for (int k = 0; k < KMT_PX; ++k) {
-                        const int py = py_base + 8 * k;
-                        if (py < Y1) {
-                            if (small_window)
-                                kmt_gather_p<true>(G, (R)px, (R)py, ex, ey, nwx, nwy, j0, j1, ib, ie, bw, sxy, sg, NQ, cc, acc[k]);
-                            else
-                                kmt_gather_p<false>(G, (R)px, (R)py, ex, ey, nwx, nwy, j0, j1, ib, ie, bw, sxy, sg, NQ, cc, acc[k]);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);  // keep the 4 pixels' LDS reads from being hoisted together (VGPRs)
-                    }
-                }
-                __syncthreads();
-            }
-        } else if (!empty) {
-            // ---- fallback: scan the box with LDS atomics (tile crossed by the vanishing line, or huge box) ----
-            float* s_acc = (float*)stage_raw;  // [cc][TH][TW]
-            for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0.f;
-            __syncthreads();
+        // ---- pass A: M = max |grad_out| over the box (these loads also warm L2 for pass B) ----
+        R vmax = 0.f;
+        bool bad = false;
+        if (!empty) {
             const int nq = bw * bh;
             for (int e = tid; e < nq; e += 256) {
-                const int qi = e / bw, qj = e - qi * bw;
-                const int jj = j0 + qj, ii = i0 + qi;
-                const R u = km_base_x<R, CM>(g, jj);
-                const R v = km_base_y<R, CM>(g, ii);
-                KmCoord<R> cd;
-                km_gen_coord<R, CM>(m, u, v, cd);
-                R mx, my;
-                const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
-                const R y = km_unnormalize(cd.gy, g.H, g.align, my);
-                KmBilin<R> t;
-                km_bilinear_setup(x, y, g.W, g.H, t);
-                if (!(t.b00 || t.b01 || t.b10 || t.b11)) continue;
-                const R xf = km_floor(x), yf = km_floor(y);
-                const int x0 = (int)fmaxf(fminf(xf, (R)g.W), (R)-1), y0 = (int)fmaxf(fminf(yf, (R)g.H), (R)-1);
-                const int x1 = x0 + 1, y1 = y0 + 1;
-                const bool in_x0 = (x0 >= X0 && x0 < X1), in_x1 = (x1 >= X0 && x1 < X1);
-                const bool in_y0 = (y0 >= Y0 && y0 < Y1), in_y1 = (y1 >= Y0 && y1 < Y1);
-                const bool t00 = t.b00 && in_x0 && in_y0, t01 = t.b01 && in_x1 && in_y0;
-                const bool t10 = t.b10 && in_x0 && in_y1, t11 = t.b11 && in_x1 && in_y1;
-                const int ox = min(max(x0, 0), g.W - 1), oy = min(max(y0, 0), g.H - 1);
-                const bool own = WANT_GM && (ox >= X0 && ox < X1 && oy >= Y0 && oy < Y1);
-                if (!(t00 || t01 || t10 || t11 || own)) continue;
-                const T* go_px = gout_b + (size_t)ii * g.w + jj;
-                const int l00 = (y0 - Y0) * KMT_TW + (x0 - X0);
-                R gix = 0, giy = 0;
-                for (int c = 0; c < cc; ++c) {
-                    const R go = km_ld(go_px + (size_t)(cbase + c) * dst_plane);
-                    R* accp = s_acc + c * (KMT_TH * KMT_TW);
-                    if (t00) atomicAdd(accp + l00, t.w00 * go);
-                    if (t01) atomicAdd(accp + l00 + 1, t.w01 * go);
-                    if (t10) atomicAdd(accp + l00 + KMT_TW, t.w10 * go);
-                    if (t11) atomicAdd(accp + l00 + KMT_TW + 1, t.w11 * go);
-                    if (own) {
-                        const T* img = src_b + (size_t)(cbase + c) * src_plane;
-                        const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
-                        if (t.b00) { const R s = km_ld(img + t.i00) - f; gix -= s * t.wy1 * go; giy -= s * t.wx1 * go; }
-                        if (t.b01) { const R s = km_ld(img + t.i01) - f; gix += s * t.wy1 * go; giy -= s * t.wx0 * go; }
-                        if (t.b10) { const R s = km_ld(img + t.i10) - f; gix -= s * t.wy0 * go; giy += s * t.wx1 * go; }
-                        if (t.b11) { const R s = km_ld(img + t.i11) - f; gix += s * t.wy0 * go; giy += s * t.wx0 * go; }
-                    }
-                }
-                if (own) kmt_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
-            }
-            __syncthreads();
-            if (px_in) {
+                int qi = (int)(((float)e + 0.5f) * inv_bw);
+                int qj = e - qi * bw;
+                if (qj < 0) { qi -= 1; qj += bw; }
+                if (qj >= bw) { qi += 1; qj -= bw; }
+                const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
 #pragma unroll
-                for (int k = 0; k < KMT_PX; ++k) {
-                    const int py = py_base + 8 * k;
-                    if (py < Y1) {
-#pragma unroll
-                        for (int c = 0; c < KMT_CC; ++c)
-                            if (c < cc) acc[k][c] = s_acc[c * (KMT_TH * KMT_TW) + (py - Y0) * KMT_TW + (px - X0)];
+                for (int c = 0; c < KMT_CC; ++c)
+                    if (c < cc) {
+                        const R v = km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane));
+                        bad = bad || !(v <= 3.0e38f);
+                        vmax = fmaxf(vmax, v);
                     }
-                }
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+        const unsigned long long badmask = __ballot(bad);
+        if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vmax;
+        __syncthreads();
+        const R M = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+        // scale = 2^k with |w * g * scale| * (taps per pixel) < 2^30
+        const bool finite = (M <= 3.0e38f) && fixed_ok;  // else: IEEE float accumulation (slow ds_add_f32)
+        int kexp = 0;
+        if (finite && M > 0.f) {
+            int ex2;
+            (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
+            kexp = 30 - hb - ex2;
+            kexp = max(-126, min(126, kexp));
+        }
+        const R scale = kmt_uniform(ldexpf(1.0f, kexp)), inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
 
-        // ---- write the owned pixels (32 consecutive floats per half-wave row) ----
-        if (px_in) {
+        // ---- pass B: scatter ----
+        if (!empty && (M > 0.f || WANT_GM)) {
+            for (int ib = i0; ib <= i1; ib += KMT_TAB) {
+                const int ie = min(i1, ib + KMT_TAB - 1);
+                __syncthreads();
+                if (tid <= ie - ib) s_v[tid] = km_base_y<R, CM>(g, ib + tid);
+                __syncthreads();
+                const int nq = bw * (ie - ib + 1);
+                for (int e = tid; e < nq; e += 256) {
+                    int qi = (int)(((float)e + 0.5f) * inv_bw);
+                    int qj = e - qi * bw;
+                    if (qj < 0) { qi -= 1; qj += bw; }
+                    if (qj >= bw) { qi += 1; qj -= bw; }
+                    const int jj = j0 + qj, ii = ib + qi;
+                    const T* go_px = gout_b + (size_t)ii * g.w + jj;
+                    R go[KMT_CC];
 #pragma unroll
-            for (int k = 0; k < KMT_PX; ++k) {
-                const int py = py_base + 8 * k;
-                if (py < Y1) {
+                    for (int c = 0; c < KMT_CC; ++c) go[c] = (c < cc) ? (R)km_ld(go_px + (size_t)(cbase + c) * dst_plane) : (R)0;
+                    KmCoord<R> cd;
+                    km_gen_coord<R, CM>(m, tab_x ? s_u[qj] : km_base_x<R, CM>(g, jj), s_v[qi], cd);
+                    R mx, my;
+                    const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
+                    const R y = km_unnormalize(cd.gy, g.H, g.align, my);
+                    if (!((x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H))) continue;  // no in-image tap
+                    KmBilin<R> t;
+                    km_bilinear_setup(x, y, g.W, g.H, t);
+                    const int x0 = (int)km_floor(x), y0 = (int)km_floor(y);
+                    const int x1 = x0 + 1, y1 = y0 + 1;
+                    const bool in_x0 = (x0 >= X0 && x0 < X1), in_x1 = (x1 >= X0 && x1 < X1);
+                    const bool in_y0 = (y0 >= Y0 && y0 < Y1), in_y1 = (y1 >= Y0 && y1 < Y1);
+                    const bool t00 = t.b00 && in_x0 && in_y0, t01 = t.b01 && in_x1 && in_y0;
+                    const bool t10 = t.b10 && in_x0 && in_y1, t11 = t.b11 && in_x1 && in_y1;
+                    // the tile holding the clamped north-west tap owns q's matrix gradient
+                    const int ox = min(max(x0, 0), g.W - 1), oy = min(max(y0, 0), g.H - 1);
+                    const bool own = WANT_GM && (ox >= X0 && ox < X1 && oy >= Y0 && oy < Y1);
+                    if (!(t00 || t01 || t10 || t11 || own)) continue;
+                    const int l00 = (y0 - Y0) * KMT_TW + (x0 - X0);
+                    if (finite) {
+                        const R w00 = t.w00 * scale, w01 = t.w01 * scale, w10 = t.w10 * scale, w11 = t.w11 * scale;
 #pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c)
-                        if (c < cc) gsrc_b[(size_t)(cbase + c) * src_plane + (size_t)py * g.W + px] = acc[k][c];
+                        for (int c = 0; c < KMT_CC; ++c) {
+                            if (c < cc) {
+                                int* accp = s_acc + c * (KMT_TH * KMT_TW) + l00;
+                                if (t00) atomicAdd(accp, __float2int_rn(w00 * go[c]));
+                                if (t01) atomicAdd(accp + 1, __float2int_rn(w01 * go[c]));
+                                if (t10) atomicAdd(accp + KMT_TW, __float2int_rn(w10 * go[c]));
+                                if (t11) atomicAdd(accp + KMT_TW + 1, __float2int_rn(w11 * go[c]));
+                            }
+                        }
+                    } else {
+                        // inf / NaN in grad_out, vanishing-line tiles, extreme magnification: float LDS atomics
+#pragma unroll
+                        for (int c = 0; c < KMT_CC; ++c) {
+                            if (c < cc) {
+                                float* accp = (float*)s_acc + c * (KMT_TH * KMT_TW) + l00;
+                                if (t00) atomicAdd(accp, t.w00 * go[c]);
+                                if (t01) atomicAdd(accp + 1, t.w01 * go[c]);
+                                if (t10) atomicAdd(accp + KMT_TW, t.w10 * go[c]);
+                                if (t11) atomicAdd(accp + KMT_TW + 1, t.w11 * go[c]);
+                            }
+                        }
+                    }
+                    if (own) {
+                        R gix = 0, giy = 0;
+#pragma unroll
+                        for (int c = 0; c < KMT_CC; ++c) {
+                            if (c < cc) {
+                                const T* img = src_b + (size_t)(cbase + c) * src_plane;
+                                const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
+                                // out-of-bounds taps do not exist in the reference's sum: value 0 after the fill subtraction
+                                const R s00 = t.b00 ? (R)km_ld(img + t.i00) - f : (R)0, s01 = t.b01 ? (R)km_ld(img + t.i01) - f : (R)0;
+                                const R s10 = t.b10 ? (R)km_ld(img + t.i10) - f : (R)0, s11 = t.b11 ? (R)km_ld(img + t.i11) - f : (R)0;
+                                // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
+                                gix += go[c] * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
+                                giy += go[c] * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+                            }
+                        }
+                        kmt_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
+                    }
                 }
             }
         }
+        __syncthreads();
+
+        // ---- convert and write the tile: rows of 64 floats, fully coalesced ----
+        for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) {
+            const int c = e / (KMT_TH * KMT_TW), r = (e / KMT_TW) % KMT_TH, col = e % KMT_TW;
+            const int yy = Y0 + r, xx = X0 + col;
+            if (yy < g.H && xx < g.W) {
+                const R val = finite ? (R)s_acc[e] * inv_scale : ((const float*)s_acc)[e];
+                gsrc_b[(size_t)(cbase + c) * src_plane + (size_t)yy * g.W + xx] = val;
+            }
+        }
+        __syncthreads();
     }
 
     if (WANT_GM) {
@@ -493,9 +386,7 @@ static int kmt_run(const void* gout, const void* src, const void* mat, void* gsr
     a.src = (const T*)src; a.gout = (const T*)gout; a.mat = (const float*)mat; a.gsrc = (float*)gsrc; a.gmat = gmat;
     a.fill = (const float*)fill;
     {
-        const char* e = getenv("KM_TILED_LDS_KB");  // tuning knob (>= 16: the scanning fallback needs C*4 KiB)
-        const int kb = e ? atoi(e) : 0;
-        a.lds_bytes = (kb >= 16 && kb <= 64) ? kb * 1024 : KMT_LDS_BYTES;
+        a.lds_bytes = KMT_LDS_BYTES;
     }
     KmWarpGeom<float>& g = a.g;
     g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
