@@ -98,6 +98,87 @@ __device__ __forceinline__ void kmt_accumulate_gm(float (&gm)[9], const KmCoord<
 __device__ __forceinline__ float kmt_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int kmt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// one output pixel of pass B.  Branch-free up to the (exec-masked) atomics: every load is unconditional
+// (clamped addresses) so that the loads of two pixels processed back to back can be in flight together.
+template <typename T, int CM, bool WANT_GM>
+__device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const float (&m)[9], int e, bool valid, int bw, float inv_bw,
+                                             int j0, int ib, bool tab_x, const float* s_u, const float* s_v, int* s_acc, bool finite,
+                                             float scale, int cbase, int cc, const T* src_b, const T* gout_b, size_t src_plane,
+                                             size_t dst_plane, int X0, int X1, int Y0, int Y1, float (&gm)[9]) {
+    typedef float R;
+    const KmWarpGeom<R>& g = a.g;
+    int qi = (int)(((float)e + 0.5f) * inv_bw);
+    int qj = e - qi * bw;
+    if (qj < 0) { qi -= 1; qj += bw; }
+    if (qj >= bw) { qi += 1; qj -= bw; }
+    const int jj = j0 + qj, ii = ib + qi;
+    const T* go_px = gout_b + (size_t)ii * g.w + jj;
+    R go[KMT_CC];
+#pragma unroll
+    for (int c = 0; c < KMT_CC; ++c) go[c] = (c < cc) ? (R)km_ld(go_px + (size_t)(cbase + c) * dst_plane) : (R)0;
+    KmCoord<R> cd;
+    km_gen_coord<R, CM>(m, tab_x ? s_u[qj] : km_base_x<R, CM>(g, jj), s_v[qi], cd);
+    R mx, my;
+    const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
+    const R y = km_unnormalize(cd.gy, g.H, g.align, my);
+    const bool live = valid && (x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H);  // has an in-image tap
+    KmBilin<R> t;
+    km_bilinear_setup(x, y, g.W, g.H, t);
+    const int x0 = (int)fmaxf(fminf(km_floor(x), (R)g.W), (R)-1), y0 = (int)fmaxf(fminf(km_floor(y), (R)g.H), (R)-1);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool in_x0 = (x0 >= X0 && x0 < X1), in_x1 = (x1 >= X0 && x1 < X1);
+    const bool in_y0 = (y0 >= Y0 && y0 < Y1), in_y1 = (y1 >= Y0 && y1 < Y1);
+    const bool t00 = live && t.b00 && in_x0 && in_y0, t01 = live && t.b01 && in_x1 && in_y0;
+    const bool t10 = live && t.b10 && in_x0 && in_y1, t11 = live && t.b11 && in_x1 && in_y1;
+    const int l00 = (y0 - Y0) * KMT_TW + (x0 - X0);
+    if (finite) {
+        const R w00 = t.w00 * scale, w01 = t.w01 * scale, w10 = t.w10 * scale, w11 = t.w11 * scale;
+#pragma unroll
+        for (int c = 0; c < KMT_CC; ++c) {
+            if (c < cc) {
+                int* accp = s_acc + c * (KMT_TH * KMT_TW) + l00;
+                if (t00) atomicAdd(accp, __float2int_rn(w00 * go[c]));
+                if (t01) atomicAdd(accp + 1, __float2int_rn(w01 * go[c]));
+                if (t10) atomicAdd(accp + KMT_TW, __float2int_rn(w10 * go[c]));
+                if (t11) atomicAdd(accp + KMT_TW + 1, __float2int_rn(w11 * go[c]));
+            }
+        }
+    } else {
+        // inf / NaN in grad_out, vanishing-line tiles, extreme magnification: float LDS atomics
+#pragma unroll
+        for (int c = 0; c < KMT_CC; ++c) {
+            if (c < cc) {
+                float* accp = (float*)s_acc + c * (KMT_TH * KMT_TW) + l00;
+                if (t00) atomicAdd(accp, t.w00 * go[c]);
+                if (t01) atomicAdd(accp + 1, t.w01 * go[c]);
+                if (t10) atomicAdd(accp + KMT_TW, t.w10 * go[c]);
+                if (t11) atomicAdd(accp + KMT_TW + 1, t.w11 * go[c]);
+            }
+        }
+    }
+    if (WANT_GM) {
+        // the tile holding the clamped north-west tap owns q's matrix gradient
+        const int ox = min(max(x0, 0), g.W - 1), oy = min(max(y0, 0), g.H - 1);
+        const bool own = live && (ox >= X0 && ox < X1 && oy >= Y0 && oy < Y1);
+        R gix = 0, giy = 0;
+#pragma unroll
+        for (int c = 0; c < KMT_CC; ++c) {
+            if (c < cc) {
+                const T* img = src_b + (size_t)(cbase + c) * src_plane;
+                const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
+                // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
+                const R v00 = (R)km_ld(img + t.i00), v01 = (R)km_ld(img + t.i01), v10 = (R)km_ld(img + t.i10), v11 = (R)km_ld(img + t.i11);
+                const R s00 = t.b00 ? v00 - f : (R)0, s01 = t.b01 ? v01 - f : (R)0;
+                const R s10 = t.b10 ? v10 - f : (R)0, s11 = t.b11 ? v11 - f : (R)0;
+                // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
+                gix += go[c] * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
+                giy += go[c] * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+            }
+        }
+        if (own) kmt_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
+    }
+}
+
 // Tile-owner SCATTER with fixed-point LDS accumulators.
 //
 // gfx950 measurements that shape this kernel (scratch micro-benchmark, 2048 blocks x 256 threads):
@@ -228,18 +309,25 @@ __global__ __launch_bounds__(256) void km_warp_bwd_tiled_kernel(const KmWarpTile
         bool bad = false;
         if (!empty) {
             const int nq = bw * bh;
-            for (int e = tid; e < nq; e += 256) {
-                int qi = (int)(((float)e + 0.5f) * inv_bw);
-                int qj = e - qi * bw;
-                if (qj < 0) { qi -= 1; qj += bw; }
-                if (qj >= bw) { qi += 1; qj -= bw; }
-                const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
+            for (int base = 0; base < nq; base += 4 * 256) {
+                R vv[4][KMT_CC];
 #pragma unroll
-                for (int c = 0; c < KMT_CC; ++c)
-                    if (c < cc) {
-                        const R v = km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane));
-                        bad = bad || !(v <= 3.0e38f);
-                        vmax = fmaxf(vmax, v);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int e = min(base + s4 * 256 + tid, nq - 1);  // clamped: duplicates do not change a max
+                    int qi = (int)(((float)e + 0.5f) * inv_bw);
+                    int qj = e - qi * bw;
+                    if (qj < 0) { qi -= 1; qj += bw; }
+                    if (qj >= bw) { qi += 1; qj -= bw; }
+                    const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
+#pragma unroll
+                    for (int c = 0; c < KMT_CC; ++c) vv[s4][c] = (c < cc) ? km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane)) : (R)0;
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int c = 0; c < KMT_CC; ++c) {
+                        bad = bad || !(vv[s4][c] <= 3.0e38f);
+                        vmax = fmaxf(vmax, vv[s4][c]);
                     }
             }
         }
@@ -268,77 +356,17 @@ __global__ __launch_bounds__(256) void km_warp_bwd_tiled_kernel(const KmWarpTile
                 if (tid <= ie - ib) s_v[tid] = km_base_y<R, CM>(g, ib + tid);
                 __syncthreads();
                 const int nq = bw * (ie - ib + 1);
-                for (int e = tid; e < nq; e += 256) {
-                    int qi = (int)(((float)e + 0.5f) * inv_bw);
-                    int qj = e - qi * bw;
-                    if (qj < 0) { qi -= 1; qj += bw; }
-                    if (qj >= bw) { qi += 1; qj -= bw; }
-                    const int jj = j0 + qj, ii = ib + qi;
-                    const T* go_px = gout_b + (size_t)ii * g.w + jj;
-                    R go[KMT_CC];
-#pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c) go[c] = (c < cc) ? (R)km_ld(go_px + (size_t)(cbase + c) * dst_plane) : (R)0;
-                    KmCoord<R> cd;
-                    km_gen_coord<R, CM>(m, tab_x ? s_u[qj] : km_base_x<R, CM>(g, jj), s_v[qi], cd);
-                    R mx, my;
-                    const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
-                    const R y = km_unnormalize(cd.gy, g.H, g.align, my);
-                    if (!((x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H))) continue;  // no in-image tap
-                    KmBilin<R> t;
-                    km_bilinear_setup(x, y, g.W, g.H, t);
-                    const int x0 = (int)km_floor(x), y0 = (int)km_floor(y);
-                    const int x1 = x0 + 1, y1 = y0 + 1;
-                    const bool in_x0 = (x0 >= X0 && x0 < X1), in_x1 = (x1 >= X0 && x1 < X1);
-                    const bool in_y0 = (y0 >= Y0 && y0 < Y1), in_y1 = (y1 >= Y0 && y1 < Y1);
-                    const bool t00 = t.b00 && in_x0 && in_y0, t01 = t.b01 && in_x1 && in_y0;
-                    const bool t10 = t.b10 && in_x0 && in_y1, t11 = t.b11 && in_x1 && in_y1;
-                    // the tile holding the clamped north-west tap owns q's matrix gradient
-                    const int ox = min(max(x0, 0), g.W - 1), oy = min(max(y0, 0), g.H - 1);
-                    const bool own = WANT_GM && (ox >= X0 && ox < X1 && oy >= Y0 && oy < Y1);
-                    if (!(t00 || t01 || t10 || t11 || own)) continue;
-                    const int l00 = (y0 - Y0) * KMT_TW + (x0 - X0);
-                    if (finite) {
-                        const R w00 = t.w00 * scale, w01 = t.w01 * scale, w10 = t.w10 * scale, w11 = t.w11 * scale;
-#pragma unroll
-                        for (int c = 0; c < KMT_CC; ++c) {
-                            if (c < cc) {
-                                int* accp = s_acc + c * (KMT_TH * KMT_TW) + l00;
-                                if (t00) atomicAdd(accp, __float2int_rn(w00 * go[c]));
-                                if (t01) atomicAdd(accp + 1, __float2int_rn(w01 * go[c]));
-                                if (t10) atomicAdd(accp + KMT_TW, __float2int_rn(w10 * go[c]));
-                                if (t11) atomicAdd(accp + KMT_TW + 1, __float2int_rn(w11 * go[c]));
-                            }
-                        }
-                    } else {
-                        // inf / NaN in grad_out, vanishing-line tiles, extreme magnification: float LDS atomics
-#pragma unroll
-                        for (int c = 0; c < KMT_CC; ++c) {
-                            if (c < cc) {
-                                float* accp = (float*)s_acc + c * (KMT_TH * KMT_TW) + l00;
-                                if (t00) atomicAdd(accp, t.w00 * go[c]);
-                                if (t01) atomicAdd(accp + 1, t.w01 * go[c]);
-                                if (t10) atomicAdd(accp + KMT_TW, t.w10 * go[c]);
-                                if (t11) atomicAdd(accp + KMT_TW + 1, t.w11 * go[c]);
-                            }
-                        }
-                    }
-                    if (own) {
-                        R gix = 0, giy = 0;
-#pragma unroll
-                        for (int c = 0; c < KMT_CC; ++c) {
-                            if (c < cc) {
-                                const T* img = src_b + (size_t)(cbase + c) * src_plane;
-                                const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
-                                // out-of-bounds taps do not exist in the reference's sum: value 0 after the fill subtraction
-                                const R s00 = t.b00 ? (R)km_ld(img + t.i00) - f : (R)0, s01 = t.b01 ? (R)km_ld(img + t.i01) - f : (R)0;
-                                const R s10 = t.b10 ? (R)km_ld(img + t.i10) - f : (R)0, s11 = t.b11 ? (R)km_ld(img + t.i11) - f : (R)0;
-                                // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
-                                gix += go[c] * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
-                                giy += go[c] * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
-                            }
-                        }
-                        kmt_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
-                    }
+                int base = 0;
+                for (; base + 2 * 256 <= nq; base += 2 * 256) {
+                    kmt_scatter_q<T, CM, WANT_GM>(a, m, base + tid, true, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale, cbase, cc,
+                                                  src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm);
+                    kmt_scatter_q<T, CM, WANT_GM>(a, m, base + 256 + tid, true, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale, cbase,
+                                                  cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm);
+                }
+                for (; base < nq; base += 256) {
+                    const int e = base + tid;
+                    kmt_scatter_q<T, CM, WANT_GM>(a, m, min(e, nq - 1), e < nq, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale, cbase,
+                                                  cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm);
                 }
             }
         }
