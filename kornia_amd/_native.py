@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libkornia_amd.so")
+LIB_PATH = os.environ.get("KORNIA_AMD_LIB") or os.path.join(_PKG, "lib", "libkornia_amd.so")  # env override: A/B builds
 ABI_VERSION = 1
 
 KM_F32, KM_F64, KM_BF16, KM_F16 = 0, 1, 2, 3
