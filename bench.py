@@ -143,12 +143,23 @@ def cpu_baseline(size, channels, cpu_batch):
         if dt > 10.0 or reps >= 20:
             break
     mpix = cpu_batch * size * size * reps / dt / 1e6
+    # second CPU figure: the plain-C oracle (OpenMP over the same host cores), fwd + bwd of the same sample
+    import oracle as c_oracle
+
+    t1 = time.perf_counter()
+    w = c_oracle.warp_perspective(x, M, (size, size))
+    c_oracle.gaussian_blur2d(w, (5, 5), (1.5, 1.5))
+    gw = c_oracle.gaussian_blur2d_backward(go, w, (5, 5), (1.5, 1.5))
+    c_oracle.warp_perspective_backward(gw, x, M, (size, size))
+    c_dt = time.perf_counter() - t1
     return {
         "value": round(mpix, 3),
         "unit": "Mpix/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"{reps} fwd+bwd steps of B={cpu_batch}x{channels}x{size}x{size} fp32 through the reference's PyTorch-CPU op sequence (oracle/torch_ref.py), {dt:.1f} s",
+        "c_oracle_value": round(cpu_batch * size * size / c_dt / 1e6, 3),
+        "c_oracle_note": f"plain-C oracle (OpenMP, {os.cpu_count()} threads), one fwd+bwd of the same sample in {c_dt:.2f} s",
     }
 
 
