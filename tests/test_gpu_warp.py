@@ -298,3 +298,38 @@ def test_warp_adjoint_identity_at_full_size():
     x2 = torch.rand(16, 3, 512, 512, device="cuda", generator=g)
     lin = K.warp_perspective(x.detach() + 2 * x2, M, (512, 512)) - (Wx.detach() + 2 * K.warp_perspective(x2, M, (512, 512)))
     assert lin.abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-6, 1.0, 1e12, 1e30])
+def test_tiled_backward_fixed_point_dynamic_range(oracle, scale):
+    """grad_src is accumulated as int32 fixed point relative to the largest |grad_out| a tile sees: the error
+    must stay ~1e-7 of that maximum whatever the absolute magnitude of the incoming gradient."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(2, 3, 70, 90, generator=g)
+    M = flagship_homographies(2, 70, 90, 70, 90, g, jitter=4.0)
+    go = (torch.rand(2, 3, 70, 90, generator=g) - 0.3) * scale
+    xg = x.cuda().requires_grad_()
+    K.warp_perspective(xg, M.cuda(), (70, 90)).backward(go.cuda())
+    gs_o, _ = oracle.warp_perspective_backward(go, x, M, (70, 90))
+    err = (xg.grad.cpu() - gs_o).abs().max().item()
+    assert err <= 2e-6 * scale, f"abs err {err:.3e} vs scale {scale:.1e}"
+
+
+def test_tiled_backward_nonfinite_gradients_propagate(oracle):
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(1, 3, 70, 90, generator=g)
+    M = flagship_homographies(1, 70, 90, 70, 90, g, jitter=2.0)
+    go = torch.rand(1, 3, 70, 90, generator=g)
+    go[0, 1, 30, 40] = float("inf")
+    go[0, 2, 10, 10] = float("nan")
+    xg = x.cuda().requires_grad_()
+    K.warp_perspective(xg, M.cuda(), (70, 90)).backward(go.cuda())
+    gs = xg.grad.cpu()
+    gs_o, _ = oracle.warp_perspective_backward(go, x, M, (70, 90))
+    assert torch.equal(torch.isnan(gs), torch.isnan(gs_o)) and torch.equal(torch.isinf(gs), torch.isinf(gs_o))
+    fin = torch.isfinite(gs_o)
+    assert torch.allclose(gs[fin], gs_o[fin], atol=1e-5, rtol=1e-5)
