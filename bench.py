@@ -235,6 +235,16 @@ def main():
             kstats = kernel_roofline(x.detach(), M.detach(), go, S, max(5, min(args.steps, 20)))
         dom = max(kstats, key=lambda k: kstats[k]["ms"])
         achieved = kstats[dom]["GBps"]
+        # HBM traffic of the dominant kernel: rocprofv3 PMC cannot run inside this process, so the figure is the
+        # committed measurement of this very command/config (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if (B, C, S) == (256, 3, 512) and os.path.exists(tpath):
+            rocname = {"km_warp_bwd_kernel": "km_warp_bwd_tiled_kernel", "km_warp_fwd_kernel": "km_warp_fwd_kernel",
+                       "km_filter_sep_fwd_kernel": "km_blur_reg_kernel<float, 5, false>", "km_filter_sep_bwd_kernel": "km_blur_reg_kernel<float, 5, true>"}[dom]
+            for kname, rec in json.load(open(tpath))["kernels"].items():
+                if rocname in kname:
+                    traffic = rec["hbm_bytes_per_launch"]
         roofline = {
             "bound": "hbm",
             "kernel": dom,
@@ -242,7 +252,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)" if traffic else None,
             "kernel_ms": kstats[dom]["ms"],
             "alg_bytes_per_launch": kstats[dom]["alg_bytes"],
         }
