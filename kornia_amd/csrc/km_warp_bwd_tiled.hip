@@ -104,7 +104,7 @@ template <typename T, int CM, bool WANT_GM>
 __device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const float (&m)[9], int e, bool valid, int bw, float inv_bw,
                                              int j0, int ib, bool tab_x, const float* s_u, const float* s_v, int* s_acc, bool finite,
                                              float scale, int cbase, int cc, const T* src_b, const T* gout_b, size_t src_plane,
-                                             size_t dst_plane, int X0, int X1, int Y0, int Y1, float (&gm)[9]) {
+                                             size_t dst_plane, int X0, int X1, int Y0, int Y1, float (&gm)[9], float bound, bool& exceeded) {
     typedef float R;
     const KmWarpGeom<R>& g = a.g;
     int qi = (int)(((float)e + 0.5f) * inv_bw);
@@ -116,6 +116,9 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const
     R go[KMT_CC];
 #pragma unroll
     for (int c = 0; c < KMT_CC; ++c) go[c] = (c < cc) ? (R)km_ld(go_px + (size_t)(cbase + c) * dst_plane) : (R)0;
+    // the fixed-point scale was chosen for |grad_out| <= bound; anything larger (or NaN) voids the attempt
+#pragma unroll
+    for (int c = 0; c < KMT_CC; ++c) exceeded = exceeded || !(km_fabs(go[c]) <= bound);
     KmCoord<R> cd;
     km_gen_coord<R, CM>(m, tab_x ? s_u[qj] : km_base_x<R, CM>(g, jj), s_v[qi], cd);
     R mx, my;
@@ -299,10 +302,6 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
     const T* gout_b = a.gout + (size_t)b * g.C * dst_plane;
     R* gsrc_b = a.gsrc + (size_t)b * g.C * src_plane;
 
-    R gm[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) gm[k] = 0;
-
     // LDS carve: base-coordinate tables, then the int32 accumulators [cc][TH][TW]
     float* s_u = (float*)smem_raw;  // [KMT_TAB]
     float* s_v = s_u + KMT_TAB;      // [KMT_TAB]
@@ -314,73 +313,120 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
         for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0;
         if (tab_x && tid < bw) s_u[tid] = km_base_x<R, CM>(g, j0 + tid);
 
-        // ---- pass A: M = max |grad_out| over the box (these loads also warm L2 for pass B) ----
-        R vmax = 0.f;
-        bool bad = false;
-        if (!empty) {
-            const int nq = bw * bh;
-            for (int base = 0; base < nq; base += 4 * 256) {
-                R vv[4][KMT_CC];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int e = min(base + s4 * 256 + tid, nq - 1);  // clamped: duplicates do not change a max
+        // The scale needs an upper bound M on |grad_out| over the box.  Reading the whole box twice costs ~0.3 ms
+        // at 256x3x512^2, so attempt 0 SPECULATES: M = 8 x (max over a 256-pixel sample of the box); pass B
+        // checks every value it loads against M, and only a tile that sees a larger one (or a NaN/inf) is redone
+        // with the exact maximum (attempt 1).  The guard factor costs 3 bits of the fixed-point resolution.
+        R scale = 1.f, inv_scale = 1.f;
+        bool finite = false;
+        for (int attempt = (fixed_ok ? 0 : 1); attempt < 2; ++attempt) {
+            R vmax = 0.f;
+            bool bad = false;
+            if (!empty) {
+                const int nq = bw * bh;
+                if (attempt == 0) {
+                    const int e = (int)(((long long)tid * nq) >> 8);  // 256 pixels spread over the box
                     int qi = (int)(((float)e + 0.5f) * inv_bw);
                     int qj = e - qi * bw;
                     if (qj < 0) { qi -= 1; qj += bw; }
                     if (qj >= bw) { qi += 1; qj -= bw; }
                     const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
 #pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c) vv[s4][c] = (c < cc) ? km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane)) : (R)0;
-                }
+                    for (int c = 0; c < KMT_CC; ++c)
+                        if (c < cc) vmax = fmaxf(vmax, km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane)));
+                    vmax = vmax * 8.0f;
+                    bad = !(vmax <= 3.0e38f);
+                } else {
+                    for (int base = 0; base < nq; base += 4 * 256) {
+                        R vv[4][KMT_CC];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int e = min(base + s4 * 256 + tid, nq - 1);  // clamped: duplicates do not change a max
+                            int qi = (int)(((float)e + 0.5f) * inv_bw);
+                            int qj = e - qi * bw;
+                            if (qj < 0) { qi -= 1; qj += bw; }
+                            if (qj >= bw) { qi += 1; qj -= bw; }
+                            const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
 #pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c) {
-                        bad = bad || !(vv[s4][c] <= 3.0e38f);
-                        vmax = fmaxf(vmax, vv[s4][c]);
+                            for (int c = 0; c < KMT_CC; ++c) vv[s4][c] = (c < cc) ? km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane)) : (R)0;
+                        }
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                            for (int c = 0; c < KMT_CC; ++c) {
+                                bad = bad || !(vv[s4][c] <= 3.0e38f);
+                                vmax = fmaxf(vmax, vv[s4][c]);
+                            }
                     }
+                }
             }
-        }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-        const unsigned long long badmask = __ballot(bad);
-        if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vmax;
-        __syncthreads();
-        const R M = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
-        // scale = 2^k with |w * g * scale| * (taps per pixel) < 2^30
-        const bool finite = (M <= 3.0e38f) && fixed_ok;  // else: IEEE float accumulation (slow ds_add_f32)
-        int kexp = 0;
-        if (finite && M > 0.f) {
-            int ex2;
-            (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
-            kexp = 30 - hb - ex2;
-            kexp = max(-126, min(126, kexp));
-        }
-        const R scale = kmt_uniform(ldexpf(1.0f, kexp)), inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+            const unsigned long long badmask = __ballot(bad);
+            __syncthreads();  // red_max may still be read by a previous attempt / channel chunk
+            if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vmax;
+            __syncthreads();
+            const R M = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+            // scale = 2^k with |w * g * scale| * (taps per pixel) < 2^30
+            finite = (M <= 3.0e38f) && fixed_ok;  // else: IEEE float accumulation (slow ds_add_f32)
+            int kexp = 0;
+            if (finite && M > 0.f) {
+                int ex2;
+                (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
+                kexp = 30 - hb - ex2;
+                kexp = max(-126, min(126, kexp));
+            }
+            scale = kmt_uniform(ldexpf(1.0f, kexp));
+            inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
+            const R bound = finite ? M : __int_as_float(0x7f800000);  // the float path accepts anything
 
-        // ---- pass B: scatter ----
-        if (!empty && (M > 0.f || WANT_GM)) {
-            for (int ib = i0; ib <= i1; ib += KMT_TAB) {
-                const int ie = min(i1, ib + KMT_TAB - 1);
-                __syncthreads();
-                if (tid <= ie - ib) s_v[tid] = km_base_y<R, CM>(g, ib + tid);
-                __syncthreads();
-                const int nq = bw * (ie - ib + 1);
-                int base = 0;
-                for (; base + KMT_UNROLL * 256 <= nq; base += KMT_UNROLL * 256) {
+            // ---- pass B: scatter ----
+            R gm_try[9];
 #pragma unroll
-                    for (int s4 = 0; s4 < KMT_UNROLL; ++s4)
-                        kmt_scatter_q<T, CM, WANT_GM>(a, m, base + s4 * 256 + tid, true, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale,
-                                                      cbase, cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm);
-                }
-                for (; base < nq; base += 256) {
-                    const int e = base + tid;
-                    kmt_scatter_q<T, CM, WANT_GM>(a, m, min(e, nq - 1), e < nq, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale, cbase,
-                                                  cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm);
+            for (int k = 0; k < 9; ++k) gm_try[k] = 0;
+            bool exceeded = false;
+            if (!empty) {
+                for (int ib = i0; ib <= i1; ib += KMT_TAB) {
+                    const int ie = min(i1, ib + KMT_TAB - 1);
+                    __syncthreads();
+                    if (tid <= ie - ib) s_v[tid] = km_base_y<R, CM>(g, ib + tid);
+                    __syncthreads();
+                    const int nq = bw * (ie - ib + 1);
+                    int base = 0;
+                    for (; base + KMT_UNROLL * 256 <= nq; base += KMT_UNROLL * 256) {
+#pragma unroll
+                        for (int s4 = 0; s4 < KMT_UNROLL; ++s4)
+                            kmt_scatter_q<T, CM, WANT_GM>(a, m, base + s4 * 256 + tid, true, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite,
+                                                          scale, cbase, cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm_try, bound,
+                                                          exceeded);
+                    }
+                    for (; base < nq; base += 256) {
+                        const int e = base + tid;
+                        kmt_scatter_q<T, CM, WANT_GM>(a, m, min(e, nq - 1), e < nq, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale,
+                                                      cbase, cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm_try, bound, exceeded);
+                    }
                 }
             }
+            const int redo = __syncthreads_or((int)exceeded);
+            if (attempt == 0 && redo) {
+                for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0;  // discard the speculative attempt
+                continue;  // the barrier at the top of attempt 1 orders these stores before the next atomics
+            }
+            if (WANT_GM) {
+                // accepted attempt: fold this chunk's matrix gradient into the global fp64 accumulators
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const double sgm = km_wave_sum((double)gm_try[k]);
+                    if (lane == 0) red[wave][k] = sgm;
+                }
+                __syncthreads();
+                if (tid < 9) {
+                    const double sgm = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                    if (sgm != 0.0) km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + tid, sgm);
+                }
+            }
+            break;
         }
-        __syncthreads();
 
         // ---- convert and write the tile: rows of 64 floats, fully coalesced ----
         for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) {
@@ -394,18 +440,6 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
         __syncthreads();
     }
 
-    if (WANT_GM) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const double s = km_wave_sum((double)gm[k]);
-            if (lane == 0) red[wave][k] = s;
-        }
-        __syncthreads();
-        if (tid < 9) {
-            const double s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-            if (s != 0.0) km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + tid, s);
-        }
-    }
 }
 
 template <typename T, int CM>
