@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = (int)tx * KM_TILE_W + lane;
     const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
+    __shared__ R s_v[KM_TILE_H];
+    if (threadIdx.x < KM_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KM_TILE_H + (int)threadIdx.x);
+    __syncthreads();
     if (j >= g.w) return;
 
     R m[9];
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
     for (int r = 0; r < KM_ROWS; ++r) {
         const int i = i_base + r;
         if (i >= g.h) break;
-        const R v = km_base_y<R, CM>(g, i);
+        const R v = s_v[wave * KM_ROWS + r];  // row base coordinate (one IEEE divide per row per block, not per lane)
         KmCoord<R> cd;
         km_gen_coord<R, CM>(m, u, v, cd);
         R mx, my, gdx, gdy;
@@ -88,18 +91,33 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
                 if (t.b11) mask = mask + t.w11;
                 inv_mask = (R)1 - mask;
             }
-            for (int c = 0; c < g.C; ++c) {
-                const T* img = src_b + (size_t)c * src_plane;
-                const R v00 = km_ld(img + t.i00), v01 = km_ld(img + t.i01);
-                const R v10 = km_ld(img + t.i10), v11 = km_ld(img + t.i11);
-                // fma chain in nw, ne, sw, se order; out-of-bounds taps are skipped
-                R acc = 0;
-                acc = t.b00 ? km_fma(v00, t.w00, acc) : acc;
-                acc = t.b01 ? km_fma(v01, t.w01, acc) : acc;
-                acc = t.b10 ? km_fma(v10, t.w10, acc) : acc;
-                acc = t.b11 ? km_fma(v11, t.w11, acc) : acc;
-                if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
-                km_st(out_px + (size_t)c * dst_plane, acc);
+            if (__all(t.b00 && t.b01 && t.b10 && t.b11)) {
+                // whole wave samples strictly inside the image (the common case): no masking, same fma chain
+                for (int c = 0; c < g.C; ++c) {
+                    const T* img = src_b + (size_t)c * src_plane;
+                    const R v00 = km_ld(img + t.i00), v01 = km_ld(img + t.i01);
+                    const R v10 = km_ld(img + t.i10), v11 = km_ld(img + t.i11);
+                    R acc = km_fma(v00, t.w00, (R)0);
+                    acc = km_fma(v01, t.w01, acc);
+                    acc = km_fma(v10, t.w10, acc);
+                    acc = km_fma(v11, t.w11, acc);
+                    if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
+                    km_st(out_px + (size_t)c * dst_plane, acc);
+                }
+            } else {
+                for (int c = 0; c < g.C; ++c) {
+                    const T* img = src_b + (size_t)c * src_plane;
+                    const R v00 = km_ld(img + t.i00), v01 = km_ld(img + t.i01);
+                    const R v10 = km_ld(img + t.i10), v11 = km_ld(img + t.i11);
+                    // fma chain in nw, ne, sw, se order; out-of-bounds taps are skipped
+                    R acc = 0;
+                    acc = t.b00 ? km_fma(v00, t.w00, acc) : acc;
+                    acc = t.b01 ? km_fma(v01, t.w01, acc) : acc;
+                    acc = t.b10 ? km_fma(v10, t.w10, acc) : acc;
+                    acc = t.b11 ? km_fma(v11, t.w11, acc) : acc;
+                    if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
+                    km_st(out_px + (size_t)c * dst_plane, acc);
+                }
             }
         } else if (INTERP == KM_INTERP_NEAREST) {
             x = km_compute_coord(x, g.W, spad, g.align, gdx);

@@ -196,9 +196,9 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const
 // from the Jacobian bound), and adds rint(w * g * scale) with ds_add_u32.  Per-term error <= 2^-(k+1),
 // i.e. <= M * 2^-(27-hb): the same order as one fp32 ulp of M.  Integer addition is associative, so the
 // result is independent of the order in which waves run: bit-reproducible, unlike float atomics.
-// measured on MI355X (256x3x512^2): min-waves 1 -> 1.73 ms (103 VGPRs), 5 -> 1.50 ms (96 VGPRs), 6 -> 1.99 ms (spills)
+// measured on MI355X (256x3x512^2), speculative-scale version: min-waves 4 -> 1.32 ms, 5 -> 1.38 ms (14 spills), 6 -> 2.00 ms
 #ifndef KMT_MIN_WAVES
-#define KMT_MIN_WAVES 5
+#define KMT_MIN_WAVES 4
 #endif
 #ifndef KMT_UNROLL
 #define KMT_UNROLL 2
