@@ -172,14 +172,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (1-GPU box): BENCH_FORCE_DEVICE=0 maps every rank to one device, BENCH_DIST_BACKEND=gloo replaces RCCL
+    force_dev = os.environ.get("BENCH_FORCE_DEVICE")
+    dev_index = int(force_dev) if force_dev is not None else local_rank
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import kornia_amd as K
 
@@ -198,8 +205,12 @@ def main():
         return y
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -212,12 +223,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     gather_ms = None
-    if args.gather and dist is not None:
+    if args.gather and dist is not None and backend == "nccl":
         outs = torch.empty(world * B, C, S, S, device=dev)
         dist.all_gather_into_tensor(outs, y.detach())
         barrier()
@@ -290,7 +301,7 @@ def main():
         print(json.dumps(result), flush=True)
 
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 
