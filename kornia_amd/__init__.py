@@ -30,4 +30,6 @@ from .geometry import (
     warp_perspective,
 )
 
+from .kornia_patch import is_patched, patch, unpatch
+
 __version__ = "0.1.0"

@@ -18,7 +18,7 @@ def test_patch_and_unpatch():
     import kornia.augmentation._2d.geometric.affine as aff_mod
     import kornia.geometry.transform.affwarp as affwarp
 
-    import kornia_amd.patch as P
+    import kornia_amd.kornia_patch as P
 
     orig = K.geometry.transform.imgwarp.warp_affine
     n = P.patch()
