@@ -71,6 +71,29 @@ __device__ __forceinline__ void km_st(double* p, double v) { *p = v; }
 __device__ __forceinline__ void km_st(km_bf16* p, float v) { p->bits = km_f32_to_bf16_bits(v); }
 __device__ __forceinline__ void km_st(km_f16* p, float v) { *p = (km_f16)v; }
 
+// two horizontally adjacent pixels with ONE load (8 bytes for fp32 / fp64 pairs, 4 bytes for 16-bit types).
+// The address is only element-aligned: gfx950 global loads handle that in hardware; the packed structs
+// keep the compiler from assuming more.  Gather loads are TA-bound on this chip (a dword-per-lane wave load
+// occupies the texture-address path as long as a 2-dword one), so halving the load count matters.
+struct __attribute__((packed, aligned(4))) km_f32x2_u { float x, y; };
+struct __attribute__((packed, aligned(8))) km_f64x2_u { double x, y; };
+struct __attribute__((packed, aligned(2))) km_u16x2_u { uint16_t x, y; };
+__device__ __forceinline__ void km_ld2(const float* p, float& a, float& b) {
+    const km_f32x2_u v = *reinterpret_cast<const km_f32x2_u*>(p);
+    a = v.x; b = v.y;
+}
+__device__ __forceinline__ void km_ld2(const double* p, double& a, double& b) {
+    const km_f64x2_u v = *reinterpret_cast<const km_f64x2_u*>(p);
+    a = v.x; b = v.y;
+}
+__device__ __forceinline__ void km_ld2(const km_bf16* p, float& a, float& b) {
+    const km_u16x2_u v = *reinterpret_cast<const km_u16x2_u*>(p);
+    a = __uint_as_float(((uint32_t)v.x) << 16); b = __uint_as_float(((uint32_t)v.y) << 16);
+}
+__device__ __forceinline__ void km_ld2(const km_f16* p, float& a, float& b) {
+    a = (float)p[0]; b = (float)p[1];
+}
+
 // ---- explicitly fused / explicitly rounded arithmetic ---------------------------------------
 __device__ __host__ __forceinline__ float km_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __host__ __forceinline__ double km_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
