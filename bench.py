@@ -251,7 +251,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if (B, C, S) == (256, 3, 512) and os.path.exists(tpath):
-            rocname = {"km_warp_bwd_kernel": "km_warp_bwd_tiled_kernel", "km_warp_fwd_kernel": "km_warp_fwd_kernel",
+            rocname = {"km_warp_bwd_kernel": "km_warp_bwd_tiled_kernel", "km_warp_fwd_kernel": "km_warp_fwd_bz_kernel",
                        "km_filter_sep_fwd_kernel": "km_blur_reg_kernel<float, 5, false>", "km_filter_sep_bwd_kernel": "km_blur_reg_kernel<float, 5, true>"}[dom]
             for kname, rec in json.load(open(tpath))["kernels"].items():
                 if rocname in kname:
