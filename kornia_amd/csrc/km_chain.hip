@@ -173,6 +173,7 @@ extern "C" {
 // dtype: KM_F32 or KM_F64 (matrices of bf16/f16 images are handled in fp32 by the caller).
 int km_homography_chain_fwd(const void* M, int rows, void* A_out, void* m_out, int B, int Hs, int Ws, int hd, int wd,
                             int dtype, void* stream) {
+    if (B == 0) return 0;  // empty batch: nothing to do (data pointers of empty tensors are null)
     KM_REQUIRE(M && (A_out || m_out), "km_homography_chain_fwd: null pointer");
     KM_REQUIRE(rows == 2 || rows == 3, "km_homography_chain_fwd: rows must be 2 or 3, got %d", rows);
     KM_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && hd > 0 && wd > 0, "km_homography_chain_fwd: bad sizes");
@@ -184,6 +185,7 @@ int km_homography_chain_fwd(const void* M, int rows, void* A_out, void* m_out, i
 // gm: (B,9) fp64 gradient wrt m_out; gM: (B,rows,3) in dtype.
 int km_homography_chain_bwd(const void* M, int rows, const double* gm, void* gM, int B, int Hs, int Ws, int hd, int wd,
                             int dtype, void* stream) {
+    if (B == 0) return 0;
     KM_REQUIRE(M && gm && gM, "km_homography_chain_bwd: null pointer");
     KM_REQUIRE(rows == 2 || rows == 3, "km_homography_chain_bwd: rows must be 2 or 3, got %d", rows);
     KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_homography_chain_bwd: dtype must be f32/f64");

@@ -530,6 +530,7 @@ extern "C" {
 // k: prepared taps (Bk,kH,kW) in the compute dtype (fp32, or fp64 for f64 data).
 int km_filter2d_fwd(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int kH, int kW, int border,
                     int same, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_fwd", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(x && k && y, "km_filter2d_fwd: null pointer");
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
@@ -541,6 +542,7 @@ int km_filter2d_fwd(const void* x, const void* k, void* y, int B, int C, int H, 
 // gradient wrt input (adjoint incl. the pad fold): gy (B,C,Ho,Wo) -> gx (B,C,H,W)
 int km_filter2d_bwd_input(const void* gy, const void* k, void* gx, int B, int C, int H, int W, int Bk, int kH, int kW,
                           int border, int same, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_bwd_input", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(gy && k && gx, "km_filter2d_bwd_input: null pointer");
     KM_REQUIRE(!same || ((kH - 1 - (kH - 1) / 2) < KM_MAX_PRE && (kW - 1 - (kW - 1) / 2) < KM_MAX_PRE), "km_filter2d_bwd_input: kernel too large");
@@ -553,6 +555,7 @@ int km_filter2d_bwd_input(const void* gy, const void* k, void* gx, int B, int C,
 // gradient wrt the prepared taps: gk (Bk,kH,kW) fp64, pre-zeroed
 int km_filter2d_bwd_kernel(const void* gy, const void* x, void* gk, int B, int C, int H, int W, int Bk, int kH, int kW,
                            int border, int same, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_bwd_kernel", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(gy && x && gk, "km_filter2d_bwd_kernel: null pointer");
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
@@ -564,6 +567,7 @@ int km_filter2d_bwd_kernel(const void* gy, const void* x, void* gk, int B, int C
 // Replaces filter2d_separable (filter.py:155-207): kx (Bk,kW), ky (Bk,kH) in the compute dtype.
 int km_filter2d_sep_fwd(const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk, int kH,
                         int kW, int border, int same, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_sep_fwd", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(x && kx && ky && y, "km_filter2d_sep_fwd: null pointer");
     if (km_sep_algo() == 0 && km_blur_fast_supported(x, y, H, W, kH, kW, border, same, dtype))
@@ -576,6 +580,7 @@ int km_filter2d_sep_fwd(const void* x, const void* kx, const void* ky, void* y, 
 
 int km_filter2d_sep_bwd_input(const void* gy, const void* kx, const void* ky, void* gx, int B, int C, int H, int W, int Bk,
                               int kH, int kW, int border, int same, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_sep_bwd_input", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(gy && kx && ky && gx, "km_filter2d_sep_bwd_input: null pointer");
     if (km_sep_algo() == 0 && km_blur_fast_supported(gy, gx, H, W, kH, kW, border, same, dtype))

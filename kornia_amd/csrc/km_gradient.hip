@@ -139,6 +139,7 @@ extern "C" {
 // null (sobel magnitude, needs n_out == 2).
 int km_spatial_gradient_fwd(const void* x, const void* kern_host, void* out, void* mag, int B, int C, int H, int W,
                             int n_out, int kS, double eps, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;
     if (km_grad_validate("km_spatial_gradient_fwd", B, C, H, W, n_out, kS, dtype)) return -1;
     KM_REQUIRE(x && kern_host && (out || mag), "km_spatial_gradient_fwd: null pointer");
     KM_REQUIRE(!mag || n_out == 2, "km_spatial_gradient_fwd: magnitude needs n_out == 2");
@@ -154,6 +155,7 @@ int km_spatial_gradient_fwd(const void* x, const void* kern_host, void* out, voi
 // gout: (B,C,n_out,H,W) -> gx: (B,C,H,W)
 int km_spatial_gradient_bwd(const void* gout, const void* kern_host, void* gx, int B, int C, int H, int W, int n_out,
                             int kS, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;
     if (km_grad_validate("km_spatial_gradient_bwd", B, C, H, W, n_out, kS, dtype)) return -1;
     KM_REQUIRE(gout && kern_host && gx, "km_spatial_gradient_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;

@@ -142,6 +142,7 @@ extern "C" {
 
 // T (B_T,D+1,D+1), pts (B,N,D) -> out (B,N,D); dtype KM_F32 | KM_F64.
 int km_transform_points_fwd(const void* T, const void* pts, void* out, int B, int N, int D, int B_T, int dtype, void* stream) {
+    if (B == 0 || N == 0) return 0;
     if (km_points_validate("km_transform_points_fwd", B, N, D, B_T, dtype)) return -1;
     KM_REQUIRE(T && pts && out, "km_transform_points_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -154,6 +155,7 @@ int km_transform_points_fwd(const void* T, const void* pts, void* out, int B, in
 // gpts (B,N,D) nullable; gT (B_T,(D+1)^2) fp64 accumulators, pre-zeroed, nullable.
 int km_transform_points_bwd(const void* gout, const void* T, const void* pts, void* gpts, void* gT, int B, int N, int D,
                             int B_T, int dtype, void* stream) {
+    if (B == 0 || N == 0) return 0;
     if (km_points_validate("km_transform_points_bwd", B, N, D, B_T, dtype)) return -1;
     KM_REQUIRE(gout && T && pts, "km_transform_points_bwd: null pointer");
     if (!gpts && !gT) return 0;

@@ -529,6 +529,7 @@ extern "C" {
 int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int H, int W, int h, int w, int B_M,
                   int coord_mode, int norm_coords, int interp, int pad, int align, const void* fill, int dtype,
                   void* stream) {
+    if (B == 0 || C == 0 || h == 0 || w == 0) return 0;  // empty output
     if (km_warp_validate("km_warp2d_fwd", src, mat, B, C, H, W, h, w, B_M, coord_mode, interp, pad, fill, dtype)) return -1;
     KM_REQUIRE(dst, "km_warp2d_fwd: null dst");
     hipStream_t s = (hipStream_t)stream;
@@ -546,6 +547,7 @@ int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int
 int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
                   int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align,
                   const void* fill, int dtype, void* stream) {
+    if (B == 0 || C == 0) return 0;
     if (km_warp_validate("km_warp2d_bwd", src, mat, B, C, H, W, h, w, B_M, coord_mode, interp, pad, fill, dtype)) return -1;
     KM_REQUIRE(gout, "km_warp2d_bwd: null gout");
     if (!gsrc && !gmat) return 0;
