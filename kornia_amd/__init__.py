@@ -22,6 +22,10 @@ from .filters import (
 )
 from .geometry import (
     HomographyWarper,
+    get_affine_matrix2d,
+    get_perspective_transform,
+    get_rotation_matrix2d,
+    get_shear_matrix2d,
     homography_warp,
     normalize_homography,
     transform_points,

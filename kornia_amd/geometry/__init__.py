@@ -8,4 +8,17 @@ from .conversions import (
 )
 from .grid import create_meshgrid
 from .linalg import transform_points
-from .transform import HomographyWarper, homography_warp, warp_affine, warp_grid, warp_perspective
+from .transform import (
+    HomographyWarper,
+    angle_to_rotation_matrix,
+    deg2rad,
+    get_affine_matrix2d,
+    get_perspective_transform,
+    get_rotation_matrix2d,
+    get_shear_matrix2d,
+    get_translation_matrix2d,
+    homography_warp,
+    warp_affine,
+    warp_grid,
+    warp_perspective,
+)

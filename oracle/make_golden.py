@@ -182,6 +182,36 @@ def main():
     save("headline_small", x=xh, M=Mh, go=gh, y=y, gx=xg.grad, gM=Mg.grad)
 
 
+    # ---- matrix builders --------------------------------------------------------
+    db = {}
+    Bb = 16
+    base = torch.tensor([[0.0, 0.0], [63.0, 0.0], [63.0, 47.0], [0.0, 47.0]])
+    db["ps"] = base[None] + 4.0 * (torch.rand(Bb, 4, 2, generator=g) - 0.5)
+    db["pd"] = base[None] + 12.0 * (torch.rand(Bb, 4, 2, generator=g) - 0.5)
+    ps, pd = db["ps"].clone().requires_grad_(), db["pd"].clone().requires_grad_()
+    Hq = T.get_perspective_transform(ps, pd)
+    gH = torch.rand(Bb, 3, 3, generator=g)
+    Hq.backward(gH)
+    db["H"], db["gH"], db["g_ps"], db["g_pd"] = Hq, gH, ps.grad, pd.grad
+    db["H64"] = T.get_perspective_transform(db["ps"].double(), db["pd"].double())
+    db["center"] = torch.rand(Bb, 2, generator=g) * 64
+    db["angle"] = (torch.rand(Bb, generator=g) - 0.5) * 360
+    db["scale"] = 0.5 + torch.rand(Bb, 2, generator=g)
+    db["trans"] = (torch.rand(Bb, 2, generator=g) - 0.5) * 20
+    db["sx"] = (torch.rand(Bb, generator=g) - 0.5)
+    db["sy"] = (torch.rand(Bb, generator=g) - 0.5)
+    db["rot"] = T.get_rotation_matrix2d(db["center"], db["angle"], db["scale"])
+    db["rot64"] = T.get_rotation_matrix2d(db["center"].double(), db["angle"].double(), db["scale"].double())
+    db["aff"] = T.get_affine_matrix2d(db["trans"], db["center"], db["scale"], db["angle"])
+    db["aff_shear"] = T.get_affine_matrix2d(db["trans"], db["center"], db["scale"], db["angle"], db["sx"], db["sy"])
+    db["aff_sx"] = T.get_affine_matrix2d(db["trans"], db["center"], db["scale"], db["angle"], sx=db["sx"])
+    db["shear"] = T.get_shear_matrix2d(db["center"], db["sx"], db["sy"])
+    db["transl"] = T.get_translation_matrix2d(db["trans"])
+    db["a2r"] = K.geometry.conversions.angle_to_rotation_matrix(db["angle"].reshape(4, 4))
+    db["d2r"] = K.geometry.conversions.deg2rad(db["angle"])
+    save("builders", **db)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     main()

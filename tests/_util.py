@@ -44,3 +44,14 @@ def smooth_image(B: int, C: int, H: int, W: int) -> torch.Tensor:
     v, u = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
     img = 0.5 + 0.5 * torch.sin(6 * torch.pi * u) * torch.cos(4 * torch.pi * v)
     return img.expand(B, C, H, W).contiguous()
+
+
+def golden(name: str):
+    """Load tests/golden/<name>.npz (reference-generated fixture) as a dict of numpy arrays."""
+    import os
+
+    import numpy as np
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}

@@ -1,0 +1,86 @@
+"""Matrix builders against fixtures produced by the real reference
+(oracle/make_golden.py -> tests/golden/builders.npz).  Device-agnostic tensor formulas, so the CPU run is
+the parity test; the gpu-marked test repeats it on the MI355X and feeds the result to the native warp."""
+import numpy as np
+import pytest
+import torch
+
+import kornia_amd as K
+from _util import golden
+
+T = K.geometry.transform
+
+
+def _t(d, k, dev="cpu", dt=None):
+    t = torch.from_numpy(np.asarray(d[k]))
+    return t.to(dev) if dt is None else t.to(dev, dt)
+
+
+def _check_all(dev):
+    d = golden("builders")
+    ps, pd = _t(d, "ps", dev), _t(d, "pd", dev)
+    H = T.get_perspective_transform(ps, pd)
+    torch.testing.assert_close(H.cpu(), _t(d, "H"), rtol=2e-4, atol=2e-5)
+    H64 = T.get_perspective_transform(ps.double(), pd.double())
+    torch.testing.assert_close(H64.cpu(), _t(d, "H64"), rtol=1e-9, atol=1e-11)
+    # the homography really maps the source quad onto the destination quad
+    q = torch.cat([ps.double(), torch.ones_like(ps[..., :1]).double()], -1) @ H64.transpose(1, 2)
+    torch.testing.assert_close(q[..., :2] / q[..., 2:], pd.double(), rtol=1e-9, atol=1e-9)
+    c, a, s = _t(d, "center", dev), _t(d, "angle", dev), _t(d, "scale", dev)
+    tr, sx, sy = _t(d, "trans", dev), _t(d, "sx", dev), _t(d, "sy", dev)
+    tol = dict(rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(T.get_rotation_matrix2d(c, a, s).cpu(), _t(d, "rot"), **tol)
+    torch.testing.assert_close(T.get_rotation_matrix2d(c.double(), a.double(), s.double()).cpu(), _t(d, "rot64"), rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(T.get_affine_matrix2d(tr, c, s, a).cpu(), _t(d, "aff"), **tol)
+    torch.testing.assert_close(T.get_affine_matrix2d(tr, c, s, a, sx, sy).cpu(), _t(d, "aff_shear"), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(T.get_affine_matrix2d(tr, c, s, a, sx=sx).cpu(), _t(d, "aff_sx"), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(T.get_shear_matrix2d(c, sx, sy).cpu(), _t(d, "shear"), rtol=0, atol=0)
+    torch.testing.assert_close(T.get_translation_matrix2d(tr).cpu(), _t(d, "transl"), rtol=0, atol=0)
+    torch.testing.assert_close(T.angle_to_rotation_matrix(a.reshape(4, 4)).cpu(), _t(d, "a2r"), rtol=0, atol=0)
+    torch.testing.assert_close(T.deg2rad(a).cpu(), _t(d, "d2r"), rtol=0, atol=0)
+    return H
+
+
+def test_builders_match_reference_fixtures():
+    _check_all("cpu")
+
+
+def test_perspective_transform_gradients():
+    d = golden("builders")
+    ps, pd = _t(d, "ps").requires_grad_(), _t(d, "pd").requires_grad_()
+    T.get_perspective_transform(ps, pd).backward(_t(d, "gH"))
+    torch.testing.assert_close(ps.grad, _t(d, "g_ps"), rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(pd.grad, _t(d, "g_pd"), rtol=2e-3, atol=2e-4)
+    ps64, pd64 = _t(d, "ps").double().requires_grad_(), _t(d, "pd").double().requires_grad_()
+    assert torch.autograd.gradcheck(T.get_perspective_transform, (ps64[:2], pd64[:2]), eps=1e-6, atol=1e-5)
+
+
+def test_builders_error_behaviour():
+    with pytest.raises(Exception):
+        T.get_perspective_transform(torch.rand(1, 3, 2), torch.rand(1, 3, 2))
+    with pytest.raises(Exception):
+        T.get_perspective_transform(torch.rand(1, 4, 2), torch.rand(1, 4, 2).double())
+    with pytest.raises(TypeError):
+        T.get_rotation_matrix2d([0.0, 0.0], torch.zeros(1), torch.ones(1, 2))
+    with pytest.raises(ValueError):
+        T.get_rotation_matrix2d(torch.zeros(1, 3), torch.zeros(1), torch.ones(1, 2))
+    with pytest.raises(ValueError):
+        T.get_rotation_matrix2d(torch.zeros(2, 2), torch.zeros(1), torch.ones(2, 2))
+    with pytest.raises(ValueError):
+        T.get_rotation_matrix2d(torch.zeros(1, 2), torch.zeros(1).double(), torch.ones(1, 2))
+    with pytest.raises(TypeError):
+        T.deg2rad(1.0)
+
+
+def test_half_precision_roundtrip():
+    d = golden("builders")
+    H = T.get_perspective_transform(_t(d, "ps").bfloat16(), _t(d, "pd").bfloat16())
+    assert H.dtype == torch.bfloat16 and H.shape == (16, 3, 3)
+
+
+@pytest.mark.gpu
+def test_builders_on_device_feed_native_warp():
+    H = _check_all("cuda")
+    x = torch.rand(16, 3, 48, 64, device="cuda")
+    y = K.warp_perspective(x, H, (48, 64))
+    assert y.shape == (16, 3, 48, 64) and torch.isfinite(y).all()
