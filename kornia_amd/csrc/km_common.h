@@ -94,6 +94,14 @@ __device__ __forceinline__ void km_ld2(const km_f16* p, float& a, float& b) {
     a = (float)p[0]; b = (float)p[1];
 }
 
+// base + 32-bit element offset with the byte offset kept in 32 bits: with a wave-uniform base the compiler can
+// use the  global_load vdst, voffset, s[base:base+1]  form (no 64-bit VALU address arithmetic per lane).
+// Callers guarantee  plane elements * sizeof(T) < 2^32.
+template <typename T>
+__device__ __forceinline__ const T* km_at(const T* base, uint32_t elem_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem_off * (uint32_t)sizeof(T));
+}
+
 // ---- explicitly fused / explicitly rounded arithmetic ---------------------------------------
 __device__ __host__ __forceinline__ float km_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __host__ __forceinline__ double km_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }

@@ -521,6 +521,11 @@ int km_warp_bwd_tiled_run(const void* gout, const void* src, const void* mat, vo
                           int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype,
                           hipStream_t s);
 
+// matrix gradient of the bilinear warps (km_warp_gm.hip)
+int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, int w);
+int km_warp_gm_run(const void* gout, const void* src, const void* mat, double* gmat, int B, int C, int H, int W, int h, int w, int B_M,
+                   int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype, hipStream_t s);
+
 extern "C" {
 
 // Replaces the eager grid construction + F.grid_sample of
@@ -552,8 +557,16 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
     KM_REQUIRE(gout, "km_warp2d_bwd: null gout");
     if (!gsrc && !gmat) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc))
-        return km_warp_bwd_tiled_run(gout, src, mat, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
+    // bilinear + zeros/fill: grad_src by the tile-owner scatter, the matrix gradient by its own forward-shaped kernel
+    const bool gm_split = gmat && km_warp_gm_supported(interp, pad, dtype, H, W, h, w);
+    if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc)) {
+        const int rc = km_warp_bwd_tiled_run(gout, src, mat, gsrc, gm_split ? nullptr : gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad,
+                                             align, fill, dtype, s);
+        if (rc != 0 || !gm_split) return rc;
+        return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
+    }
+    if (!gsrc && gm_split)  // matrix gradient only (learned-homography loops: SURVEY.md config 5)
+        return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
     switch (dtype) {
         case KM_F32: return km_warp_run<float>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         case KM_F64: return km_warp_run<double>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);

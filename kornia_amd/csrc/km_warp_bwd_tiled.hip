@@ -68,28 +68,147 @@ __device__ __forceinline__ void kmt_index_affine(const KmWarpGeom<float>& g, int
     }
 }
 
-// matrix-gradient contribution of one output pixel
+// ---- the box of output pixels (j0..j1) x (i0..i1) whose bilinear footprint can touch the source tile ----
+struct KmtBox {
+    int j0, j1, i0, i1;
+    float mult;     // bound on the number of output pixels whose footprint covers one source pixel
+    bool fixed_ok;  // bounded multiplicity: fixed-point accumulation is accurate enough
+};
+
+#ifndef KMT_TIGHT_BOX
+#define KMT_TIGHT_BOX 1
+#endif
+
+// G = (output index <- source pixel) as a projective map: (Jn, In, D) = G (x, y, 1), (j, i) = (Jn, In) / D.
+// A projective map sends the tile rectangle (grown by the 1-pixel footprint) to a convex quad when D keeps
+// its sign, so the bounding box of the four mapped corners contains every output pixel that can touch the
+// tile - up to rounding.  The margin added around the box is an explicit bound on that rounding:
+//   * error of the fp32 inverse map itself (entries of G are differences of products: the bound follows
+//     the sums of absolute values, so cancellation is accounted for),
+//   * error of the forward fp32 position of a pixel (which is what decides whether it touches the tile),
+//     pushed through the Jacobian of G,
+// times a safety factor, plus 1/8 px.  (The first version used a flat 1 px + floor/ceil slack, i.e. ~1.5 px
+// per side: 8 % more pixels to visit on a 64x32 tile.)
 template <int CM>
-__device__ __forceinline__ void kmt_accumulate_gm(float (&gm)[9], const KmCoord<float>& cd, float gix, float giy) {
+__device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const float (&m)[9], int X0, int X1, int Y0, int Y1) {
     typedef float R;
-    if (CM == KM_COORD_PERSPECTIVE) {
-        const R inv = __frcp_rn(cd.den);
-        const R ax = gix * inv, ay = giy * inv;
-        const R az = -(gix * cd.gx + giy * cd.gy) * inv;
-        gm[0] += ax * cd.u; gm[1] += ax * cd.v; gm[2] += ax;
-        gm[3] += ay * cd.u; gm[4] += ay * cd.v; gm[5] += ay;
-        gm[6] += az * cd.u; gm[7] += az * cd.v; gm[8] += az;
-    } else if (CM == KM_COORD_AFFINE) {
-        gm[0] += gix * cd.u; gm[1] += gix * cd.v; gm[2] += gix;
-        gm[3] += giy * cd.u; gm[4] += giy * cd.v; gm[5] += giy;
-    } else {
-        const R s = cd.den;
-        const R ax = gix * s, ay = giy * s;
-        const R az = cd.live ? -(gix * cd.X + giy * cd.Y) * s * s : (R)0;
-        gm[0] += ax * cd.u; gm[1] += ax * cd.v; gm[2] += ax;
-        gm[3] += ay * cd.u; gm[4] += ay * cd.v; gm[5] += ay;
-        gm[6] += az * cd.u; gm[7] += az * cd.v; gm[8] += az;
+    KmtBox o;
+    o.j0 = 0; o.j1 = g.w - 1; o.i0 = 0; o.i1 = g.h - 1;
+    o.mult = (R)g.w * (R)g.h;  // whole-output scan: no multiplicity bound
+    o.fixed_ok = false;
+    R G[9], Ga[9];
+    // adjugate of m (un-normalised inverse: the common scale cancels in the projective divide); *a = same with |.|
+    const R A0 = m[4] * m[8] - m[5] * m[7], A1 = m[2] * m[7] - m[1] * m[8], A2 = m[1] * m[5] - m[2] * m[4];
+    const R A3 = m[5] * m[6] - m[3] * m[8], A4 = m[0] * m[8] - m[2] * m[6], A5 = m[2] * m[3] - m[0] * m[5];
+    const R A6 = m[3] * m[7] - m[4] * m[6], A7 = m[1] * m[6] - m[0] * m[7], A8 = m[0] * m[4] - m[1] * m[3];
+    const R A0a = fabsf(m[4] * m[8]) + fabsf(m[5] * m[7]), A1a = fabsf(m[2] * m[7]) + fabsf(m[1] * m[8]), A2a = fabsf(m[1] * m[5]) + fabsf(m[2] * m[4]);
+    const R A3a = fabsf(m[5] * m[6]) + fabsf(m[3] * m[8]), A4a = fabsf(m[0] * m[8]) + fabsf(m[2] * m[6]), A5a = fabsf(m[2] * m[3]) + fabsf(m[0] * m[5]);
+    const R A6a = fabsf(m[3] * m[7]) + fabsf(m[4] * m[6]), A7a = fabsf(m[1] * m[6]) + fabsf(m[0] * m[7]), A8a = fabsf(m[0] * m[4]) + fabsf(m[1] * m[3]);
+    // pixel -> normalised source coordinate (inverse of km_unnormalize): gn = ax * x + bx
+    const R ax = g.align ? (g.W > 1 ? 2.0f / (R)(g.W - 1) : 0.0f) : 2.0f / (R)g.W;
+    const R bx = g.align ? -1.0f : 1.0f / (R)g.W - 1.0f;
+    const R ay = g.align ? (g.H > 1 ? 2.0f / (R)(g.H - 1) : 0.0f) : 2.0f / (R)g.H;
+    const R by = g.align ? -1.0f : 1.0f / (R)g.H - 1.0f;
+    const R P0 = A0 * ax, P1 = A1 * ay, P2 = A0 * bx + A1 * by + A2;
+    const R P3 = A3 * ax, P4 = A4 * ay, P5 = A3 * bx + A4 * by + A5;
+    const R P6 = A6 * ax, P7 = A7 * ay, P8 = A6 * bx + A7 * by + A8;
+    const R abx = fabsf(bx), aby = fabsf(by);
+    const R P0a = A0a * ax, P1a = A1a * ay, P2a = A0a * abx + A1a * aby + A2a;
+    const R P3a = A3a * ax, P4a = A4a * ay, P5a = A3a * abx + A4a * aby + A5a;
+    const R P6a = A6a * ax, P7a = A7a * ay, P8a = A6a * abx + A7a * aby + A8a;
+    R sj, oj, si, oi;
+    kmt_index_affine<CM>(g, g.w, g.lin_lo_x, g.lin_step_x, sj, oj);
+    kmt_index_affine<CM>(g, g.h, g.lin_lo_y, g.lin_step_y, si, oi);
+    G[0] = sj * P0 + oj * P6; G[1] = sj * P1 + oj * P7; G[2] = sj * P2 + oj * P8;
+    G[3] = si * P3 + oi * P6; G[4] = si * P4 + oi * P7; G[5] = si * P5 + oi * P8;
+    G[6] = P6; G[7] = P7; G[8] = P8;
+    const R asj = fabsf(sj), aoj = fabsf(oj), asi = fabsf(si), aoi = fabsf(oi);
+    Ga[0] = asj * P0a + aoj * P6a; Ga[1] = asj * P1a + aoj * P7a; Ga[2] = asj * P2a + aoj * P8a;
+    Ga[3] = asi * P3a + aoi * P6a; Ga[4] = asi * P4a + aoi * P7a; Ga[5] = asi * P5a + aoi * P8a;
+    Ga[6] = P6a; Ga[7] = P7a; Ga[8] = P8a;
+
+    // corners of the tile grown by the bilinear footprint: floor(x) in [X0-1, X1-1]  <=>  x in [X0-1, X1)
+    const R xs[2] = {(R)(X0 - 1), (R)X1}, ys[2] = {(R)(Y0 - 1), (R)Y1};
+    R jmin = 3.0e38f, jmax = -3.0e38f, imin = 3.0e38f, imax = -3.0e38f, dmin = 3.0e38f, dmax = -3.0e38f, nmax = 0.f;
+    R njx = 0.f, njy = 0.f, nix = 0.f, niy = 0.f;
+    R egj = 0.f, egi = 0.f;     // rounding of the inverse map at the corners, in output pixels (before the factor gamma)
+    R drel = 0.f;               // max |D| rounding relative to |D|
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+            const R Jn = G[0] * xs[cx] + G[1] * ys[cy] + G[2];
+            const R In = G[3] * xs[cx] + G[4] * ys[cy] + G[5];
+            const R D = G[6] * xs[cx] + G[7] * ys[cy] + G[8];
+            dmin = fminf(dmin, D); dmax = fmaxf(dmax, D);
+            nmax = fmaxf(nmax, fmaxf(fabsf(Jn), fabsf(In)));
+            const R fj = Jn / D, fi = In / D;
+            jmin = fminf(jmin, fj); jmax = fmaxf(jmax, fj);
+            imin = fminf(imin, fi); imax = fmaxf(imax, fi);
+            njx = fmaxf(njx, fabsf(G[0] * D - Jn * G[6])); njy = fmaxf(njy, fabsf(G[1] * D - Jn * G[7]));
+            nix = fmaxf(nix, fabsf(G[3] * D - In * G[6])); niy = fmaxf(niy, fabsf(G[4] * D - In * G[7]));
+            if (KMT_TIGHT_BOX) {
+                const R axs = fabsf(xs[cx]), ays = fabsf(ys[cy]);
+                const R Ja = Ga[0] * axs + Ga[1] * ays + Ga[2], Ia = Ga[3] * axs + Ga[4] * ays + Ga[5], Da = Ga[6] * axs + Ga[7] * ays + Ga[8];
+                const R invd = 1.0f / fabsf(D);
+                egj = fmaxf(egj, (Ja + fabsf(fj) * Da) * invd);
+                egi = fmaxf(egi, (Ia + fabsf(fi) * Da) * invd);
+                drel = fmaxf(drel, Da * invd);
+            }
+        }
+    const bool same_sign = (dmin > 0.f) || (dmax < 0.f);
+    const R dabs_min = fminf(fabsf(dmin), fabsf(dmax)), dabs_max = fmaxf(fabsf(dmin), fabsf(dmax));
+    const bool ok = same_sign && (dabs_min > 1e-6f * fmaxf(nmax, dabs_max)) && (jmin == jmin) && (jmax == jmax) && (imin == imin) && (imax == imax);
+    if (!ok) return o;  // tile crossed by the vanishing line: visit the whole output (correct, slower)
+
+    const R big = 1.0e9f;
+    jmin = fmaxf(jmin, -big); jmax = fminf(jmax, big); imin = fmaxf(imin, -big); imax = fminf(imax, big);
+    const R inv_d2 = 1.0f / (dabs_min * dabs_min);
+    const R jac_j = (njx + njy) * inv_d2, jac_i = (nix + niy) * inv_d2;  // |dj/dx| + |dj/dy|, |di/dx| + |di/dy| over the tile
+    R mj = 1.0f, mi = 1.0f;     // margins in output pixels; with floor / ceil below this is the first version's box
+    bool flat_box = true;
+    if (KMT_TIGHT_BOX) {
+        const R gamma = 64.0f * 5.9604645e-8f;  // ~10 roundings per quantity, x6 safety
+        // forward rounding: the position of output pixel (j, i) is N / Dn with |u|, |v| <= U, V; Dn is affine in
+        // (u, v), so its smallest magnitude over the (flat-margin) box is attained at a corner
+        const int pj0 = max(0, (int)floorf(jmin) - 1), pj1 = min(g.w - 1, (int)ceilf(jmax) + 1);
+        const int pi0 = max(0, (int)floorf(imin) - 1), pi1 = min(g.h - 1, (int)ceilf(imax) + 1);
+        if (pj0 <= pj1 && pi0 <= pi1) {
+            const R u0 = km_base_x<R, CM>(g, pj0), u1 = km_base_x<R, CM>(g, pj1), v0 = km_base_y<R, CM>(g, pi0), v1 = km_base_y<R, CM>(g, pi1);
+            const R U = fmaxf(fabsf(u0), fabsf(u1)), V = fmaxf(fabsf(v0), fabsf(v1));
+            R dn_min = 1.0f, dn_sgn_ok = 1.0f;
+            if (CM != KM_COORD_AFFINE) {
+                const R d00 = (m[6] * u0 + m[7] * v0) + m[8], d01 = (m[6] * u1 + m[7] * v0) + m[8];
+                const R d10 = (m[6] * u0 + m[7] * v1) + m[8], d11 = (m[6] * u1 + m[7] * v1) + m[8];
+                const R lo = fminf(fminf(d00, d01), fminf(d10, d11)), hi = fmaxf(fmaxf(d00, d01), fmaxf(d10, d11));
+                dn_sgn_ok = ((lo > 0.f) || (hi < 0.f)) ? 1.0f : 0.0f;
+                dn_min = fminf(fabsf(lo), fabsf(hi));
+            }
+            const R Sx = fabsf(m[0]) * U + fabsf(m[1]) * V + fabsf(m[2]), Sy = fabsf(m[3]) * U + fabsf(m[4]) * V + fabsf(m[5]);
+            const R Sd = (CM == KM_COORD_AFFINE) ? 0.0f : fabsf(m[6]) * U + fabsf(m[7]) * V + fabsf(m[8]);
+            const R gmax = 2.0f;  // |normalised coordinate| of a pixel that touches the image is < 1 + 2/size
+            const R dgx = gamma * (Sx + gmax * Sd) / dn_min, dgy = gamma * (Sy + gmax * Sd) / dn_min;
+            const R dx = 0.5f * (R)g.W * dgx + gamma * (R)g.W, dy = 0.5f * (R)g.H * dgy + gamma * (R)g.H;  // source pixels
+            const R dfwd = fmaxf(dx, dy);
+            const R tj = 0.125f + 2.0f * (gamma * egj + jac_j * dfwd), ti = 0.125f + 2.0f * (gamma * egi + jac_i * dfwd);
+            // the first-order bounds need D and Dn well away from zero relative to their own rounding
+            const bool trust = (dn_sgn_ok > 0.5f) && (gamma * drel < 0.125f) && (gamma * Sd < 0.125f * dn_min) && (tj == tj) && (ti == ti) &&
+                               (tj < 1.0f) && (ti < 1.0f);
+            if (trust) { mj = tj; mi = ti; flat_box = false; }
+        }
     }
+    if (flat_box) {
+        o.j0 = max(0, (int)floorf(jmin) - 1); o.j1 = min(g.w - 1, (int)ceilf(jmax) + 1);
+        o.i0 = max(0, (int)floorf(imin) - 1); o.i1 = min(g.h - 1, (int)ceilf(imax) + 1);
+    } else {
+        o.j0 = max(0, (int)floorf(jmin - mj)); o.j1 = min(g.w - 1, (int)ceilf(jmax + mj));
+        o.i0 = max(0, (int)floorf(imin - mi)); o.i1 = min(g.h - 1, (int)ceilf(imax + mi));
+    }
+    // output pixels per source pixel: the 2x2 footprint box maps to at most (2 ex + 1)(2 ey + 1) lattice points
+    const R ex = jac_j + 0.1f, ey = jac_i + 0.1f;
+    o.mult = fminf((2.f * ex + 1.f) * (2.f * ey + 1.f), 1.0e6f);
+    o.fixed_ok = o.mult <= 256.f;  // beyond ~7x magnification the head-room would eat the mantissa: float path
+    return o;
 }
 
 #define KMT_TAB 256  // capacity of the per-band base-coordinate tables
@@ -98,90 +217,153 @@ __device__ __forceinline__ void kmt_accumulate_gm(float (&gm)[9], const KmCoord<
 __device__ __forceinline__ float kmt_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int kmt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// fixed-point quantisation of one contribution: floor(v + 0.5) in ONE instruction (v_cvt_rpi_i32_f32) instead of
+// v_rndne_f32 + v_cvt_i32_f32.  Ties round up instead of to even; both are exact integers of the same
+// magnitude bound, and the result stays independent of the order of accumulation.
+#ifndef KMT_CVT_RPI
+#define KMT_CVT_RPI 1
+#endif
+__device__ __forceinline__ int kmt_quant(float v) {
+#if KMT_CVT_RPI
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    return __float2int_rn(v);
+#endif
+}
+
 // one output pixel of pass B.  Branch-free up to the (exec-masked) atomics: every load is unconditional
 // (clamped addresses) so that the loads of two pixels processed back to back can be in flight together.
+// per-thread walk over the box in steps of 256 elements: (qi, qj) of element e + 256 from those of e
+__device__ __forceinline__ void kmt_advance(int& qi, int& qj, int di, int dj, int bw) {
+    qj += dj;
+    qi += di;
+    const bool carry = qj >= bw;
+    qj = carry ? qj - bw : qj;
+    qi = carry ? qi + 1 : qi;
+}
+
 template <typename T, int CM, bool WANT_GM>
-__device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const float (&m)[9], int e, bool valid, int bw, float inv_bw,
-                                             int j0, int ib, bool tab_x, const float* s_u, const float* s_v, int* s_acc, bool finite,
-                                             float scale, int cbase, int cc, const T* src_b, const T* gout_b, size_t src_plane,
-                                             size_t dst_plane, int X0, int X1, int Y0, int Y1, float (&gm)[9], float bound, bool& exceeded) {
+__device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const float (&m)[9], int qi, int qj, bool valid, int j0, int ib,
+                                             bool tab_x, const float* s_u, const float* s_v, int* s_acc, bool finite, float scale, int cbase,
+                                             int cc, const T* src_b, const T* const (&gout_c)[KMT_CC], size_t src_plane, int X0, int TWc, int Y0,
+                                             int THc, float (&gm)[9], uint32_t& seen_bits) {
     typedef float R;
     const KmWarpGeom<R>& g = a.g;
-    int qi = (int)(((float)e + 0.5f) * inv_bw);
-    int qj = e - qi * bw;
-    if (qj < 0) { qi -= 1; qj += bw; }
-    if (qj >= bw) { qi += 1; qj -= bw; }
     const int jj = j0 + qj, ii = ib + qi;
-    const T* go_px = gout_b + (size_t)ii * g.w + jj;
+    const uint32_t off = (uint32_t)ii * (uint32_t)g.w + (uint32_t)jj;  // host guarantees h * w < 2^31
     R go[KMT_CC];
 #pragma unroll
-    for (int c = 0; c < KMT_CC; ++c) go[c] = (c < cc) ? (R)km_ld(go_px + (size_t)(cbase + c) * dst_plane) : (R)0;
-    // the fixed-point scale was chosen for |grad_out| <= bound; anything larger (or NaN) voids the attempt
+    for (int c = 0; c < KMT_CC; ++c) go[c] = (R)km_ld(gout_c[c] + off);  // channels >= cc alias channel cc-1 (never used)
+    // the fixed-point scale was chosen for |grad_out| <= bound: remember the largest magnitude seen, as an integer
+    // (sign cleared, IEEE bit patterns order like unsigned integers and NaN / inf sort above every finite value)
+    {
+        uint32_t mb = __float_as_uint(go[0]) & 0x7fffffffu;
 #pragma unroll
-    for (int c = 0; c < KMT_CC; ++c) exceeded = exceeded || !(km_fabs(go[c]) <= bound);
+        for (int c = 1; c < KMT_CC; ++c) mb = max(mb, __float_as_uint(go[c]) & 0x7fffffffu);
+        seen_bits = max(seen_bits, mb);
+    }
     KmCoord<R> cd;
     km_gen_coord<R, CM>(m, tab_x ? s_u[qj] : km_base_x<R, CM>(g, jj), s_v[qi], cd);
     R mx, my;
     const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
     const R y = km_unnormalize(cd.gy, g.H, g.align, my);
-    const bool live = valid && (x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H);  // has an in-image tap
-    KmBilin<R> t;
-    km_bilinear_setup(x, y, g.W, g.H, t);
-    const int x0 = (int)fmaxf(fminf(km_floor(x), (R)g.W), (R)-1), y0 = (int)fmaxf(fminf(km_floor(y), (R)g.H), (R)-1);
-    const int x1 = x0 + 1, y1 = y0 + 1;
-    const bool in_x0 = (x0 >= X0 && x0 < X1), in_x1 = (x1 >= X0 && x1 < X1);
-    const bool in_y0 = (y0 >= Y0 && y0 < Y1), in_y1 = (y1 >= Y0 && y1 < Y1);
-    const bool t00 = live && t.b00 && in_x0 && in_y0, t01 = live && t.b01 && in_x1 && in_y0;
-    const bool t10 = live && t.b10 && in_x0 && in_y1, t11 = live && t.b11 && in_x1 && in_y1;
-    const int l00 = (y0 - Y0) * KMT_TW + (x0 - X0);
+    // weights: the forward's own expressions ((x0 + 1) - x, x - x0), so grad_src = W^T grad_out for the very W it applied
+    const R xf = km_floor(x), yf = km_floor(y);
+    const R wx0 = x - xf, wx1 = (xf + 1) - x, wy0 = y - yf, wy1 = (yf + 1) - y;
+    // tile-relative tap position.  A tap inside the tile is inside the image, so the in-tile test is the whole
+    // predicate; clamping in float first sends NaN / huge coordinates (and the padding lanes) outside the tile
+    const int ux = (int)fmaxf(fminf(xf, (R)g.W), (R)-2) - X0;
+    const int uy = valid ? (int)fmaxf(fminf(yf, (R)g.H), (R)-2) - Y0 : (1 << 20);
+    const bool in_x0 = (uint32_t)ux < (uint32_t)TWc, in_x1 = (uint32_t)(ux + 1) < (uint32_t)TWc;
+    const bool in_y0 = (uint32_t)uy < (uint32_t)THc, in_y1 = (uint32_t)(uy + 1) < (uint32_t)THc;
+    const bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;
+    const int l00 = uy * KMT_TW + ux;
+    struct { R w00, w01, w10, w11; } t;
+    t.w00 = wx1 * wy1; t.w01 = wx0 * wy1; t.w10 = wx1 * wy0; t.w11 = wx0 * wy0;
+    // tap-outer order: one exec-mask region per tap (4 per pixel) instead of one per atomic (4 * C)
     if (finite) {
         const R w00 = t.w00 * scale, w01 = t.w01 * scale, w10 = t.w10 * scale, w11 = t.w11 * scale;
+        int* accp = s_acc + l00;
+        if (t00) {
 #pragma unroll
-        for (int c = 0; c < KMT_CC; ++c) {
-            if (c < cc) {
-                int* accp = s_acc + c * (KMT_TH * KMT_TW) + l00;
-                if (t00) atomicAdd(accp, __float2int_rn(w00 * go[c]));
-                if (t01) atomicAdd(accp + 1, __float2int_rn(w01 * go[c]));
-                if (t10) atomicAdd(accp + KMT_TW, __float2int_rn(w10 * go[c]));
-                if (t11) atomicAdd(accp + KMT_TW + 1, __float2int_rn(w11 * go[c]));
-            }
+            for (int c = 0; c < KMT_CC; ++c)
+                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW), kmt_quant(w00 * go[c]));
+        }
+        if (t01) {
+#pragma unroll
+            for (int c = 0; c < KMT_CC; ++c)
+                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW) + 1, kmt_quant(w01 * go[c]));
+        }
+        if (t10) {
+#pragma unroll
+            for (int c = 0; c < KMT_CC; ++c)
+                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW, kmt_quant(w10 * go[c]));
+        }
+        if (t11) {
+#pragma unroll
+            for (int c = 0; c < KMT_CC; ++c)
+                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW + 1, kmt_quant(w11 * go[c]));
         }
     } else {
         // inf / NaN in grad_out, vanishing-line tiles, extreme magnification: float LDS atomics
+        float* accp = (float*)s_acc + l00;
 #pragma unroll
         for (int c = 0; c < KMT_CC; ++c) {
             if (c < cc) {
-                float* accp = (float*)s_acc + c * (KMT_TH * KMT_TW) + l00;
-                if (t00) atomicAdd(accp, t.w00 * go[c]);
-                if (t01) atomicAdd(accp + 1, t.w01 * go[c]);
-                if (t10) atomicAdd(accp + KMT_TW, t.w10 * go[c]);
-                if (t11) atomicAdd(accp + KMT_TW + 1, t.w11 * go[c]);
+                if (t00) atomicAdd(accp + c * (KMT_TH * KMT_TW), t.w00 * go[c]);
+                if (t01) atomicAdd(accp + c * (KMT_TH * KMT_TW) + 1, t.w01 * go[c]);
+                if (t10) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW, t.w10 * go[c]);
+                if (t11) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW + 1, t.w11 * go[c]);
             }
         }
     }
     if (WANT_GM) {
         // the tile holding the clamped north-west tap owns q's matrix gradient
-        const int ox = min(max(x0, 0), g.W - 1), oy = min(max(y0, 0), g.H - 1);
-        const bool own = live && (ox >= X0 && ox < X1 && oy >= Y0 && oy < Y1);
+        const bool live = valid && (x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H);  // has an in-image tap
+        KmBilin<R> tb;
+        km_bilinear_setup(x, y, g.W, g.H, tb);
+        const int x0 = (int)fmaxf(fminf(xf, (R)g.W), (R)-1), y0 = (int)fmaxf(fminf(yf, (R)g.H), (R)-1);
+        const int ox = min(max(x0, 0), g.W - 1) - X0, oy = min(max(y0, 0), g.H - 1) - Y0;
+        const bool own = live && ((uint32_t)ox < (uint32_t)TWc) && ((uint32_t)oy < (uint32_t)THc);
         R gix = 0, giy = 0;
-        if (own)  // measured: skipping the tap loads of non-owned pixels beats batching them (1.56 -> 1.50 ms)
-        {
+        if (own) {  // measured: skipping the tap loads of non-owned pixels beats batching them (1.56 -> 1.50 ms)
+            // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
+            if (__all(tb.b00 && tb.b01 && tb.b10 && tb.b11)) {
+                // every owner lane of the wave samples inside the image: (x0, x0 + 1) come with one load per row
 #pragma unroll
-        for (int c = 0; c < KMT_CC; ++c) {
-            if (c < cc) {
-                const T* img = src_b + (size_t)(cbase + c) * src_plane;
-                const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
-                // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
-                const R v00 = (R)km_ld(img + t.i00), v01 = (R)km_ld(img + t.i01), v10 = (R)km_ld(img + t.i10), v11 = (R)km_ld(img + t.i11);
-                const R s00 = t.b00 ? v00 - f : (R)0, s01 = t.b01 ? v01 - f : (R)0;
-                const R s10 = t.b10 ? v10 - f : (R)0, s11 = t.b11 ? v11 - f : (R)0;
-                // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
-                gix += go[c] * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
-                giy += go[c] * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+                for (int c = 0; c < KMT_CC; ++c) {
+                    if (c < cc) {
+                        const T* img = src_b + (size_t)(cbase + c) * src_plane;
+                        R s00, s01, s10, s11;
+                        km_ld2(img + tb.i00, s00, s01);
+                        km_ld2(img + tb.i10, s10, s11);
+                        if (g.pad == KM_PAD_FILL) {  // same rounding sequence as the oracle: (v - fill) first
+                            const R f = a.fill[cbase + c];
+                            s00 -= f; s01 -= f; s10 -= f; s11 -= f;
+                        }
+                        gix += go[c] * ((s01 - s00) * tb.wy1 + (s11 - s10) * tb.wy0);
+                        giy += go[c] * ((s10 - s00) * tb.wx1 + (s11 - s01) * tb.wx0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < KMT_CC; ++c) {
+                    if (c < cc) {
+                        const T* img = src_b + (size_t)(cbase + c) * src_plane;
+                        const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
+                        // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
+                        const R v00 = (R)km_ld(img + tb.i00), v01 = (R)km_ld(img + tb.i01), v10 = (R)km_ld(img + tb.i10), v11 = (R)km_ld(img + tb.i11);
+                        const R s00 = tb.b00 ? v00 - f : (R)0, s01 = tb.b01 ? v01 - f : (R)0;
+                        const R s10 = tb.b10 ? v10 - f : (R)0, s11 = tb.b11 ? v11 - f : (R)0;
+                        gix += go[c] * ((s01 - s00) * tb.wy1 + (s11 - s10) * tb.wy0);
+                        giy += go[c] * ((s10 - s00) * tb.wx1 + (s11 - s01) * tb.wx0);
+                    }
+                }
             }
         }
-        }
-        if (own) kmt_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
+        if (own) km_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
     }
 }
 
@@ -209,6 +391,7 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ double red[4][9];
     __shared__ float red_max[4];
+    __shared__ int s_box[8];
 
     const KmWarpGeom<R>& g = a.g;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
@@ -227,75 +410,23 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
         for (int k = 0; k < 9; ++k) m[k] = mp[k];
     }
 
-    // ---- G: source pixel (x, y, 1) -> (Jn, In, D), output index (j, i) = (Jn, In) / D -----------------
-    int j0 = 0, j1 = g.w - 1, i0 = 0, i1 = g.h - 1;
-    R mult = 16.f;  // bound on the number of output pixels whose footprint covers one source pixel
-    bool fixed_ok = false;  // fixed-point accumulation is accurate enough (bounded multiplicity)
-    {
-        R G[9];
-        // adjugate of m (un-normalised inverse: the common scale cancels in the projective divide)
-        const R A0 = m[4] * m[8] - m[5] * m[7], A1 = m[2] * m[7] - m[1] * m[8], A2 = m[1] * m[5] - m[2] * m[4];
-        const R A3 = m[5] * m[6] - m[3] * m[8], A4 = m[0] * m[8] - m[2] * m[6], A5 = m[2] * m[3] - m[0] * m[5];
-        const R A6 = m[3] * m[7] - m[4] * m[6], A7 = m[1] * m[6] - m[0] * m[7], A8 = m[0] * m[4] - m[1] * m[3];
-        // pixel -> normalised source coordinate (inverse of km_unnormalize): gn = ax * x + bx
-        const R ax = g.align ? (g.W > 1 ? 2.0f / (R)(g.W - 1) : 0.0f) : 2.0f / (R)g.W;
-        const R bx = g.align ? -1.0f : 1.0f / (R)g.W - 1.0f;
-        const R ay = g.align ? (g.H > 1 ? 2.0f / (R)(g.H - 1) : 0.0f) : 2.0f / (R)g.H;
-        const R by = g.align ? -1.0f : 1.0f / (R)g.H - 1.0f;
-        const R P0 = A0 * ax, P1 = A1 * ay, P2 = A0 * bx + A1 * by + A2;
-        const R P3 = A3 * ax, P4 = A4 * ay, P5 = A3 * bx + A4 * by + A5;
-        const R P6 = A6 * ax, P7 = A7 * ay, P8 = A6 * bx + A7 * by + A8;
-        R sj, oj, si, oi;
-        kmt_index_affine<CM>(g, g.w, g.lin_lo_x, g.lin_step_x, sj, oj);
-        kmt_index_affine<CM>(g, g.h, g.lin_lo_y, g.lin_step_y, si, oi);
-        G[0] = sj * P0 + oj * P6; G[1] = sj * P1 + oj * P7; G[2] = sj * P2 + oj * P8;
-        G[3] = si * P3 + oi * P6; G[4] = si * P4 + oi * P7; G[5] = si * P5 + oi * P8;
-        G[6] = P6; G[7] = P7; G[8] = P8;
-
-        // box of output pixels that can touch the tile (corners of the tile grown by the bilinear footprint)
-        const R xs[2] = {(R)(X0 - 1), (R)X1}, ys[2] = {(R)(Y0 - 1), (R)Y1};
-        R jmin = 3.0e38f, jmax = -3.0e38f, imin = 3.0e38f, imax = -3.0e38f, dmin = 3.0e38f, dmax = -3.0e38f, nmax = 0.f;
-        R njx = 0.f, njy = 0.f, nix = 0.f, niy = 0.f;
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const R Jn = G[0] * xs[cx] + G[1] * ys[cy] + G[2];
-                const R In = G[3] * xs[cx] + G[4] * ys[cy] + G[5];
-                const R D = G[6] * xs[cx] + G[7] * ys[cy] + G[8];
-                dmin = fminf(dmin, D); dmax = fmaxf(dmax, D);
-                nmax = fmaxf(nmax, fmaxf(fabsf(Jn), fabsf(In)));
-                const R fj = Jn / D, fi = In / D;
-                jmin = fminf(jmin, fj); jmax = fmaxf(jmax, fj);
-                imin = fminf(imin, fi); imax = fmaxf(imax, fi);
-                njx = fmaxf(njx, fabsf(G[0] * D - Jn * G[6])); njy = fmaxf(njy, fabsf(G[1] * D - Jn * G[7]));
-                nix = fmaxf(nix, fabsf(G[3] * D - In * G[6])); niy = fmaxf(niy, fabsf(G[4] * D - In * G[7]));
-            }
-        const bool same_sign = (dmin > 0.f) || (dmax < 0.f);
-        const R dabs_min = fminf(fabsf(dmin), fabsf(dmax)), dabs_max = fmaxf(fabsf(dmin), fabsf(dmax));
-        const bool ok = same_sign && (dabs_min > 1e-6f * fmaxf(nmax, dabs_max)) && (jmin == jmin) && (jmax == jmax) && (imin == imin) && (imax == imax);
-        if (ok) {
-            const R big = 1.0e9f;
-            j0 = max(0, (int)floorf(fmaxf(jmin, -big)) - 1);
-            j1 = min(g.w - 1, (int)ceilf(fminf(jmax, big)) + 1);
-            i0 = max(0, (int)floorf(fmaxf(imin, -big)) - 1);
-            i1 = min(g.h - 1, (int)ceilf(fminf(imax, big)) + 1);
-            // output pixels per source pixel: the 2x2 footprint box maps to at most (2 ex + 1)(2 ey + 1) lattice points
-            const R inv_d2 = 1.0f / (dabs_min * dabs_min);
-            const R ex = (njx + njy) * inv_d2 + 0.1f, ey = (nix + niy) * inv_d2 + 0.1f;
-            mult = fminf((2.f * ex + 1.f) * (2.f * ey + 1.f), 1.0e6f);
-            fixed_ok = mult <= 256.f;  // beyond ~7x magnification the head-room would eat the mantissa: float path
-        } else {
-            // tile crossed by the vanishing line: visit the whole output (correct, slower); no multiplicity bound
-            mult = (R)g.w * (R)g.h;
+    // ---- box of output pixels that can touch the tile: computed by wave 0 only (it is ~300 block-uniform
+    //      VALU instructions, ~15 % of a block's work if all four waves repeat it), broadcast through LDS
+    if (wave == 0) {
+        const KmtBox bx = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
+        if (lane == 0) {
+            s_box[0] = bx.j0; s_box[1] = bx.j1; s_box[2] = bx.i0; s_box[3] = bx.i1;
+            s_box[4] = (int)ceilf(log2f(fmaxf(bx.mult, 1.f))) + 1;  // head-room bits
+            s_box[5] = bx.fixed_ok ? 1 : 0;
         }
     }
-    j0 = kmt_uniform(j0); j1 = kmt_uniform(j1); i0 = kmt_uniform(i0); i1 = kmt_uniform(i1);
+    __syncthreads();
+    const int j0 = kmt_uniform(s_box[0]), j1 = kmt_uniform(s_box[1]), i0 = kmt_uniform(s_box[2]), i1 = kmt_uniform(s_box[3]);
+    const int hb = kmt_uniform(s_box[4]);
+    const bool fixed_ok = kmt_uniform(s_box[5]) != 0;  // fixed-point accumulation is accurate enough (bounded multiplicity)
     const int bw = j1 - j0 + 1, bh = i1 - i0 + 1;
     const bool empty = (bw <= 0 || bh <= 0);
     const float inv_bw = kmt_uniform(bw > 0 ? 1.0f / (float)bw : 0.f);
-    const int hb = kmt_uniform((int)ceilf(log2f(fmaxf(mult, 1.f))) + 1);  // head-room bits
-    fixed_ok = kmt_uniform((int)fixed_ok) != 0;
 
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
     const T* src_b = a.src + (size_t)b * g.C * src_plane;
@@ -384,29 +515,39 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
             R gm_try[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) gm_try[k] = 0;
-            bool exceeded = false;
+            uint32_t seen_bits = 0;  // largest |grad_out| bit pattern this thread has loaded
             if (!empty) {
+                const T* gout_c[KMT_CC];
+#pragma unroll
+                for (int c = 0; c < KMT_CC; ++c) gout_c[c] = gout_b + (size_t)(cbase + min(c, cc - 1)) * dst_plane;
+                const int di = kmt_uniform(256 / bw), dj = kmt_uniform(256 % bw);  // element e + 256 is di rows and dj columns on
+                const int TWc = X1 - X0, THc = Y1 - Y0;
                 for (int ib = i0; ib <= i1; ib += KMT_TAB) {
                     const int ie = min(i1, ib + KMT_TAB - 1);
                     __syncthreads();
                     if (tid <= ie - ib) s_v[tid] = km_base_y<R, CM>(g, ib + tid);
                     __syncthreads();
                     const int nq = bw * (ie - ib + 1);
+                    int qi = tid / bw, qj = tid - qi * bw;  // element e = base + tid
                     int base = 0;
                     for (; base + KMT_UNROLL * 256 <= nq; base += KMT_UNROLL * 256) {
 #pragma unroll
-                        for (int s4 = 0; s4 < KMT_UNROLL; ++s4)
-                            kmt_scatter_q<T, CM, WANT_GM>(a, m, base + s4 * 256 + tid, true, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite,
-                                                          scale, cbase, cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm_try, bound,
-                                                          exceeded);
+                        for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {
+                            kmt_scatter_q<T, CM, WANT_GM>(a, m, qi, qj, true, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale, cbase, cc, src_b,
+                                                          gout_c, src_plane, X0, TWc, Y0, THc, gm_try, seen_bits);
+                            kmt_advance(qi, qj, di, dj, bw);
+                        }
                     }
                     for (; base < nq; base += 256) {
-                        const int e = base + tid;
-                        kmt_scatter_q<T, CM, WANT_GM>(a, m, min(e, nq - 1), e < nq, bw, inv_bw, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale,
-                                                      cbase, cc, src_b, gout_b, src_plane, dst_plane, X0, X1, Y0, Y1, gm_try, bound, exceeded);
+                        const bool valid = base + tid < nq;
+                        kmt_scatter_q<T, CM, WANT_GM>(a, m, valid ? qi : 0, valid ? qj : 0, valid, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale,
+                                                      cbase, cc, src_b, gout_c, src_plane, X0, TWc, Y0, THc, gm_try, seen_bits);
+                        kmt_advance(qi, qj, di, dj, bw);
                     }
                 }
             }
+            // the fixed-point scale was chosen for |grad_out| <= bound; anything larger (or NaN) voids the attempt
+            const bool exceeded = seen_bits > __float_as_uint(bound);
             const int redo = __syncthreads_or((int)exceeded);
             if (attempt == 0 && redo) {
                 for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0;  // discard the speculative attempt

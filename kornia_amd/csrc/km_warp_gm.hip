@@ -1,0 +1,214 @@
+// kornia_amd - gradient of the bilinear warps with respect to the (B,3,3) matrix, for gfx950.
+//
+// d loss / d M  =  sum over output pixels q of  J_q^T (dL/dx_q, dL/dy_q),  with
+//   dL/dx_q = sum_c grad_out[q,c] * ((ne - nw)(y1 - y) + (se - sw)(y - y0))     (image gradient at the sample)
+//   dL/dy_q = sum_c grad_out[q,c] * ((sw - nw)(x1 - x) + (se - ne)(x - x0))
+// and J_q the Jacobian of the sampling position with respect to the matrix entries (SURVEY.md A.6;
+// reference: autograd through kornia/geometry/transform/imgwarp.py:157-174 / linalg.py:219-239).
+//
+// This is an OUTPUT-pixel-centric reduction: it has the access pattern of the forward warp (coalesced
+// grad_out reads, gathered src taps) and none of the scatter of grad_src, so it runs as its own kernel
+// shaped like the specialised forward (km_warp_fwd_bz_kernel) instead of riding in the tile-owner
+// scatter kernel, where it cost more than the scatter itself (owner predication, 118 VGPRs).
+//   * a wave owns a 64-wide x KMG_ROWS-tall strip of the output, lane = column;
+//   * per-thread partial sums in fp32 (<= KMG_ROWS * C terms), wave + block reduction and the global
+//     accumulation in fp64 (9 atomics per block);
+//   * HBM traffic: read grad_out once + src once = 2e bytes / element.
+#include <stdlib.h>
+
+#include "km_sampler.h"
+
+#define KMG_ROWS 8
+#define KMG_TILE_W 64
+#define KMG_TILE_H (4 * KMG_ROWS)
+
+template <typename T>
+struct KmWarpGmArgs {
+    const T* src;       // (B,C,H,W)
+    const T* gout;      // (B,C,h,w)
+    const float* mat;   // (B_M,9)
+    double* gmat;       // (B_M,9) fp64 accumulators, pre-zeroed
+    const float* fill;  // (C), pad == fill only
+    KmWarpGeom<float> g;
+    uint32_t tiles_x, tiles_y, nblocks;
+};
+
+template <typename T, int CM, int NC>  // NC = 3: RGB unrolled ; NC = 0: runtime channel loop
+__global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a) {
+    typedef float R;
+    const KmWarpGeom<R>& g = a.g;
+    __shared__ double red[4][9];
+    __shared__ R s_v[KMG_TILE_H];
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = (int)tx * KMG_TILE_W + lane;
+    const int i_base = (int)ty * KMG_TILE_H + wave * KMG_ROWS;
+    if (threadIdx.x < KMG_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KMG_TILE_H + (int)threadIdx.x);
+    __syncthreads();
+
+    R m[9];
+    {
+        const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+    }
+    const int W = g.W, H = g.H, align = g.align;
+    const int C = (NC > 0) ? NC : g.C;
+    const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
+    const T* __restrict__ src_b = a.src + (size_t)b * C * src_plane;
+    const T* __restrict__ gout_b = a.gout + (size_t)b * C * dst_plane;
+    const bool col_ok = j < g.w;
+    const R u = km_base_x<R, CM>(g, col_ok ? j : 0);
+    const bool is_fill = (g.pad == KM_PAD_FILL);
+
+    R gm[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gm[k] = 0;
+
+#pragma unroll 2
+    for (int r = 0; r < KMG_ROWS; ++r) {
+        const int i = i_base + r;
+        const bool ok = col_ok && (i < g.h);
+        KmCoord<R> cd;
+        km_gen_coord<R, CM>(m, u, s_v[wave * KMG_ROWS + r], cd);
+        R mx, my;
+        const R x = km_unnormalize(cd.gx, W, align, mx);
+        const R y = km_unnormalize(cd.gy, H, align, my);
+        KmBilin<R> t;
+        km_bilinear_setup(x, y, W, H, t);
+        const uint32_t go_off = ok ? (uint32_t)i * (uint32_t)g.w + (uint32_t)j : 0u;
+        R gix = 0, giy = 0;
+        if (__all(t.b00 && t.b01 && t.b10 && t.b11)) {
+            // the whole wave samples inside the image: (x0, x0 + 1) come with one load per row
+            if (NC == 3) {
+                const R g0 = (R)km_ld(km_at(gout_b, go_off)), g1 = (R)km_ld(km_at(gout_b + dst_plane, go_off));
+                const R g2 = (R)km_ld(km_at(gout_b + 2 * dst_plane, go_off));
+                R a00, a01, a10, a11, b00, b01, b10, b11, c00, c01, c10, c11;
+                km_ld2(km_at(src_b, (uint32_t)t.i00), a00, a01);
+                km_ld2(km_at(src_b, (uint32_t)t.i10), a10, a11);
+                km_ld2(km_at(src_b + src_plane, (uint32_t)t.i00), b00, b01);
+                km_ld2(km_at(src_b + src_plane, (uint32_t)t.i10), b10, b11);
+                km_ld2(km_at(src_b + 2 * src_plane, (uint32_t)t.i00), c00, c01);
+                km_ld2(km_at(src_b + 2 * src_plane, (uint32_t)t.i10), c10, c11);
+                if (is_fill) {  // same rounding sequence as the oracle: (v - fill) first
+                    const R f0 = a.fill[0], f1 = a.fill[1], f2 = a.fill[2];
+                    a00 -= f0; a01 -= f0; a10 -= f0; a11 -= f0;
+                    b00 -= f1; b01 -= f1; b10 -= f1; b11 -= f1;
+                    c00 -= f2; c01 -= f2; c10 -= f2; c11 -= f2;
+                }
+                gix += g0 * ((a01 - a00) * t.wy1 + (a11 - a10) * t.wy0);
+                giy += g0 * ((a10 - a00) * t.wx1 + (a11 - a01) * t.wx0);
+                gix += g1 * ((b01 - b00) * t.wy1 + (b11 - b10) * t.wy0);
+                giy += g1 * ((b10 - b00) * t.wx1 + (b11 - b01) * t.wx0);
+                gix += g2 * ((c01 - c00) * t.wy1 + (c11 - c10) * t.wy0);
+                giy += g2 * ((c10 - c00) * t.wx1 + (c11 - c01) * t.wx0);
+            } else {
+                for (int c = 0; c < C; ++c) {
+                    const R go = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off));
+                    const T* img = src_b + (size_t)c * src_plane;
+                    R s00, s01, s10, s11;
+                    km_ld2(km_at(img, (uint32_t)t.i00), s00, s01);
+                    km_ld2(km_at(img, (uint32_t)t.i10), s10, s11);
+                    if (is_fill) {
+                        const R f = a.fill[c];
+                        s00 -= f; s01 -= f; s10 -= f; s11 -= f;
+                    }
+                    gix += go * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
+                    giy += go * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+                }
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                const R go = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off));
+                const T* img = src_b + (size_t)c * src_plane;
+                const R f = is_fill ? a.fill[c] : (R)0;
+                // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
+                const R v00 = (R)km_ld(img + t.i00), v01 = (R)km_ld(img + t.i01), v10 = (R)km_ld(img + t.i10), v11 = (R)km_ld(img + t.i11);
+                const R s00 = t.b00 ? v00 - f : (R)0, s01 = t.b01 ? v01 - f : (R)0;
+                const R s10 = t.b10 ? v10 - f : (R)0, s11 = t.b11 ? v11 - f : (R)0;
+                gix += go * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
+                giy += go * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+            }
+        }
+        // pixels outside the output (padding lanes / rows of the last tiles) contribute nothing
+        gix = ok ? gix * mx : (R)0;
+        giy = ok ? giy * my : (R)0;
+        km_accumulate_gm<CM>(gm, cd, gix, giy);
+    }
+
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double s = km_wave_sum((double)gm[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (s != 0.0) km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + threadIdx.x, s);
+    }
+}
+
+template <typename T, int CM>
+static int kmg_launch(const KmWarpGmArgs<T>& a, hipStream_t s) {
+    if (a.g.C == 3)
+        hipLaunchKernelGGL((km_warp_gm_kernel<T, CM, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_gm_kernel<T, CM, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch("km_warp2d_bwd(matrix gradient)");
+}
+
+template <typename T>
+static int kmg_run(const void* gout, const void* src, const void* mat, double* gmat, int B, int C, int H, int W, int h, int w, int B_M,
+                   int coord_mode, int norm_coords, int pad, int align, const void* fill, hipStream_t s) {
+    KmWarpGmArgs<T> a;
+    a.src = (const T*)src; a.gout = (const T*)gout; a.mat = (const float*)mat; a.gmat = gmat; a.fill = (const float*)fill;
+    KmWarpGeom<float>& g = a.g;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
+    g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = KM_INTERP_BILINEAR; g.pad = pad; g.align = align;
+    if (align) {
+        g.lin_lo_x = -1.0f; g.lin_hi_x = 1.0f; g.lin_lo_y = -1.0f; g.lin_hi_y = 1.0f;
+    } else {
+        g.lin_lo_x = (float)(-1.0 + 1.0 / w); g.lin_hi_x = (float)(1.0 - 1.0 / w);
+        g.lin_lo_y = (float)(-1.0 + 1.0 / h); g.lin_hi_y = (float)(1.0 - 1.0 / h);
+    }
+    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (float)(w - 1) : 0.0f;
+    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (float)(h - 1) : 0.0f;
+    a.tiles_x = (uint32_t)((w + KMG_TILE_W - 1) / KMG_TILE_W);
+    a.tiles_y = (uint32_t)((h + KMG_TILE_H - 1) / KMG_TILE_H);
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
+    KM_REQUIRE(nb < (1ull << 31), "km_warp2d_bwd: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    switch (coord_mode) {
+        case KM_COORD_PERSPECTIVE: return kmg_launch<T, KM_COORD_PERSPECTIVE>(a, s);
+        case KM_COORD_AFFINE: return kmg_launch<T, KM_COORD_AFFINE>(a, s);
+        default: return kmg_launch<T, KM_COORD_HOMOGRAPHY>(a, s);
+    }
+}
+
+// 1 if this kernel computes the matrix gradient for these modes (bilinear, zeros / fill padding, fp32 compute)
+int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, int w) {
+    static int disabled = -1;
+    if (disabled < 0) {
+        const char* e = getenv("KM_WARP_GM_ALGO");  // "generic": the atomic scatter kernel computes it (A/B timing)
+        disabled = (e && e[0] == 'g') ? 1 : 0;
+    }
+    if (disabled) return 0;
+    if (!(interp == KM_INTERP_BILINEAR && (pad == KM_PAD_ZEROS || pad == KM_PAD_FILL) && dtype != KM_F64)) return 0;
+    if (W < 2) return 0;  // the pair loads need two columns
+    // 32-bit byte offsets inside a plane
+    return ((uint64_t)H * W * 4 < (1ull << 32) && (uint64_t)h * w * 4 < (1ull << 32)) ? 1 : 0;
+}
+
+int km_warp_gm_run(const void* gout, const void* src, const void* mat, double* gmat, int B, int C, int H, int W, int h, int w, int B_M,
+                   int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case KM_F32: return kmg_run<float>(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+        case KM_BF16: return kmg_run<km_bf16>(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+        default: return kmg_run<km_f16>(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+    }
+}
