@@ -107,18 +107,30 @@ def kernel_roofline(x, M, go, size, iters):
     def blur_bwd():
         N.check(lib.km_filter2d_sep_bwd_input(go.data_ptr(), kx.data_ptr(), ky.data_ptr(), gw.data_ptr(), B, C, h, w, 1, 5, 5, 1, 1, 0, stream), "bb")
 
-    def warp_bwd():
+    def warp_bwd_gsrc():  # tile-owner scatter: grad wrt the image
+        N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), None, B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
+
+    def warp_bwd_gmat():  # forward-shaped reduction: grad wrt the homography
+        N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), None, gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wm")
+
+    def warp_bwd():  # the public op = both kernels back to back
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
 
+    # algorithmic bytes per launch = compulsory traffic of what the kernel computes (DESIGN.md "Roofline accounting"):
+    # every tensor it must read once + every tensor it must write once, e bytes per element
     stats = {}
     for name, fn, nbytes in (
-        ("km_warp_fwd_kernel", warp_fwd, 2 * e * n_el),
-        ("km_filter_sep_fwd_kernel", blur_fwd, 2 * e * n_el),
-        ("km_filter_sep_bwd_kernel", blur_bwd, 2 * e * n_el),
-        ("km_warp_bwd_kernel", warp_bwd, 3 * e * n_el),
+        ("km_warp_fwd_bz_kernel", warp_fwd, 2 * e * n_el),        # read src, write out
+        ("km_blur_reg_kernel<fwd>", blur_fwd, 2 * e * n_el),      # read x, write y
+        ("km_blur_reg_kernel<bwd>", blur_bwd, 2 * e * n_el),      # read grad_y, write grad_x
+        ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el),  # read grad_out, write grad_src
+        ("km_warp_gm_kernel", warp_bwd_gmat, 2 * e * n_el),       # read grad_out, read src
     ):
         ms = event_time_ms(fn, iters)
         stats[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1)}
+    ms = event_time_ms(warp_bwd, iters)
+    # the public op km_warp2d_bwd (both launches) against SURVEY 8(d)'s 3e: read grad_out, read src, write grad_src
+    stats["op:km_warp2d_bwd"] = {"ms": round(ms, 4), "alg_bytes": 3 * e * n_el, "GBps": round(3 * e * n_el / ms / 1e6, 1)}
     return stats
 
 
@@ -244,15 +256,16 @@ def main():
     if rank == 0:
         with torch.no_grad():
             kstats = kernel_roofline(x.detach(), M.detach(), go, S, max(5, min(args.steps, 20)))
-        dom = max(kstats, key=lambda k: kstats[k]["ms"])
+        dom = max((k for k in kstats if not k.startswith("op:")), key=lambda k: kstats[k]["ms"])
         achieved = kstats[dom]["GBps"]
         # HBM traffic of the dominant kernel: rocprofv3 PMC cannot run inside this process, so the figure is the
         # committed measurement of this very command/config (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if (B, C, S) == (256, 3, 512) and os.path.exists(tpath):
-            rocname = {"km_warp_bwd_kernel": "km_warp_bwd_tiled_kernel", "km_warp_fwd_kernel": "km_warp_fwd_bz_kernel",
-                       "km_filter_sep_fwd_kernel": "km_blur_reg_kernel<float, 5, false>", "km_filter_sep_bwd_kernel": "km_blur_reg_kernel<float, 5, true>"}[dom]
+            rocname = {"km_warp_bwd_tiled_kernel": "km_warp_bwd_tiled_kernel", "km_warp_gm_kernel": "km_warp_gm_kernel",
+                       "km_warp_fwd_bz_kernel": "km_warp_fwd_bz_kernel", "km_blur_reg_kernel<fwd>": "km_blur_reg_kernel<float, 5, false>",
+                       "km_blur_reg_kernel<bwd>": "km_blur_reg_kernel<float, 5, true>"}[dom]
             for kname, rec in json.load(open(tpath))["kernels"].items():
                 if rocname in kname:
                     traffic = rec["hbm_bytes_per_launch"]

@@ -515,11 +515,11 @@ static int km_warp_validate(const char* fn, const void* src, const void* mat, in
     return 0;
 }
 
-// owner-computes backward for bilinear + zeros/fill (km_warp_bwd_tiled.hip)
+// owner-computes grad_src for bilinear + zeros/fill (km_warp_bwd_tiled.hip)
 int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc);
-int km_warp_bwd_tiled_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H, int W,
-                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype,
-                          hipStream_t s);
+int km_warp_bwd_tiled_dims_ok(int h, int w);
+int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode,
+                          int norm_coords, int pad, int align, int dtype, hipStream_t s);
 
 // matrix gradient of the bilinear warps (km_warp_gm.hip)
 int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, int w);
@@ -558,15 +558,22 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
     if (!gsrc && !gmat) return 0;
     hipStream_t s = (hipStream_t)stream;
     // bilinear + zeros/fill: grad_src by the tile-owner scatter, the matrix gradient by its own forward-shaped kernel
-    const bool gm_split = gmat && km_warp_gm_supported(interp, pad, dtype, H, W, h, w);
+    const bool gm_fast = gmat && km_warp_gm_supported(interp, pad, dtype, H, W, h, w);
     if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc)) {
-        const int rc = km_warp_bwd_tiled_run(gout, src, mat, gsrc, gm_split ? nullptr : gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad,
-                                             align, fill, dtype, s);
-        if (rc != 0 || !gm_split) return rc;
+        if (km_warp_bwd_tiled_dims_ok(h, w)) {
+            const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, dtype, s);
+            if (rc != 0 || !gmat) return rc;
+            if (gm_fast) return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
+            gsrc = nullptr;  // matrix gradient by the generic kernel below (W < 2)
+        } else {
+            // planes beyond 2^30 pixels: generic atomic scatter; the caller was told not to zero grad_src (needs_zero_init == 0)
+            const size_t esz = 4;  // fp32 accumulators (fp64 never reaches this branch)
+            const hipError_t e = hipMemsetAsync(gsrc, 0, (size_t)B * C * H * W * esz, s);
+            if (e != hipSuccess) { km_set_error("km_warp2d_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    } else if (!gsrc && gm_fast) {  // matrix gradient only (learned-homography loops: SURVEY.md config 5)
         return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
     }
-    if (!gsrc && gm_split)  // matrix gradient only (learned-homography loops: SURVEY.md config 5)
-        return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
     switch (dtype) {
         case KM_F32: return km_warp_run<float>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         case KM_F64: return km_warp_run<double>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);

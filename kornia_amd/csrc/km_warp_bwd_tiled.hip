@@ -1,56 +1,55 @@
-// kornia_amd - "owner-computes" backward of the bilinear warps (zeros / fill padding) for gfx950.
+// kornia_amd - "owner-computes" gradient of the bilinear warps (zeros / fill padding) with respect to the
+// IMAGE, for gfx950.  (The gradient with respect to the matrix is km_warp_gm.hip.)
 //
-// The generic backward (km_warp.hip) scatters 4*C fp32 atomics per output pixel into HBM - what
-// ATen's grid_sampler_2d_backward does - and needs grad_src zeroed first: ~5e bytes of HBM traffic
-// per element against 3e algorithmic, serialised by the L2 atomic units (4.2 ms at 256x3x512^2).
-// LDS float atomics are no better on gfx950 (ds_add_f32 measured at ~2.5 ms for the same work).
-// This kernel therefore turns the scatter into an atomic-free, deterministic GATHER:
+// The generic backward (km_warp.hip) scatters 4*C fp32 atomics per output pixel into HBM - what ATen's
+// grid_sampler_2d_backward does - and needs grad_src zeroed first: ~5e bytes of HBM traffic per element
+// against 2e algorithmic, serialised by the L2 atomic units (4.2 ms at 256x3x512^2).  Here:
 //
-//   * a workgroup OWNS one 32x32 tile of grad_src (all channels); every thread owns 4 of its pixels
-//     and accumulates them in registers;
-//   * the output pixels q that can touch the tile are found by pushing the tile rectangle (grown by
-//     the 1-pixel bilinear footprint) through the inverse map G (source pixel -> output index): a
-//     projective map sends the rectangle to a convex quad, so the bounding box of the four mapped
-//     corners (+1 px) contains them all;
-//   * phase 1: for every q of the box the sampling position (x, y) is computed with EXACTLY the
-//     instruction sequence of the forward kernel (km_gen_coord), and staged in LDS together with
-//     grad_out[q, c].  The q's whose (clamped) north-west tap lies in this tile also contribute the
-//     matrix gradient here (each q exactly once over all tiles);
-//   * phase 2: each owned pixel p evaluates G(p) and inspects only the small window of q's around it
-//     that can satisfy |x_q - px| < 1 and |y_q - py| < 1; the window half-size is the L1 norm of the
-//     rows of the Jacobian of G over the tile (mean-value bound), 3x3 for near-unit scale.  Weights
-//     are the forward's own expressions ((x0+1) - x, x - x0), so grad_src = W^T grad_out for the very
-//     W the forward applied;
-//   * the tile is written once with plain coalesced stores: no memset, no atomics on grad_src, and
-//     a fixed summation order (bit-reproducible run to run).
+//   * a workgroup OWNS one KMT_TW x KMT_TH tile of grad_src (all channels) and accumulates it in LDS;
+//   * the output pixels q that can touch the tile are found by pushing the tile rectangle (grown by the
+//     1-pixel bilinear footprint) through the inverse map G (source pixel -> output index): a projective map
+//     sends the rectangle to a convex quad, so the bounding box of the four mapped corners plus an explicit
+//     rounding bound contains them all (kmt_tile_box);
+//   * every q of the box recomputes its sampling position with EXACTLY the forward's instruction sequence
+//     and adds its four contributions w * grad_out[q, c] to the taps that fall inside the tile.  Taps in
+//     other tiles are added by those tiles' owners, so every contribution is added exactly once;
+//   * gfx950 LDS float atomics are ~40x slower than integer ones (profiles/r01_lds_atomics_microbench.txt),
+//     so the accumulators are int32 fixed point (see the kernel comment): deterministic, order-independent;
+//   * the tile is converted and written once with coalesced stores: no memset, no global atomics.
 //
-// If the tile straddles the vanishing line of G (corner denominators of mixed sign or ~0) the
-// pre-image is not a bounded convex quad: that tile falls back to scanning the whole output image
-// with LDS atomics (correct, slower; only the tiles crossed by the line pay).
+// If the tile straddles the vanishing line of G (corner denominators of mixed sign or ~0) the pre-image is
+// not a bounded convex quad: that tile scans the whole output image (correct, slower; only the tiles crossed
+// by the line pay).
 //
-// HBM traffic: read grad_out ~1.4x (halo re-reads served by L2), read src once (matrix gradient
-// only), write grad_src once  =>  ~3e bytes/element, the algorithmic figure.
+// HBM traffic: read grad_out ~1.1x (box overlap, mostly served by L2) + write grad_src once = 2e bytes/element.
+// The kernel is VALU-issue bound (~150 instructions per visited pixel for the exact coordinate pipeline and
+// the 12 quantise+atomic pairs), not HBM bound: see DESIGN.md for the counters.
 #include <stdlib.h>
 
 #include "km_sampler.h"
 
-#define KMT_TW 64
-#define KMT_TH 32
-#define KMT_PX 4            // source pixels per thread (rows ty, ty+8, ty+16, ty+24)
+#ifndef KMT_TW
+#define KMT_TW 64           // tile width  (the flush maps lane -> column: keep 64)
+#endif
+#ifndef KMT_TH
+#define KMT_TH 64           // tile height
+#endif
+#ifndef KMT_NT
+#define KMT_NT 512          // threads per workgroup
+#endif
+#define KMT_NW (KMT_NT / 64)
 #define KMT_CC 3            // channels per pass
-#define KMT_LDS_BYTES (2 * 256 * 4 + KMT_CC * KMT_TH * KMT_TW * 4)
+#define KMT_TAB 128         // capacity of the per-band coordinate tables (float4 entries)
+#define KMT_PLANE (KMT_TH * KMT_TW)
+#define KMT_LDS_BYTES (2 * KMT_TAB * 16 + KMT_CC * KMT_PLANE * 4)
 
 template <typename T>
 struct KmWarpTiledArgs {
-    const T* src;
-    const T* gout;
+    const T* gout;       // (B,C,h,w)
     const float* mat;    // (B_M,9)
     float* gsrc;         // (B,C,H,W) fp32, written completely (no pre-zeroing needed)
-    double* gmat;        // (B_M,9) fp64 accumulators, pre-zeroed, nullable
-    const float* fill;   // (C) for pad == fill
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, nblocks;
-    int lds_bytes;       // dynamic LDS given to the block (staging capacity)
 };
 
 template <int CM>
@@ -211,8 +210,6 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
     return o;
 }
 
-#define KMT_TAB 256  // capacity of the per-band base-coordinate tables
-
 // block-uniform values computed with VALU float math live in VGPRs unless moved to SGPRs explicitly
 __device__ __forceinline__ float kmt_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int kmt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -220,22 +217,13 @@ __device__ __forceinline__ int kmt_uniform(int v) { return __builtin_amdgcn_read
 // fixed-point quantisation of one contribution: floor(v + 0.5) in ONE instruction (v_cvt_rpi_i32_f32) instead of
 // v_rndne_f32 + v_cvt_i32_f32.  Ties round up instead of to even; both are exact integers of the same
 // magnitude bound, and the result stays independent of the order of accumulation.
-#ifndef KMT_CVT_RPI
-#define KMT_CVT_RPI 1
-#endif
 __device__ __forceinline__ int kmt_quant(float v) {
-#if KMT_CVT_RPI
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
     return r;
-#else
-    return __float2int_rn(v);
-#endif
 }
 
-// one output pixel of pass B.  Branch-free up to the (exec-masked) atomics: every load is unconditional
-// (clamped addresses) so that the loads of two pixels processed back to back can be in flight together.
-// per-thread walk over the box in steps of 256 elements: (qi, qj) of element e + 256 from those of e
+// per-thread walk over the box in steps of KMT_NT elements: (qi, qj) of element e + KMT_NT from those of e
 __device__ __forceinline__ void kmt_advance(int& qi, int& qj, int di, int dj, int bw) {
     qj += dj;
     qi += di;
@@ -244,18 +232,51 @@ __device__ __forceinline__ void kmt_advance(int& qi, int& qj, int di, int dj, in
     qi = carry ? qi + 1 : qi;
 }
 
-template <typename T, int CM, bool WANT_GM>
-__device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const float (&m)[9], int qi, int qj, bool valid, int j0, int ib,
-                                             bool tab_x, const float* s_u, const float* s_v, int* s_acc, bool finite, float scale, int cbase,
-                                             int cc, const T* src_b, const T* const (&gout_c)[KMT_CC], size_t src_plane, int X0, int TWc, int Y0,
-                                             int THc, float (&gm)[9], uint32_t& seen_bits) {
+// Column / row halves of the coordinate numerators, tabulated once per block so that a pixel needs adds only.
+// The products are the very ones km_gen_coord forms (m0*u, m1*v, ...), so the sums round identically.
+template <int CM>
+__device__ __forceinline__ float4 kmt_col_entry(const float (&m)[9], float u) {
+    return make_float4(m[0] * u, m[3] * u, m[6] * u, 0.f);  // homography mode: u*m0 - multiplication commutes bit for bit
+}
+template <int CM>
+__device__ __forceinline__ float4 kmt_row_entry(const float (&m)[9], float v) {
+    if (CM == KM_COORD_HOMOGRAPHY) return make_float4(v, 0.f, 0.f, 0.f);  // fma(v, m1, u*m0) needs v itself
+    return make_float4(m[1] * v, m[4] * v, m[7] * v, 0.f);
+}
+// normalised sampling coordinate of one pixel: same rounding sequence as km_gen_coord (km_sampler.h)
+template <int CM>
+__device__ __forceinline__ void kmt_coord(const float (&m)[9], const float4 cu, const float4 rv, float& gx, float& gy) {
+    if (CM == KM_COORD_PERSPECTIVE) {
+        const float den = (cu.z + rv.z) + m[8];
+        gx = ((cu.x + rv.x) + m[2]) / den;
+        gy = ((cu.y + rv.y) + m[5]) / den;
+    } else if (CM == KM_COORD_AFFINE) {
+        gx = (cu.x + rv.x) + m[2];
+        gy = (cu.y + rv.y) + m[5];
+    } else {
+        const float v = rv.x;
+        const float X = km_fma(v, m[1], cu.x) + m[2];
+        const float Y = km_fma(v, m[4], cu.y) + m[5];
+        const float Z = km_fma(v, m[7], cu.z) + m[8];
+        const float eps = 1e-8f;
+        const float s = (km_fabs(Z) > eps) ? 1.0f / (Z + eps) : 1.0f;
+        gx = s * X;
+        gy = s * Y;
+    }
+}
+
+// one output pixel of the scatter pass.  Branch-free up to the (exec-masked) atomics: every load is unconditional
+// so that the loads of the pixels processed back to back can be in flight together.
+template <typename T, int CM>
+__device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const float (&m)[9], int qi, int qj, bool valid, int j0, int ib,
+                                             bool tab_x, const float4* s_u4, const float4* s_v4, int* s_acc, bool finite, float scale,
+                                             int cc, const T* const (&gout_c)[KMT_CC], int X0, int TWc, int Y0, int THc, uint32_t& seen_bits) {
     typedef float R;
-    const KmWarpGeom<R>& g = a.g;
     const int jj = j0 + qj, ii = ib + qi;
-    const uint32_t off = (uint32_t)ii * (uint32_t)g.w + (uint32_t)jj;  // host guarantees h * w < 2^31
+    const uint32_t off = (uint32_t)ii * (uint32_t)g.w + (uint32_t)jj;  // the host guarantees 4 * h * w < 2^32
     R go[KMT_CC];
 #pragma unroll
-    for (int c = 0; c < KMT_CC; ++c) go[c] = (R)km_ld(gout_c[c] + off);  // channels >= cc alias channel cc-1 (never used)
+    for (int c = 0; c < KMT_CC; ++c) go[c] = (R)km_ld(km_at(gout_c[c], off));  // channels >= cc alias channel cc-1 (never used)
     // the fixed-point scale was chosen for |grad_out| <= bound: remember the largest magnitude seen, as an integer
     // (sign cleared, IEEE bit patterns order like unsigned integers and NaN / inf sort above every finite value)
     {
@@ -264,11 +285,12 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const
         for (int c = 1; c < KMT_CC; ++c) mb = max(mb, __float_as_uint(go[c]) & 0x7fffffffu);
         seen_bits = max(seen_bits, mb);
     }
-    KmCoord<R> cd;
-    km_gen_coord<R, CM>(m, tab_x ? s_u[qj] : km_base_x<R, CM>(g, jj), s_v[qi], cd);
+    const float4 cu = tab_x ? s_u4[qj] : kmt_col_entry<CM>(m, km_base_x<R, CM>(g, jj));
+    R gx, gy;
+    kmt_coord<CM>(m, cu, s_v4[qi], gx, gy);
     R mx, my;
-    const R x = km_unnormalize(cd.gx, g.W, g.align, mx);
-    const R y = km_unnormalize(cd.gy, g.H, g.align, my);
+    const R x = km_unnormalize(gx, g.W, g.align, mx);
+    const R y = km_unnormalize(gy, g.H, g.align, my);
     // weights: the forward's own expressions ((x0 + 1) - x, x - x0), so grad_src = W^T grad_out for the very W it applied
     const R xf = km_floor(x), yf = km_floor(y);
     const R wx0 = x - xf, wx1 = (xf + 1) - x, wy0 = y - yf, wy1 = (yf + 1) - y;
@@ -280,90 +302,45 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const
     const bool in_y0 = (uint32_t)uy < (uint32_t)THc, in_y1 = (uint32_t)(uy + 1) < (uint32_t)THc;
     const bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;
     const int l00 = uy * KMT_TW + ux;
-    struct { R w00, w01, w10, w11; } t;
-    t.w00 = wx1 * wy1; t.w01 = wx0 * wy1; t.w10 = wx1 * wy0; t.w11 = wx0 * wy0;
     // tap-outer order: one exec-mask region per tap (4 per pixel) instead of one per atomic (4 * C)
     if (finite) {
-        const R w00 = t.w00 * scale, w01 = t.w01 * scale, w10 = t.w10 * scale, w11 = t.w11 * scale;
+        // scale = 2^k: (wx * wy) * scale == wx * (wy * scale) bit for bit
+        const R wy0s = wy0 * scale, wy1s = wy1 * scale;
+        const R w00 = wx1 * wy1s, w01 = wx0 * wy1s, w10 = wx1 * wy0s, w11 = wx0 * wy0s;
         int* accp = s_acc + l00;
         if (t00) {
 #pragma unroll
             for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW), kmt_quant(w00 * go[c]));
+                if (c < cc) atomicAdd(accp + c * KMT_PLANE, kmt_quant(w00 * go[c]));
         }
         if (t01) {
 #pragma unroll
             for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW) + 1, kmt_quant(w01 * go[c]));
+                if (c < cc) atomicAdd(accp + c * KMT_PLANE + 1, kmt_quant(w01 * go[c]));
         }
         if (t10) {
 #pragma unroll
             for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW, kmt_quant(w10 * go[c]));
+                if (c < cc) atomicAdd(accp + c * KMT_PLANE + KMT_TW, kmt_quant(w10 * go[c]));
         }
         if (t11) {
 #pragma unroll
             for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW + 1, kmt_quant(w11 * go[c]));
+                if (c < cc) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, kmt_quant(w11 * go[c]));
         }
     } else {
         // inf / NaN in grad_out, vanishing-line tiles, extreme magnification: float LDS atomics
+        const R w00 = wx1 * wy1, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx0 * wy0;
         float* accp = (float*)s_acc + l00;
 #pragma unroll
         for (int c = 0; c < KMT_CC; ++c) {
             if (c < cc) {
-                if (t00) atomicAdd(accp + c * (KMT_TH * KMT_TW), t.w00 * go[c]);
-                if (t01) atomicAdd(accp + c * (KMT_TH * KMT_TW) + 1, t.w01 * go[c]);
-                if (t10) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW, t.w10 * go[c]);
-                if (t11) atomicAdd(accp + c * (KMT_TH * KMT_TW) + KMT_TW + 1, t.w11 * go[c]);
+                if (t00) atomicAdd(accp + c * KMT_PLANE, w00 * go[c]);
+                if (t01) atomicAdd(accp + c * KMT_PLANE + 1, w01 * go[c]);
+                if (t10) atomicAdd(accp + c * KMT_PLANE + KMT_TW, w10 * go[c]);
+                if (t11) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, w11 * go[c]);
             }
         }
-    }
-    if (WANT_GM) {
-        // the tile holding the clamped north-west tap owns q's matrix gradient
-        const bool live = valid && (x >= (R)-1) && (x < (R)g.W) && (y >= (R)-1) && (y < (R)g.H);  // has an in-image tap
-        KmBilin<R> tb;
-        km_bilinear_setup(x, y, g.W, g.H, tb);
-        const int x0 = (int)fmaxf(fminf(xf, (R)g.W), (R)-1), y0 = (int)fmaxf(fminf(yf, (R)g.H), (R)-1);
-        const int ox = min(max(x0, 0), g.W - 1) - X0, oy = min(max(y0, 0), g.H - 1) - Y0;
-        const bool own = live && ((uint32_t)ox < (uint32_t)TWc) && ((uint32_t)oy < (uint32_t)THc);
-        R gix = 0, giy = 0;
-        if (own) {  // measured: skipping the tap loads of non-owned pixels beats batching them (1.56 -> 1.50 ms)
-            // d/dx = (ne - nw)(y1 - y) + (se - sw)(y - y0) ; d/dy = (sw - nw)(x1 - x) + (se - ne)(x - x0)
-            if (__all(tb.b00 && tb.b01 && tb.b10 && tb.b11)) {
-                // every owner lane of the wave samples inside the image: (x0, x0 + 1) come with one load per row
-#pragma unroll
-                for (int c = 0; c < KMT_CC; ++c) {
-                    if (c < cc) {
-                        const T* img = src_b + (size_t)(cbase + c) * src_plane;
-                        R s00, s01, s10, s11;
-                        km_ld2(img + tb.i00, s00, s01);
-                        km_ld2(img + tb.i10, s10, s11);
-                        if (g.pad == KM_PAD_FILL) {  // same rounding sequence as the oracle: (v - fill) first
-                            const R f = a.fill[cbase + c];
-                            s00 -= f; s01 -= f; s10 -= f; s11 -= f;
-                        }
-                        gix += go[c] * ((s01 - s00) * tb.wy1 + (s11 - s10) * tb.wy0);
-                        giy += go[c] * ((s10 - s00) * tb.wx1 + (s11 - s01) * tb.wx0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < KMT_CC; ++c) {
-                    if (c < cc) {
-                        const T* img = src_b + (size_t)(cbase + c) * src_plane;
-                        const R f = (g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : (R)0;
-                        // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
-                        const R v00 = (R)km_ld(img + tb.i00), v01 = (R)km_ld(img + tb.i01), v10 = (R)km_ld(img + tb.i10), v11 = (R)km_ld(img + tb.i11);
-                        const R s00 = tb.b00 ? v00 - f : (R)0, s01 = tb.b01 ? v01 - f : (R)0;
-                        const R s10 = tb.b10 ? v10 - f : (R)0, s11 = tb.b11 ? v11 - f : (R)0;
-                        gix += go[c] * ((s01 - s00) * tb.wy1 + (s11 - s10) * tb.wy0);
-                        giy += go[c] * ((s10 - s00) * tb.wx1 + (s11 - s01) * tb.wx0);
-                    }
-                }
-            }
-        }
-        if (own) km_accumulate_gm<CM>(gm, cd, gix * mx, giy * my);
     }
 }
 
@@ -375,22 +352,20 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpTiledArgs<T>& a, const
 // so the per-tap contributions w * grad_out are accumulated as int32 fixed point: the block first finds
 // M = max |grad_out| over the output pixels it will visit, picks scale = 2^k with
 // k = 30 - hb - ceil(log2 M) (hb = head-room bits for the number of taps that can land on one source pixel,
-// from the Jacobian bound), and adds rint(w * g * scale) with ds_add_u32.  Per-term error <= 2^-(k+1),
+// from the Jacobian bound), and adds floor(w * g * scale + 0.5) with ds_add_u32.  Per-term error <= 2^-(k+1),
 // i.e. <= M * 2^-(27-hb): the same order as one fp32 ulp of M.  Integer addition is associative, so the
 // result is independent of the order in which waves run: bit-reproducible, unlike float atomics.
-// measured on MI355X (256x3x512^2), speculative-scale version: min-waves 4 -> 1.32 ms, 5 -> 1.38 ms (14 spills), 6 -> 2.00 ms
 #ifndef KMT_MIN_WAVES
-#define KMT_MIN_WAVES 4
+#define KMT_MIN_WAVES 6
 #endif
 #ifndef KMT_UNROLL
 #define KMT_UNROLL 2
 #endif
-template <typename T, int CM, bool WANT_GM>
-__global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
+template <typename T, int CM>
+__global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
     typedef float R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ double red[4][9];
-    __shared__ float red_max[4];
+    __shared__ float red_max[KMT_NW];
     __shared__ int s_box[8];
 
     const KmWarpGeom<R>& g = a.g;
@@ -402,6 +377,7 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = (int)tx * KMT_TW, Y0 = (int)ty * KMT_TH;
     const int X1 = min(X0 + KMT_TW, g.W), Y1 = min(Y0 + KMT_TH, g.H);  // tile = [X0,X1) x [Y0,Y1)
+    const int TWc = X1 - X0, THc = Y1 - Y0;
 
     R m[9];
     {
@@ -410,8 +386,8 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
         for (int k = 0; k < 9; ++k) m[k] = mp[k];
     }
 
-    // ---- box of output pixels that can touch the tile: computed by wave 0 only (it is ~300 block-uniform
-    //      VALU instructions, ~15 % of a block's work if all four waves repeat it), broadcast through LDS
+    // ---- box of output pixels that can touch the tile: computed by wave 0 only (it is ~400 block-uniform
+    //      VALU instructions, ~15 % of a block's work if every wave repeats it), broadcast through LDS
     if (wave == 0) {
         const KmtBox bx = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
         if (lane == 0) {
@@ -429,24 +405,26 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
     const float inv_bw = kmt_uniform(bw > 0 ? 1.0f / (float)bw : 0.f);
 
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
-    const T* src_b = a.src + (size_t)b * g.C * src_plane;
     const T* gout_b = a.gout + (size_t)b * g.C * dst_plane;
     R* gsrc_b = a.gsrc + (size_t)b * g.C * src_plane;
 
-    // LDS carve: base-coordinate tables, then the int32 accumulators [cc][TH][TW]
-    float* s_u = (float*)smem_raw;  // [KMT_TAB]
-    float* s_v = s_u + KMT_TAB;      // [KMT_TAB]
-    int* s_acc = (int*)(s_v + KMT_TAB);
+    // LDS carve: coordinate tables, then the int32 accumulators [cc][TH][TW]
+    float4* s_u4 = (float4*)smem_raw;   // [KMT_TAB] per column of the box
+    float4* s_v4 = s_u4 + KMT_TAB;      // [KMT_TAB] per row of the current band
+    int* s_acc = (int*)(s_v4 + KMT_TAB);
     const bool tab_x = bw <= KMT_TAB;
 
     for (int cbase = 0; cbase < g.C; cbase += KMT_CC) {
         const int cc = min(KMT_CC, g.C - cbase);
-        for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0;
-        if (tab_x && tid < bw) s_u[tid] = km_base_x<R, CM>(g, j0 + tid);
+        for (int e = tid; e < cc * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);
+        if (tab_x && tid < bw) s_u4[tid] = kmt_col_entry<CM>(m, km_base_x<R, CM>(g, j0 + tid));
+        const T* gout_c[KMT_CC];
+#pragma unroll
+        for (int c = 0; c < KMT_CC; ++c) gout_c[c] = gout_b + (size_t)(cbase + min(c, cc - 1)) * dst_plane;
 
         // The scale needs an upper bound M on |grad_out| over the box.  Reading the whole box twice costs ~0.3 ms
-        // at 256x3x512^2, so attempt 0 SPECULATES: M = 8 x (max over a 256-pixel sample of the box); pass B
-        // checks every value it loads against M, and only a tile that sees a larger one (or a NaN/inf) is redone
+        // at 256x3x512^2, so attempt 0 SPECULATES: M = 8 x (max over a KMT_NT-pixel sample of the box); the scatter
+        // pass tracks the largest magnitude it loads, and only a tile that sees a larger one (or a NaN/inf) is redone
         // with the exact maximum (attempt 1).  The guard factor costs 3 bits of the fixed-point resolution.
         R scale = 1.f, inv_scale = 1.f;
         bool finite = false;
@@ -456,30 +434,29 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
             if (!empty) {
                 const int nq = bw * bh;
                 if (attempt == 0) {
-                    const int e = (int)(((long long)tid * nq) >> 8);  // 256 pixels spread over the box
+                    const int e = (int)(((long long)tid * nq) / KMT_NT);  // KMT_NT pixels spread over the box
                     int qi = (int)(((float)e + 0.5f) * inv_bw);
                     int qj = e - qi * bw;
                     if (qj < 0) { qi -= 1; qj += bw; }
                     if (qj >= bw) { qi += 1; qj -= bw; }
-                    const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
+                    const uint32_t off = (uint32_t)(i0 + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);
 #pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c)
-                        if (c < cc) vmax = fmaxf(vmax, km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane)));
+                    for (int c = 0; c < KMT_CC; ++c) vmax = fmaxf(vmax, km_fabs((R)km_ld(km_at(gout_c[c], off))));
                     vmax = vmax * 8.0f;
                     bad = !(vmax <= 3.0e38f);
                 } else {
-                    for (int base = 0; base < nq; base += 4 * 256) {
+                    for (int base = 0; base < nq; base += 4 * KMT_NT) {
                         R vv[4][KMT_CC];
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
-                            const int e = min(base + s4 * 256 + tid, nq - 1);  // clamped: duplicates do not change a max
+                            const int e = min(base + s4 * KMT_NT + tid, nq - 1);  // clamped: duplicates do not change a max
                             int qi = (int)(((float)e + 0.5f) * inv_bw);
                             int qj = e - qi * bw;
                             if (qj < 0) { qi -= 1; qj += bw; }
                             if (qj >= bw) { qi += 1; qj -= bw; }
-                            const T* go_px = gout_b + (size_t)(i0 + qi) * g.w + (j0 + qj);
+                            const uint32_t off = (uint32_t)(i0 + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);
 #pragma unroll
-                            for (int c = 0; c < KMT_CC; ++c) vv[s4][c] = (c < cc) ? km_fabs((R)km_ld(go_px + (size_t)(cbase + c) * dst_plane)) : (R)0;
+                            for (int c = 0; c < KMT_CC; ++c) vv[s4][c] = km_fabs((R)km_ld(km_at(gout_c[c], off)));
                         }
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4)
@@ -497,7 +474,9 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
             __syncthreads();  // red_max may still be read by a previous attempt / channel chunk
             if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vmax;
             __syncthreads();
-            const R M = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+            R M = red_max[0];
+#pragma unroll
+            for (int k = 1; k < KMT_NW; ++k) M = fmaxf(M, red_max[k]);
             // scale = 2^k with |w * g * scale| * (taps per pixel) < 2^30
             finite = (M <= 3.0e38f) && fixed_ok;  // else: IEEE float accumulation (slow ds_add_f32)
             int kexp = 0;
@@ -511,37 +490,30 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
             inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
             const R bound = finite ? M : __int_as_float(0x7f800000);  // the float path accepts anything
 
-            // ---- pass B: scatter ----
-            R gm_try[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) gm_try[k] = 0;
+            // ---- scatter pass ----
             uint32_t seen_bits = 0;  // largest |grad_out| bit pattern this thread has loaded
             if (!empty) {
-                const T* gout_c[KMT_CC];
-#pragma unroll
-                for (int c = 0; c < KMT_CC; ++c) gout_c[c] = gout_b + (size_t)(cbase + min(c, cc - 1)) * dst_plane;
-                const int di = kmt_uniform(256 / bw), dj = kmt_uniform(256 % bw);  // element e + 256 is di rows and dj columns on
-                const int TWc = X1 - X0, THc = Y1 - Y0;
+                const int di = kmt_uniform(KMT_NT / bw), dj = kmt_uniform(KMT_NT % bw);  // element e + KMT_NT is di rows, dj columns on
                 for (int ib = i0; ib <= i1; ib += KMT_TAB) {
                     const int ie = min(i1, ib + KMT_TAB - 1);
                     __syncthreads();
-                    if (tid <= ie - ib) s_v[tid] = km_base_y<R, CM>(g, ib + tid);
+                    if (tid <= ie - ib) s_v4[tid] = kmt_row_entry<CM>(m, km_base_y<R, CM>(g, ib + tid));
                     __syncthreads();
                     const int nq = bw * (ie - ib + 1);
                     int qi = tid / bw, qj = tid - qi * bw;  // element e = base + tid
                     int base = 0;
-                    for (; base + KMT_UNROLL * 256 <= nq; base += KMT_UNROLL * 256) {
+                    for (; base + KMT_UNROLL * KMT_NT <= nq; base += KMT_UNROLL * KMT_NT) {
 #pragma unroll
                         for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {
-                            kmt_scatter_q<T, CM, WANT_GM>(a, m, qi, qj, true, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale, cbase, cc, src_b,
-                                                          gout_c, src_plane, X0, TWc, Y0, THc, gm_try, seen_bits);
+                            kmt_scatter_q<T, CM>(g, m, qi, qj, true, j0, ib, tab_x, s_u4, s_v4, s_acc, finite, scale, cc, gout_c, X0, TWc, Y0, THc,
+                                                 seen_bits);
                             kmt_advance(qi, qj, di, dj, bw);
                         }
                     }
-                    for (; base < nq; base += 256) {
+                    for (; base < nq; base += KMT_NT) {
                         const bool valid = base + tid < nq;
-                        kmt_scatter_q<T, CM, WANT_GM>(a, m, valid ? qi : 0, valid ? qj : 0, valid, j0, ib, tab_x, s_u, s_v, s_acc, finite, scale,
-                                                      cbase, cc, src_b, gout_c, src_plane, X0, TWc, Y0, THc, gm_try, seen_bits);
+                        kmt_scatter_q<T, CM>(g, m, valid ? qi : 0, valid ? qj : 0, valid, j0, ib, tab_x, s_u4, s_v4, s_acc, finite, scale, cc, gout_c,
+                                             X0, TWc, Y0, THc, seen_bits);
                         kmt_advance(qi, qj, di, dj, bw);
                     }
                 }
@@ -550,57 +522,47 @@ __global__ __launch_bounds__(256, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(c
             const bool exceeded = seen_bits > __float_as_uint(bound);
             const int redo = __syncthreads_or((int)exceeded);
             if (attempt == 0 && redo) {
-                for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) s_acc[e] = 0;  // discard the speculative attempt
+                for (int e = tid; e < cc * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);  // discard the attempt
                 continue;  // the barrier at the top of attempt 1 orders these stores before the next atomics
-            }
-            if (WANT_GM) {
-                // accepted attempt: fold this chunk's matrix gradient into the global fp64 accumulators
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const double sgm = km_wave_sum((double)gm_try[k]);
-                    if (lane == 0) red[wave][k] = sgm;
-                }
-                __syncthreads();
-                if (tid < 9) {
-                    const double sgm = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-                    if (sgm != 0.0) km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + tid, sgm);
-                }
             }
             break;
         }
 
-        // ---- convert and write the tile: rows of 64 floats, fully coalesced ----
-        for (int e = tid; e < cc * KMT_TH * KMT_TW; e += 256) {
-            const int c = e / (KMT_TH * KMT_TW), r = (e / KMT_TW) % KMT_TH, col = e % KMT_TW;
-            const int yy = Y0 + r, xx = X0 + col;
-            if (yy < g.H && xx < g.W) {
-                const R val = finite ? (R)s_acc[e] * inv_scale : ((const float*)s_acc)[e];
-                gsrc_b[(size_t)(cbase + c) * src_plane + (size_t)yy * g.W + xx] = val;
+        // ---- convert and write the tile: lane -> column, waves -> rows: rows of 64 floats, fully coalesced ----
+        {
+            const int col = tid & (KMT_TW - 1), row0 = tid >> 6;
+            if (col < TWc) {
+#pragma unroll
+                for (int c = 0; c < KMT_CC; ++c) {
+                    if (c < cc) {
+                        R* outp = gsrc_b + (size_t)(cbase + c) * src_plane + (size_t)(Y0 + row0) * g.W + (X0 + col);
+                        const int* accp = s_acc + c * KMT_PLANE + row0 * KMT_TW + col;
+                        const size_t ostep = (size_t)KMT_NW * g.W;
+#pragma unroll 4
+                        for (int r = row0; r < THc; r += KMT_NW) {
+                            *outp = finite ? (R)(*accp) * inv_scale : *(const float*)accp;
+                            outp += ostep;
+                            accp += KMT_NW * KMT_TW;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
     }
-
 }
 
 template <typename T, int CM>
 static int kmt_launch(const KmWarpTiledArgs<T>& a, hipStream_t s) {
-    if (a.gmat)
-        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, true>), dim3(a.nblocks), dim3(256), (size_t)a.lds_bytes, s, a);
-    else
-        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, false>), dim3(a.nblocks), dim3(256), (size_t)a.lds_bytes, s, a);
+    hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
     return km_check_launch("km_warp2d_bwd(tiled)");
 }
 
 template <typename T>
-static int kmt_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H, int W, int h,
-                   int w, int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, hipStream_t s) {
+static int kmt_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode,
+                   int norm_coords, int pad, int align, hipStream_t s) {
     KmWarpTiledArgs<T> a;
-    a.src = (const T*)src; a.gout = (const T*)gout; a.mat = (const float*)mat; a.gsrc = (float*)gsrc; a.gmat = gmat;
-    a.fill = (const float*)fill;
-    {
-        a.lds_bytes = KMT_LDS_BYTES;
-    }
+    a.gout = (const T*)gout; a.mat = (const float*)mat; a.gsrc = (float*)gsrc;
     KmWarpGeom<float>& g = a.g;
     g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
     g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = KM_INTERP_BILINEAR; g.pad = pad; g.align = align;
@@ -625,7 +587,7 @@ static int kmt_run(const void* gout, const void* src, const void* mat, void* gsr
     }
 }
 
-// 1 if the tiled backward applies (bilinear, zeros/fill padding, fp32 compute, grad_src wanted)
+// 1 if the tile-owner kernel computes grad_src for these modes (bilinear, zeros/fill padding, fp32 compute)
 int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc) {
     static int disabled = -1;
     if (disabled < 0) {
@@ -636,12 +598,15 @@ int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc
     return (interp == KM_INTERP_BILINEAR && (pad == KM_PAD_ZEROS || pad == KM_PAD_FILL) && dtype != KM_F64 && gsrc != nullptr) ? 1 : 0;
 }
 
-int km_warp_bwd_tiled_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H, int W,
-                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype,
-                          hipStream_t s) {
+// 32-bit byte offsets inside a grad_out plane (the caller falls back to the generic kernel otherwise)
+int km_warp_bwd_tiled_dims_ok(int h, int w) { return ((uint64_t)h * (uint64_t)w * 4 < (1ull << 32)) ? 1 : 0; }
+
+// grad_src only; pad (zeros / fill) does not change it
+int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode,
+                          int norm_coords, int pad, int align, int dtype, hipStream_t s) {
     switch (dtype) {
-        case KM_F32: return kmt_run<float>(gout, src, mat, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
-        case KM_BF16: return kmt_run<km_bf16>(gout, src, mat, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
-        default: return kmt_run<km_f16>(gout, src, mat, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+        case KM_F32: return kmt_run<float>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        case KM_BF16: return kmt_run<km_bf16>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        default: return kmt_run<km_f16>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
     }
 }
