@@ -237,26 +237,25 @@ __device__ __forceinline__ void km_bilinear_setup(R x, R y, int W, int H, KmBili
     t.i11 = y1 * W + x1;
 }
 
-// matrix-gradient contribution of one output pixel
+// matrix-gradient contribution of one output pixel: with r = (u, v, 1) the pixel adds
+//   d/dm0k += ax r_k ,  d/dm1k += ay r_k ,  d/dm2k += az r_k
+// for the (ax, ay, az) returned here (gix, giy = d loss / d (x, y) already scaled to normalised coordinates)
 template <int CM>
-__device__ __forceinline__ void km_accumulate_gm(float (&gm)[9], const KmCoord<float>& cd, float gix, float giy) {
+__device__ __forceinline__ void km_gm_terms(const KmCoord<float>& cd, float gix, float giy, float& ax, float& ay, float& az) {
     typedef float R;
     if (CM == KM_COORD_PERSPECTIVE) {
         const R inv = __frcp_rn(cd.den);
-        const R ax = gix * inv, ay = giy * inv;
-        const R az = -(gix * cd.gx + giy * cd.gy) * inv;
-        gm[0] += ax * cd.u; gm[1] += ax * cd.v; gm[2] += ax;
-        gm[3] += ay * cd.u; gm[4] += ay * cd.v; gm[5] += ay;
-        gm[6] += az * cd.u; gm[7] += az * cd.v; gm[8] += az;
+        ax = gix * inv;
+        ay = giy * inv;
+        az = -km_fma(gix, cd.gx, giy * cd.gy) * inv;
     } else if (CM == KM_COORD_AFFINE) {
-        gm[0] += gix * cd.u; gm[1] += gix * cd.v; gm[2] += gix;
-        gm[3] += giy * cd.u; gm[4] += giy * cd.v; gm[5] += giy;
+        ax = gix;
+        ay = giy;
+        az = 0;
     } else {
         const R s = cd.den;
-        const R ax = gix * s, ay = giy * s;
-        const R az = cd.live ? -(gix * cd.X + giy * cd.Y) * s * s : (R)0;
-        gm[0] += ax * cd.u; gm[1] += ax * cd.v; gm[2] += ax;
-        gm[3] += ay * cd.u; gm[4] += ay * cd.v; gm[5] += ay;
-        gm[6] += az * cd.u; gm[7] += az * cd.v; gm[8] += az;
+        ax = gix * s;
+        ay = giy * s;
+        az = cd.live ? -km_fma(gix, cd.X, giy * cd.Y) * s * s : (R)0;
     }
 }

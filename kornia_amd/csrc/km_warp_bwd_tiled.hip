@@ -267,9 +267,9 @@ __device__ __forceinline__ void kmt_coord(const float (&m)[9], const float4 cu, 
 
 // one output pixel of the scatter pass.  Branch-free up to the (exec-masked) atomics: every load is unconditional
 // so that the loads of the pixels processed back to back can be in flight together.
-template <typename T, int CM>
+template <typename T, int CM, int ALIGN>
 __device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const float (&m)[9], int qi, int qj, bool valid, int j0, int ib,
-                                             bool tab_x, const float4* s_u4, const float4* s_v4, int* s_acc, bool finite, float scale,
+                                             const float4* s_u4, const float4* s_v4, int* s_acc, bool finite, float scale,
                                              int cc, const T* const (&gout_c)[KMT_CC], int X0, int TWc, int Y0, int THc, uint32_t& seen_bits) {
     typedef float R;
     const int jj = j0 + qj, ii = ib + qi;
@@ -285,19 +285,19 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const 
         for (int c = 1; c < KMT_CC; ++c) mb = max(mb, __float_as_uint(go[c]) & 0x7fffffffu);
         seen_bits = max(seen_bits, mb);
     }
-    const float4 cu = tab_x ? s_u4[qj] : kmt_col_entry<CM>(m, km_base_x<R, CM>(g, jj));
     R gx, gy;
-    kmt_coord<CM>(m, cu, s_v4[qi], gx, gy);
+    kmt_coord<CM>(m, s_u4[qj], s_v4[qi], gx, gy);
     R mx, my;
-    const R x = km_unnormalize(gx, g.W, g.align, mx);
-    const R y = km_unnormalize(gy, g.H, g.align, my);
+    const R x = km_unnormalize(gx, g.W, ALIGN, mx);
+    const R y = km_unnormalize(gy, g.H, ALIGN, my);
     // weights: the forward's own expressions ((x0 + 1) - x, x - x0), so grad_src = W^T grad_out for the very W it applied
     const R xf = km_floor(x), yf = km_floor(y);
     const R wx0 = x - xf, wx1 = (xf + 1) - x, wy0 = y - yf, wy1 = (yf + 1) - y;
     // tile-relative tap position.  A tap inside the tile is inside the image, so the in-tile test is the whole
     // predicate; clamping in float first sends NaN / huge coordinates (and the padding lanes) outside the tile
-    const int ux = (int)fmaxf(fminf(xf, (R)g.W), (R)-2) - X0;
-    const int uy = valid ? (int)fmaxf(fminf(yf, (R)g.H), (R)-2) - Y0 : (1 << 20);
+    // (v_med3_f32 returns the smallest operand when one is NaN: -2, outside every tile)
+    const int ux = (int)__builtin_amdgcn_fmed3f(xf, (R)-2, (R)g.W) - X0;
+    const int uy = valid ? (int)__builtin_amdgcn_fmed3f(yf, (R)-2, (R)g.H) - Y0 : (1 << 20);
     const bool in_x0 = (uint32_t)ux < (uint32_t)TWc, in_x1 = (uint32_t)(ux + 1) < (uint32_t)TWc;
     const bool in_y0 = (uint32_t)uy < (uint32_t)THc, in_y1 = (uint32_t)(uy + 1) < (uint32_t)THc;
     const bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;
@@ -361,7 +361,7 @@ __device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const 
 #ifndef KMT_UNROLL
 #define KMT_UNROLL 2
 #endif
-template <typename T, int CM>
+template <typename T, int CM, int ALIGN>
 __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
     typedef float R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -412,12 +412,10 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
     float4* s_u4 = (float4*)smem_raw;   // [KMT_TAB] per column of the box
     float4* s_v4 = s_u4 + KMT_TAB;      // [KMT_TAB] per row of the current band
     int* s_acc = (int*)(s_v4 + KMT_TAB);
-    const bool tab_x = bw <= KMT_TAB;
 
     for (int cbase = 0; cbase < g.C; cbase += KMT_CC) {
         const int cc = min(KMT_CC, g.C - cbase);
         for (int e = tid; e < cc * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);
-        if (tab_x && tid < bw) s_u4[tid] = kmt_col_entry<CM>(m, km_base_x<R, CM>(g, j0 + tid));
         const T* gout_c[KMT_CC];
 #pragma unroll
         for (int c = 0; c < KMT_CC; ++c) gout_c[c] = gout_b + (size_t)(cbase + min(c, cc - 1)) * dst_plane;
@@ -493,28 +491,34 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
             // ---- scatter pass ----
             uint32_t seen_bits = 0;  // largest |grad_out| bit pattern this thread has loaded
             if (!empty) {
-                const int di = kmt_uniform(KMT_NT / bw), dj = kmt_uniform(KMT_NT % bw);  // element e + KMT_NT is di rows, dj columns on
-                for (int ib = i0; ib <= i1; ib += KMT_TAB) {
-                    const int ie = min(i1, ib + KMT_TAB - 1);
-                    __syncthreads();
-                    if (tid <= ie - ib) s_v4[tid] = kmt_row_entry<CM>(m, km_base_y<R, CM>(g, ib + tid));
-                    __syncthreads();
-                    const int nq = bw * (ie - ib + 1);
-                    int qi = tid / bw, qj = tid - qi * bw;  // element e = base + tid
-                    int base = 0;
-                    for (; base + KMT_UNROLL * KMT_NT <= nq; base += KMT_UNROLL * KMT_NT) {
+                // the box is walked in bands of at most KMT_TAB columns x KMT_TAB rows (one band for any warp that does
+                // not shrink the image by more than 2x), whose coordinate halves sit in the LDS tables
+                for (int jb = j0; jb <= j1; jb += KMT_TAB) {
+                    const int bwb = min(KMT_TAB, j1 - jb + 1);
+                    const int di = kmt_uniform(KMT_NT / bwb), dj = kmt_uniform(KMT_NT % bwb);  // element e + KMT_NT is di rows, dj columns on
+                    for (int ib = i0; ib <= i1; ib += KMT_TAB) {
+                        const int ie = min(i1, ib + KMT_TAB - 1);
+                        __syncthreads();
+                        if (tid < bwb && (ib == i0)) s_u4[tid] = kmt_col_entry<CM>(m, km_base_x<R, CM>(g, jb + tid));
+                        if (tid <= ie - ib) s_v4[tid] = kmt_row_entry<CM>(m, km_base_y<R, CM>(g, ib + tid));
+                        __syncthreads();
+                        const int nq = bwb * (ie - ib + 1);
+                        int qi = tid / bwb, qj = tid - qi * bwb;  // element e = base + tid
+                        int base = 0;
+                        for (; base + KMT_UNROLL * KMT_NT <= nq; base += KMT_UNROLL * KMT_NT) {
 #pragma unroll
-                        for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {
-                            kmt_scatter_q<T, CM>(g, m, qi, qj, true, j0, ib, tab_x, s_u4, s_v4, s_acc, finite, scale, cc, gout_c, X0, TWc, Y0, THc,
-                                                 seen_bits);
-                            kmt_advance(qi, qj, di, dj, bw);
+                            for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {
+                                kmt_scatter_q<T, CM, ALIGN>(g, m, qi, qj, true, jb, ib, s_u4, s_v4, s_acc, finite, scale, cc, gout_c, X0, TWc, Y0, THc,
+                                                            seen_bits);
+                                kmt_advance(qi, qj, di, dj, bwb);
+                            }
                         }
-                    }
-                    for (; base < nq; base += KMT_NT) {
-                        const bool valid = base + tid < nq;
-                        kmt_scatter_q<T, CM>(g, m, valid ? qi : 0, valid ? qj : 0, valid, j0, ib, tab_x, s_u4, s_v4, s_acc, finite, scale, cc, gout_c,
-                                             X0, TWc, Y0, THc, seen_bits);
-                        kmt_advance(qi, qj, di, dj, bw);
+                        for (; base < nq; base += KMT_NT) {
+                            const bool valid = base + tid < nq;
+                            kmt_scatter_q<T, CM, ALIGN>(g, m, valid ? qi : 0, valid ? qj : 0, valid, jb, ib, s_u4, s_v4, s_acc, finite, scale, cc, gout_c,
+                                                        X0, TWc, Y0, THc, seen_bits);
+                            kmt_advance(qi, qj, di, dj, bwb);
+                        }
                     }
                 }
             }
@@ -554,7 +558,10 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
 
 template <typename T, int CM>
 static int kmt_launch(const KmWarpTiledArgs<T>& a, hipStream_t s) {
-    hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+    if (a.g.align)
+        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 1>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 0>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
     return km_check_launch("km_warp2d_bwd(tiled)");
 }
 

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
     const R u = km_base_x<R, CM>(g, col_ok ? j : 0);
     const bool is_fill = (g.pad == KM_PAD_FILL);
 
-    R gm[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) gm[k] = 0;
+    // u is fixed per thread (lane = column): accumulate S = sum(ax, ay, az) and Sv = sum(v * (ax, ay, az)) over the
+    // thread's rows and multiply by u once at the end
+    R S[3] = {0, 0, 0}, Sv[3] = {0, 0, 0};
 
 #pragma unroll 2
     for (int r = 0; r < KMG_ROWS; ++r) {
@@ -100,12 +100,12 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
                     b00 -= f1; b01 -= f1; b10 -= f1; b11 -= f1;
                     c00 -= f2; c01 -= f2; c10 -= f2; c11 -= f2;
                 }
-                gix += g0 * ((a01 - a00) * t.wy1 + (a11 - a10) * t.wy0);
-                giy += g0 * ((a10 - a00) * t.wx1 + (a11 - a01) * t.wx0);
-                gix += g1 * ((b01 - b00) * t.wy1 + (b11 - b10) * t.wy0);
-                giy += g1 * ((b10 - b00) * t.wx1 + (b11 - b01) * t.wx0);
-                gix += g2 * ((c01 - c00) * t.wy1 + (c11 - c10) * t.wy0);
-                giy += g2 * ((c10 - c00) * t.wx1 + (c11 - c01) * t.wx0);
+                gix = km_fma(g0, km_fma(a01 - a00, t.wy1, (a11 - a10) * t.wy0), gix);
+                giy = km_fma(g0, km_fma(a10 - a00, t.wx1, (a11 - a01) * t.wx0), giy);
+                gix = km_fma(g1, km_fma(b01 - b00, t.wy1, (b11 - b10) * t.wy0), gix);
+                giy = km_fma(g1, km_fma(b10 - b00, t.wx1, (b11 - b01) * t.wx0), giy);
+                gix = km_fma(g2, km_fma(c01 - c00, t.wy1, (c11 - c10) * t.wy0), gix);
+                giy = km_fma(g2, km_fma(c10 - c00, t.wx1, (c11 - c01) * t.wx0), giy);
             } else {
                 for (int c = 0; c < C; ++c) {
                     const R go = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off));
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
                         const R f = a.fill[c];
                         s00 -= f; s01 -= f; s10 -= f; s11 -= f;
                     }
-                    gix += go * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
-                    giy += go * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+                    gix = km_fma(go, km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
+                    giy = km_fma(go, km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
                 }
             }
         } else {
@@ -130,15 +130,26 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
                 const R v00 = (R)km_ld(img + t.i00), v01 = (R)km_ld(img + t.i01), v10 = (R)km_ld(img + t.i10), v11 = (R)km_ld(img + t.i11);
                 const R s00 = t.b00 ? v00 - f : (R)0, s01 = t.b01 ? v01 - f : (R)0;
                 const R s10 = t.b10 ? v10 - f : (R)0, s11 = t.b11 ? v11 - f : (R)0;
-                gix += go * ((s01 - s00) * t.wy1 + (s11 - s10) * t.wy0);
-                giy += go * ((s10 - s00) * t.wx1 + (s11 - s01) * t.wx0);
+                gix = km_fma(go, km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
+                giy = km_fma(go, km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
             }
         }
         // pixels outside the output (padding lanes / rows of the last tiles) contribute nothing
         gix = ok ? gix * mx : (R)0;
         giy = ok ? giy * my : (R)0;
-        km_accumulate_gm<CM>(gm, cd, gix, giy);
+        R ax, ay, az;
+        km_gm_terms<CM>(cd, gix, giy, ax, ay, az);
+        S[0] += ax; S[1] += ay; S[2] += az;
+        Sv[0] = km_fma(ax, cd.v, Sv[0]); Sv[1] = km_fma(ay, cd.v, Sv[1]); Sv[2] = km_fma(az, cd.v, Sv[2]);
     }
+    R gm[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gm[3 * k + 0] = S[k] * u;
+        gm[3 * k + 1] = Sv[k];
+        gm[3 * k + 2] = S[k];
+    }
+    if (CM == KM_COORD_AFFINE) gm[6] = gm[7] = gm[8] = 0;
 
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
