@@ -18,7 +18,9 @@
 
 #include "km_sampler.h"
 
-#define KMG_ROWS 8
+#ifndef KMG_ROWS
+#define KMG_ROWS 16
+#endif
 #define KMG_TILE_W 64
 #define KMG_TILE_H (4 * KMG_ROWS)
 
