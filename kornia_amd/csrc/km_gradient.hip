@@ -5,6 +5,8 @@
 // sqrt(gx*gx + gy*gy + eps)).  One launch computes every output channel from one set of taps
 // (9 or 25 loads served by L1) and, for sobel(), fuses the magnitude so the (B,C,2,H,W) stack is
 // never written.  fma chain in (p,q) order == oracle/ko_impl.h ko_spatial_gradient_fwd.
+#include <stdlib.h>
+
 #include "km_common.h"
 
 #define KM_SG_MAX_K 5
@@ -101,6 +103,153 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_bwd_kernel(const KmGr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Register-tiled forward for the shapes the reference produces (3x3 or 5x5 stacks, 2 or 3 outputs): the same
+// organisation as the separable blur (km_blur_fast.hip) - a lane owns 4 adjacent columns (one 16-byte load per
+// input row + PD clamped scalar halo loads per side, 16-byte stores), a wave walks a strip of rows keeping the last
+// KS input rows in registers.  Replicate border = clamped row / column addresses.  Each output keeps the
+// reference's fma chain in (p, q) order over the full stack (zero taps included: 0 * inf must stay NaN).
+// HBM traffic = read x once + write n_out (or 1 for the fused magnitude) planes = the algorithmic (1 + n_out) e.
+#define KM_SG_ROWS 32
+
+__device__ __forceinline__ void km_sg_ld4(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void km_sg_ld4(const km_bf16* p, float (&o)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void km_sg_ld4(const km_f16* p, float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
+}
+__device__ __forceinline__ void km_sg_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ void km_sg_st4(km_bf16* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
+    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void km_sg_st4(km_f16* p, const float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 v;
+    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    *reinterpret_cast<h4*>(p) = v;
+}
+
+template <typename T, int KS, int NOUT>
+__global__ __launch_bounds__(256) void km_spatial_gradient_reg_kernel(const KmGradArgs<T> a) {
+    constexpr int PD = KS / 2, NV = 4 + 2 * PD;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t tby = bid % a.tiles_y;
+    const uint32_t bc = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = (int)tbx * 64 + lane;                     // column group (4 px)
+    const int r0 = ((int)tby * 4 + wave) * KM_SG_ROWS;       // first output row of this wave's strip
+    const int H = a.H, W = a.W;
+    if (gx * 4 >= W || r0 >= H) return;
+    const int c0 = gx * 4;
+    const size_t plane = (size_t)H * W;
+    const T* img = a.x + (size_t)bc * plane;
+    // clamped halo columns (replicate border)
+    int hl[PD], hr[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+        hl[q] = max(c0 - PD + q, 0);
+        hr[q] = min(c0 + 4 + q, W - 1);
+    }
+    float k[NOUT][KS][KS];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int p = 0; p < KS; ++p)
+#pragma unroll
+            for (int q = 0; q < KS; ++q) k[o][p][q] = a.kern[(o * KS + p) * KS + q];
+
+    float ring[KS][NV];  // last KS input rows: ring[.][i] = column c0 - PD + i
+    const int n_rows = (r0 + KM_SG_ROWS <= H ? KM_SG_ROWS : H - r0);
+    const int total = n_rows + KS - 1;
+    for (int it0 = 0; it0 < total; it0 += KS) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int it = it0 + kk;
+            if (it < total) {
+                const int rin = min(max(r0 - PD + it, 0), H - 1);
+                const T* rowp = img + (size_t)rin * W;
+                float o4[4];
+                km_sg_ld4(rowp + c0, o4);
+#pragma unroll
+                for (int q = 0; q < PD; ++q) {
+                    ring[kk][q] = (float)km_ld(rowp + hl[q]);
+                    ring[kk][PD + 4 + q] = (float)km_ld(rowp + hr[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ring[kk][PD + q] = o4[q];
+                if (it >= KS - 1) {
+                    const int r = r0 + it - (KS - 1);
+                    float acc[NOUT][4];
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int p = 0; p < KS; ++p)
+#pragma unroll
+                                for (int q = 0; q < KS; ++q) s = km_fma(k[o][p][q], ring[(kk + 1 + p) % KS][c + q], s);
+                            acc[o][c] = s;
+                        }
+                    if (a.out) {
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o) km_sg_st4(a.out + ((size_t)bc * NOUT + o) * plane + (size_t)r * W + c0, acc[o]);
+                    }
+                    if (NOUT == 2 && a.mag) {
+                        float mg[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) mg[c] = km_sqrt((acc[0][c] * acc[0][c] + acc[1][c] * acc[1][c]) + a.eps);
+                        km_sg_st4(a.mag + (size_t)bc * plane + (size_t)r * W + c0, mg);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 1 if the register-tiled forward handles this problem
+template <typename T>
+static bool km_sg_fast_ok(const void* x, const void* out, const void* mag, int H, int W, int n_out, int kS) {
+    if (!((kS == 3 && (n_out == 2 || n_out == 3)) || (kS == 5 && n_out == 3))) return false;
+    if ((W & 3) != 0 || W < 8 || H < 1) return false;
+    const size_t al = 4 * sizeof(T);
+    if (((uintptr_t)x % al) || (out && ((uintptr_t)out % al)) || (mag && ((uintptr_t)mag % al))) return false;
+    return (((size_t)H * W * sizeof(T)) % al) == 0;
+}
+
+template <typename T>
+static int km_sg_fast_launch(const KmGradArgs<T>& a0, hipStream_t s) {
+    KmGradArgs<T> a = a0;
+    a.tiles_x = (uint32_t)((a.W / 4 + 63) / 64);
+    a.tiles_y = (uint32_t)((a.H + 4 * KM_SG_ROWS - 1) / (4 * KM_SG_ROWS));
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)a.BC;
+    KM_REQUIRE(nb < (1ull << 31), "km_spatial_gradient: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (a.kS == 3 && a.n_out == 2)
+        hipLaunchKernelGGL((km_spatial_gradient_reg_kernel<T, 3, 2>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else if (a.kS == 3)
+        hipLaunchKernelGGL((km_spatial_gradient_reg_kernel<T, 3, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_spatial_gradient_reg_kernel<T, 5, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch("km_spatial_gradient_fwd(reg)");
+}
+template <>
+int km_sg_fast_launch<double>(const KmGradArgs<double>&, hipStream_t) { return -1; }  // fp64 stays on the generic kernel
+
 template <typename T>
 static int km_grad_run(bool bwd, const void* x, const void* gout, const void* kern_host, void* out, void* mag, int BC, int H,
                        int W, int n_out, int kS, double eps, hipStream_t s) {
@@ -116,6 +265,11 @@ static int km_grad_run(bool bwd, const void* x, const void* gout, const void* ke
     KM_REQUIRE(nb < (1ull << 31), "km_spatial_gradient: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
+    {
+        static int generic = -1;
+        if (generic < 0) { const char* e = getenv("KM_SG_ALGO"); generic = (e && e[0] == 'g') ? 1 : 0; }  // "generic": A/B timing
+        if (!bwd && !generic && sizeof(T) != 8 && km_sg_fast_ok<T>(x, out, mag, H, W, n_out, kS)) return km_sg_fast_launch<T>(a, s);
+    }
     if (bwd)
         hipLaunchKernelGGL(km_spatial_gradient_bwd_kernel<T>, dim3(a.nblocks), dim3(256), 0, s, a);
     else

@@ -141,6 +141,24 @@ def test_spatial_gradient(oracle, mode, order, normalized):
     assert torch.allclose(xg.grad.cpu(), oracle.spatial_gradient_backward(go, x, mode, order, normalized), atol=1e-4 if not normalized else 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 72), (3, 1, 37, 128), (1, 2, 5, 8), (1, 1, 1, 264), (2, 1, 140, 260)])
+@pytest.mark.parametrize("mode,order", [("sobel", 1), ("diff", 1), ("sobel", 2), ("diff", 2)])
+def test_register_tiled_spatial_gradient(oracle, mode, order, shape):
+    """W % 4 == 0 takes km_spatial_gradient_reg_kernel: bit-identical to the oracle, sobel magnitude fused."""
+    import kornia_amd as K
+
+    x, g = _x(*shape, seed=11)
+    ref = oracle.spatial_gradient(x, mode, order, True)
+    out = K.spatial_gradient(x.cuda(), mode, order, True)
+    assert out.shape == ref.shape and out.is_contiguous()
+    assert torch.equal(out.cpu(), ref), f"max |d| = {(out.cpu() - ref).abs().max().item():.3e}"
+    if mode == "sobel" and order == 1:
+        assert torch.equal(K.sobel(x.cuda()).cpu(), oracle.sobel(x))
+        xb = x.bfloat16()
+        ob = K.spatial_gradient(xb.cuda(), mode, order, True).float().cpu()
+        assert torch.allclose(ob, oracle.spatial_gradient(xb.float(), mode, order, True), atol=2e-2)
+
+
 def test_sobel(oracle):
     import kornia_amd as K
 
