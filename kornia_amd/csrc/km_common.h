@@ -94,6 +94,27 @@ __device__ __forceinline__ void km_ld2(const km_f16* p, float& a, float& b) {
     a = (float)p[0]; b = (float)p[1];
 }
 
+// four horizontally adjacent pixels with one load (element-aligned address), for the bicubic taps
+struct __attribute__((packed, aligned(4))) km_f32x4_u { float x, y, z, w; };
+struct __attribute__((packed, aligned(8))) km_f64x4_u { double x, y, z, w; };
+struct __attribute__((packed, aligned(2))) km_u16x4_u { uint16_t x, y, z, w; };
+__device__ __forceinline__ void km_ld4u(const float* p, float (&o)[4]) {
+    const km_f32x4_u v = *reinterpret_cast<const km_f32x4_u*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void km_ld4u(const double* p, double (&o)[4]) {
+    const km_f64x4_u v = *reinterpret_cast<const km_f64x4_u*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void km_ld4u(const km_bf16* p, float (&o)[4]) {
+    const km_u16x4_u v = *reinterpret_cast<const km_u16x4_u*>(p);
+    o[0] = __uint_as_float(((uint32_t)v.x) << 16); o[1] = __uint_as_float(((uint32_t)v.y) << 16);
+    o[2] = __uint_as_float(((uint32_t)v.z) << 16); o[3] = __uint_as_float(((uint32_t)v.w) << 16);
+}
+__device__ __forceinline__ void km_ld4u(const km_f16* p, float (&o)[4]) {
+    o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2]; o[3] = (float)p[3];
+}
+
 // base + 32-bit element offset with the byte offset kept in 32 bits: with a wave-uniform base the compiler can
 // use the  global_load vdst, voffset, s[base:base+1]  form (no 64-bit VALU address arithmetic per lane).
 // Callers guarantee  plane elements * sizeof(T) < 2^32.

@@ -137,6 +137,32 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
             R cx[4], cy[4];
             km_cubic_coeffs(x - xf, cx);
             km_cubic_coeffs(y - yf, cy);
+            // all 16 taps of every lane inside the image: every padding transform is the identity on them, and the
+            // four taps of a row are contiguous -> 4 wide loads per channel instead of 16 predicated ones
+            const bool interior = (xf >= (R)1) && (xf <= (R)(g.W - 3)) && (yf >= (R)1) && (yf <= (R)(g.H - 3));
+            if (__all(interior)) {
+                const int base = ((int)yf - 1) * g.W + ((int)xf - 1);
+                R inv_mask = 0;
+                if (g.pad == KM_PAD_FILL) {  // same expression as the general case with every tap present
+                    const R one = 1;
+                    const R r1 = one * cx[0] + one * cx[1] + one * cx[2] + one * cx[3];
+                    inv_mask = (R)1 - (r1 * cy[0] + r1 * cy[1] + r1 * cy[2] + r1 * cy[3]);
+                }
+                for (int c = 0; c < g.C; ++c) {
+                    const T* img = src_b + (size_t)c * src_plane + base;
+                    R rows[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        R tt[4];
+                        km_ld4u(img + rr * g.W, tt);
+                        rows[rr] = tt[0] * cx[0] + tt[1] * cx[1] + tt[2] * cx[2] + tt[3] * cx[3];
+                    }
+                    R acc = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+                    if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
+                    km_st(out_px + (size_t)c * dst_plane, acc);
+                }
+                continue;
+            }
             int idx[4][4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
