@@ -503,7 +503,10 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
                         if (tid <= ie - ib) s_v4[tid] = kmt_row_entry<CM>(m, km_base_y<R, CM>(g, ib + tid));
                         __syncthreads();
                         const int nq = bwb * (ie - ib + 1);
-                        int qi = tid / bwb, qj = tid - qi * bwb;  // element e = base + tid
+                        // element e = base + tid  (tid < 2^24: the float quotient is off by at most one)
+                        int qi = (int)(((float)tid + 0.5f) / (float)bwb), qj = tid - qi * bwb;
+                        if (qj < 0) { qi -= 1; qj += bwb; }
+                        if (qj >= bwb) { qi += 1; qj -= bwb; }
                         int base = 0;
                         for (; base + KMT_UNROLL * KMT_NT <= nq; base += KMT_UNROLL * KMT_NT) {
 #pragma unroll
@@ -532,8 +535,33 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
             break;
         }
 
-        // ---- convert and write the tile: lane -> column, waves -> rows: rows of 64 floats, fully coalesced ----
-        {
+        // ---- convert and write the tile ----
+        if (TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0) {
+            // full-width tile, 16-byte aligned rows: 16 lanes x 16 bytes cover a tile row, a wave writes 4 rows per store
+            const int col4 = (tid & 15) * 4, row0 = tid >> 4;
+#pragma unroll
+            for (int c = 0; c < KMT_CC; ++c) {
+                if (c < cc) {
+                    R* outp = gsrc_b + (size_t)(cbase + c) * src_plane + (size_t)(Y0 + row0) * g.W + (X0 + col4);
+                    const int* accp = s_acc + c * KMT_PLANE + row0 * KMT_TW + col4;
+                    const size_t ostep = (size_t)(KMT_NT / 16) * g.W;
+#pragma unroll 2
+                    for (int r = row0; r < THc; r += KMT_NT / 16) {
+                        const int4 q = *reinterpret_cast<const int4*>(accp);
+                        float4 v;
+                        if (finite) {
+                            v = make_float4((R)q.x * inv_scale, (R)q.y * inv_scale, (R)q.z * inv_scale, (R)q.w * inv_scale);
+                        } else {
+                            v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
+                        }
+                        *reinterpret_cast<float4*>(outp) = v;
+                        outp += ostep;
+                        accp += (KMT_NT / 16) * KMT_TW;
+                    }
+                }
+            }
+        } else {
+            // ragged right edge / unaligned rows: lane -> column, waves -> rows, one float per store
             const int col = tid & (KMT_TW - 1), row0 = tid >> 6;
             if (col < TWc) {
 #pragma unroll
