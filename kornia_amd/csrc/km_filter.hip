@@ -502,6 +502,10 @@ static int km_full_run(int which, const void* x, const void* gy, const void* k, 
     return km_check_launch(which == 0 ? "km_filter2d_fwd" : "km_filter2d_bwd_input");
 }
 
+// register-tiled full kH x kW forward for square odd 3/5/7 kernels (km_filter2d_fast.hip)
+int km_filter2d_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype);
+int km_filter2d_fast_run(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int K, int border, int dtype, hipStream_t s);
+
 // register-tiled fast path for small square odd kernels (km_blur_fast.hip)
 int km_blur_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype);
 int km_blur_fast_run(bool bwd, const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk, int K,
@@ -533,6 +537,8 @@ int km_filter2d_fwd(const void* x, const void* k, void* y, int B, int C, int H, 
     if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_fwd", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(x && k && y, "km_filter2d_fwd: null pointer");
+    if (km_sep_algo() == 0 && km_filter2d_fast_supported(x, y, H, W, kH, kW, border, same, dtype))
+        return km_filter2d_fast_run(x, k, y, B, C, H, W, Bk, kH, border, dtype, (hipStream_t)stream);
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
 #define CALL(T) km_full_run<T>(0, x, nullptr, k, y, nullptr, g, (hipStream_t)stream)
     KM_DISPATCH_DTYPE(dtype, CALL)

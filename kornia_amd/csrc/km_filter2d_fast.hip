@@ -1,0 +1,184 @@
+// kornia_amd - register-tiled full kH x kW correlation for small square odd kernels ('same' padding):
+// the filter2d shapes behind box_blur / laplacian / unsharp / non-separable gaussian_blur2d
+// (reference: kornia/filters/filter.py:121-150 - F.pad + grouped F.conv2d).
+//
+// Same organisation as the separable blur (km_blur_fast.hip) and spatial_gradient (km_gradient.hip): a lane owns
+// 4 adjacent columns (one 16-byte load per input row + PD scalar halo loads per side, one 16-byte store per
+// output row), a wave walks a strip of rows keeping the last K input rows in registers.  Border = index map
+// (rows: wave-uniform address select; columns: per-lane halo indices computed once).  The fma chain runs in
+// (p, q) order from 0 over the whole kernel - bit-identical to oracle/ko_impl.h ko_filter2d_fwd.
+// HBM traffic = read x once + write y once = 2e bytes / element.
+#include "km_common.h"
+
+enum { KMF_CONSTANT = 0, KMF_REFLECT = 1, KMF_REPLICATE = 2, KMF_CIRCULAR = 3 };
+#define KMF_ROWS 32
+
+__device__ __forceinline__ int kmf_map(int s, int n, int border) {
+    if (s >= 0 && s < n) return s;
+    switch (border) {
+        case KMF_REFLECT:
+            if (s < 0) s = -s;
+            if (s >= n) s = 2 * (n - 1) - s;
+            return (s >= 0 && s < n) ? s : -1;
+        case KMF_REPLICATE: return s < 0 ? 0 : n - 1;
+        case KMF_CIRCULAR: { int r = s % n; return r < 0 ? r + n : r; }
+        default: return -1;
+    }
+}
+
+__device__ __forceinline__ void kmf_ld4(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void kmf_ld4(const km_bf16* p, float (&o)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void kmf_ld4(const km_f16* p, float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
+}
+__device__ __forceinline__ void kmf_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ void kmf_st4(km_bf16* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
+    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void kmf_st4(km_f16* p, const float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 v;
+    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    *reinterpret_cast<h4*>(p) = v;
+}
+
+template <typename T>
+struct KmF2Args {
+    const T* x;
+    T* y;
+    const float* k;  // (Bk, K, K)
+    int C, H, W, Bk, border;
+    uint32_t tiles_x, tiles_y, nblocks;
+};
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void km_filter2d_reg_kernel(const KmF2Args<T> a) {
+    constexpr int PD = (K - 1) / 2, NV = 4 + 2 * PD;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t tby = bid % a.tiles_y;
+    const uint32_t bc = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = (int)tbx * 64 + lane;                  // column group (4 px)
+    const int r0 = ((int)tby * 4 + wave) * KMF_ROWS;      // first output row of this wave's strip
+    const int H = a.H, W = a.W, border = a.border;
+    if (gx * 4 >= W || r0 >= H) return;
+    const int c0 = gx * 4;
+    const size_t plane = (size_t)H * W;
+    const T* img = a.x + (size_t)bc * plane;
+    T* out = a.y + (size_t)bc * plane;
+    const int b = (int)(bc / a.C);
+
+    // halo columns through the border map (only the edge lanes of a row see anything but c0 - PD + q)
+    int hl[PD], hr[PD];
+    bool okl[PD], okr[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+        const int il = kmf_map(c0 - PD + q, W, border), ir = kmf_map(c0 + 4 + q, W, border);
+        okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
+        okr[q] = ir >= 0; hr[q] = okr[q] ? ir : 0;
+    }
+    float k[K][K];
+    {
+        const float* kp = a.k + (size_t)(b % a.Bk) * K * K;
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+#pragma unroll
+            for (int q = 0; q < K; ++q) k[p][q] = kp[p * K + q];
+    }
+
+    float ring[K][NV];  // last K input rows: ring[.][i] = column c0 - PD + i
+    const int n_rows = (r0 + KMF_ROWS <= H ? KMF_ROWS : H - r0);
+    const int total = n_rows + K - 1;
+    for (int it0 = 0; it0 < total; it0 += K) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int it = it0 + kk;
+            if (it < total) {
+                const int srow = kmf_map(r0 - PD + it, H, border);  // wave-uniform
+                if (srow >= 0) {
+                    const T* rowp = img + (size_t)srow * W;
+                    float o4[4];
+                    kmf_ld4(rowp + c0, o4);
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) {
+                        const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
+                        ring[kk][q] = okl[q] ? vl : 0.f;
+                        ring[kk][PD + 4 + q] = okr[q] ? vr : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ring[kk][PD + q] = o4[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) ring[kk][q] = 0.f;
+                }
+                if (it >= K - 1) {
+                    const int r = r0 + it - (K - 1);
+                    float acc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int p = 0; p < K; ++p)
+#pragma unroll
+                            for (int q = 0; q < K; ++q) s = km_fma(k[p][q], ring[(kk + 1 + p) % K][c + q], s);
+                        acc[c] = s;
+                    }
+                    kmf_st4(out + (size_t)r * W + c0, acc);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int kmf_run(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int K, int border, hipStream_t s) {
+    KmF2Args<T> a;
+    a.x = (const T*)x; a.y = (T*)y; a.k = (const float*)k;
+    a.C = C; a.H = H; a.W = W; a.Bk = Bk; a.border = border;
+    a.tiles_x = (uint32_t)((W / 4 + 63) / 64);
+    a.tiles_y = (uint32_t)((H + 4 * KMF_ROWS - 1) / (4 * KMF_ROWS));
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B * C;
+    KM_REQUIRE(nb < (1ull << 31), "km_filter2d: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    switch (K) {
+        case 3: hipLaunchKernelGGL((km_filter2d_reg_kernel<T, 3>), dim3(a.nblocks), dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((km_filter2d_reg_kernel<T, 5>), dim3(a.nblocks), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((km_filter2d_reg_kernel<T, 7>), dim3(a.nblocks), dim3(256), 0, s, a); break;
+    }
+    return km_check_launch("km_filter2d_fwd(reg)");
+}
+
+// 1 if the register-tiled kernel handles this problem ('same', square odd 3/5/7, W % 4 == 0, 16-byte aligned, not fp64)
+int km_filter2d_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype) {
+    if (!same || kH != kW || !(kH == 3 || kH == 5 || kH == 7)) return 0;
+    if (dtype == KM_F64) return 0;
+    if ((W & 3) != 0 || W < 8 || H < 1) return 0;
+    if (border == KMF_REFLECT && (kH - 1) / 2 >= (H < W ? H : W)) return 0;
+    const size_t esz = (dtype == KM_F32) ? 4 : 2;
+    if (((uintptr_t)x % (4 * esz)) != 0 || ((uintptr_t)y % (4 * esz)) != 0) return 0;
+    return 1;
+}
+
+int km_filter2d_fast_run(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int K, int border, int dtype,
+                         hipStream_t s) {
+    switch (dtype) {
+        case KM_F32: return kmf_run<float>(x, k, y, B, C, H, W, Bk, K, border, s);
+        case KM_BF16: return kmf_run<km_bf16>(x, k, y, B, C, H, W, Bk, K, border, s);
+        default: return kmf_run<km_f16>(x, k, y, B, C, H, W, Bk, K, border, s);
+    }
+}

@@ -159,6 +159,27 @@ def test_register_tiled_spatial_gradient(oracle, mode, order, shape):
         assert torch.allclose(ob, oracle.spatial_gradient(xb.float(), mode, order, True), atol=2e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 72), (3, 2, 37, 128), (2, 1, 5, 8), (1, 1, 140, 260)])
+@pytest.mark.parametrize("K", [3, 5, 7])
+@pytest.mark.parametrize("border", BORDERS)
+def test_register_tiled_filter2d(oracle, border, K, shape):
+    """Square odd 3/5/7 kernels with W % 4 == 0 take km_filter2d_reg_kernel: bit-identical to the oracle."""
+    import kornia_amd as K_
+
+    B, C, H, W = shape
+    if border == "reflect" and (K - 1) // 2 >= min(H, W):
+        pytest.skip("reflect pad wider than the image")
+    x, g = _x(*shape, seed=5)
+    for nb in (1, B):
+        k = torch.rand(nb, K, K, generator=g) - 0.3
+        ref = oracle.filter2d(x, k, border)
+        out = K_.filter2d(x.cuda(), k.cuda(), border)
+        assert torch.equal(out.cpu(), ref), f"max |d| = {(out.cpu() - ref).abs().max().item():.3e}"
+    kb = torch.rand(1, K, K, generator=g)
+    ob = K_.filter2d(x.bfloat16().cuda(), kb.cuda(), border).float().cpu()
+    assert torch.allclose(ob, oracle.filter2d(x.bfloat16().float(), kb.bfloat16().float(), border), atol=3e-2, rtol=2e-2)
+
+
 def test_sobel(oracle):
     import kornia_amd as K
 
