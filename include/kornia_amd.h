@@ -79,6 +79,19 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
  * 0 if it overwrites gsrc completely (tile-owner path: bilinear, zeros/fill padding, dtype != f64). */
 int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype);
 
+/* ---- explicit sampling grid ------------------------------------------------------------------
+ * Replaces F.grid_sample(input, grid, mode, padding_mode, align_corners) as called by remap
+ * (kornia/geometry/transform/imgwarp.py:702) and by HomographyWarper's cached-grid forward
+ * (kornia/geometry/transform/homography_warper.py:182).
+ *   grid (B_G,h,w,2): normalised (x, y) pairs in the IMAGE dtype, B_G in {1, B} (1 = shared by the batch);
+ *   interp 0 nearest / 1 bilinear / 2 bicubic; pad 0 zeros / 1 border / 2 reflection.
+ *   bwd: gsrc (B,C,H,W) compute dtype, zeroed by the caller, nullable; ggrid (B,h,w,2) compute dtype,
+ *   overwritten, nullable (for B_G == 1 the caller sums it over the batch). */
+int km_grid_sample2d_fwd(const void* src, const void* grid, void* dst, int B, int C, int H, int W, int h, int w, int B_G,
+                         int interp, int pad, int align, int dtype, void* stream);
+int km_grid_sample2d_bwd(const void* gout, const void* src, const void* grid, void* gsrc, void* ggrid, int B, int C, int H,
+                         int W, int h, int w, int B_G, int interp, int pad, int align, int dtype, void* stream);
+
 /* ---- filters -------------------------------------------------------------------------------
  * Replaces F.pad + F.conv2d(groups = Bk*C) of filter2d (kornia/filters/filter.py:131-150).
  *   x (B,C,H,W) dtype; k (Bk,kH,kW) prepared taps (flipped for 'conv', normalised, rounded to the

@@ -26,8 +26,10 @@ from .geometry import (
     get_perspective_transform,
     get_rotation_matrix2d,
     get_shear_matrix2d,
+    grid_sample,
     homography_warp,
     normalize_homography,
+    remap,
     transform_points,
     warp_affine,
     warp_grid,

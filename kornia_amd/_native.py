@@ -34,6 +34,8 @@ _PROTOTYPES = {
     "km_warp2d_fwd": [_P, _P, _P] + [_I] * 12 + [_P, _I, _P],
     "km_warp2d_bwd": [_P, _P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],
     "km_warp2d_bwd_needs_zero_init": [_I, _I, _I],
+    "km_grid_sample2d_fwd": [_P, _P, _P] + [_I] * 10 + [_I, _P],
+    "km_grid_sample2d_bwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_I, _P],
     "km_filter2d_fwd": [_P, _P, _P] + [_I] * 10 + [_P],
     "km_filter2d_bwd_input": [_P, _P, _P] + [_I] * 10 + [_P],
     "km_filter2d_bwd_kernel": [_P, _P, _P] + [_I] * 10 + [_P],

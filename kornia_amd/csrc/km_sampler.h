@@ -13,7 +13,7 @@
 
 #include "km_common.h"
 
-enum { KM_COORD_PERSPECTIVE = 0, KM_COORD_AFFINE = 1, KM_COORD_HOMOGRAPHY = 2 };
+enum { KM_COORD_PERSPECTIVE = 0, KM_COORD_AFFINE = 1, KM_COORD_HOMOGRAPHY = 2, KM_COORD_GRID = 3 /* explicit (B_G,h,w,2) grid */ };
 enum { KM_INTERP_NEAREST = 0, KM_INTERP_BILINEAR = 1, KM_INTERP_BICUBIC = 2 };
 enum { KM_PAD_ZEROS = 0, KM_PAD_BORDER = 1, KM_PAD_REFLECTION = 2, KM_PAD_FILL = 3 };
 
@@ -53,12 +53,14 @@ __device__ __forceinline__ R km_linspace(R lo, R hi, R step, int n, int i) {
 // base coordinate along x (column j) / y (row i)
 template <typename R, int CM>
 __device__ __forceinline__ R km_base_x(const KmWarpGeom<R>& g, int j) {
+    if (CM == KM_COORD_GRID) return (R)0;  // coordinates come from memory
     if (CM == KM_COORD_PERSPECTIVE) return (R)km_mesh_f32(j, g.w);  // always computed in fp32, then cast
     if (CM == KM_COORD_AFFINE) return km_linspace<R>(g.lin_lo_x, g.lin_hi_x, g.lin_step_x, g.w, j);
     return g.norm_coords ? km_mesh<R>(j, g.w) : (R)j;
 }
 template <typename R, int CM>
 __device__ __forceinline__ R km_base_y(const KmWarpGeom<R>& g, int i) {
+    if (CM == KM_COORD_GRID) return (R)0;
     if (CM == KM_COORD_PERSPECTIVE) return (R)km_mesh_f32(i, g.h);
     if (CM == KM_COORD_AFFINE) return km_linspace<R>(g.lin_lo_y, g.lin_hi_y, g.lin_step_y, g.h, i);
     return g.norm_coords ? km_mesh<R>(i, g.h) : (R)i;
@@ -68,7 +70,10 @@ template <typename R, int CM>
 __device__ __forceinline__ void km_gen_coord(const R (&m)[9], R u, R v, KmCoord<R>& c) {
     c.u = u;
     c.v = v;
-    if (CM == KM_COORD_PERSPECTIVE) {
+    if (CM == KM_COORD_GRID) {
+        // (gx, gy) are loaded by the caller (km_grid_coord)
+        c.den = (R)1;
+    } else if (CM == KM_COORD_PERSPECTIVE) {
         // imgwarp.py:167-169: ((m20*u) + (m21*v)) + m22 ; ((m00*u) + (m01*v) + m02) / den
         const R den = (m[6] * u + m[7] * v) + m[8];
         c.den = den;
@@ -93,6 +98,14 @@ __device__ __forceinline__ void km_gen_coord(const R (&m)[9], R u, R v, KmCoord<
         c.gx = s * X;
         c.gy = s * Y;
     }
+}
+
+// explicit-grid mode: the normalised sampling position of output pixel (i, j) of image b, stored as (x, y) pairs in
+// the image dtype (F.grid_sample requires grid.dtype == input.dtype); one 2-element load
+template <typename T, typename R>
+__device__ __forceinline__ void km_grid_coord(const T* grid, const KmWarpGeom<R>& g, uint32_t b, int i, int j, KmCoord<R>& c) {
+    const T* gp = grid + (((size_t)(g.B_M == 1 ? 0 : b) * g.h + i) * g.w + j) * 2;
+    km_ld2(gp, c.gx, c.gy);
 }
 
 // ---- ATen GridSampler.h primitives ---------------------------------------------------------------

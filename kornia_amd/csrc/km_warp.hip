@@ -32,6 +32,8 @@ struct KmWarpArgs {
     R* gsrc;          // bwd: (B,C,H,W) accumulators in compute dtype, pre-zeroed (nullable)
     double* gmat;     // bwd: (B_M,9) fp64 accumulators, pre-zeroed (nullable)
     const R* fill;    // (C) compute dtype, pad == fill only
+    const T* grid;    // KM_COORD_GRID: (B_M,h,w,2) normalised sampling grid in the image dtype
+    R* ggrid;         // KM_COORD_GRID bwd: (B,h,w,2) gradient wrt the grid, written (nullable)
     KmWarpGeom<R> g;
     uint32_t tiles_x, tiles_y, nblocks;
 };
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
     {
         const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+        for (int k = 0; k < 9; ++k) m[k] = (CM == KM_COORD_GRID) ? (R)0 : mp[k];  // grid mode has no matrix
     }
     const int spad = (g.pad == KM_PAD_FILL) ? KM_PAD_ZEROS : g.pad;
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
         const R v = s_v[wave * KM_ROWS + r];  // row base coordinate (one IEEE divide per row per block, not per lane)
         KmCoord<R> cd;
         km_gen_coord<R, CM>(m, u, v, cd);
+        if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, i, j, cd);
         R mx, my, gdx, gdy;
         R x = km_unnormalize(cd.gx, g.W, g.align, mx);
         R y = km_unnormalize(cd.gy, g.H, g.align, my);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
     {
         const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+        for (int k = 0; k < 9; ++k) m[k] = (CM == KM_COORD_GRID) ? (R)0 : mp[k];  // grid mode has no matrix
     }
     const int W = g.W, H = g.H, align = g.align;
     const int C = (NC > 0) ? NC : g.C;
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
         const bool row_ok = i < g.h;
         KmCoord<R> cd;
         km_gen_coord<R, CM>(m, u, s_v[wave * KM_ROWS + r], cd);
+        if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, row_ok ? i : 0, j, cd);
         R mx, my;
         const R x = km_unnormalize(cd.gx, W, align, mx);
         const R y = km_unnormalize(cd.gy, H, align, my);
@@ -314,14 +318,15 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = (int)tx * KM_TILE_W + lane;
     const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
-    const bool want_gm = (a.gmat != nullptr) && (INTERP != KM_INTERP_NEAREST);
+    const bool want_gg = (CM == KM_COORD_GRID) && (a.ggrid != nullptr);  // gradient wrt the explicit grid
+    const bool want_gm = ((a.gmat != nullptr) || want_gg) && (INTERP != KM_INTERP_NEAREST);  // needs d out / d (x, y)
     const bool want_gs = (a.gsrc != nullptr);
 
     R m[9];
     {
         const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+        for (int k = 0; k < 9; ++k) m[k] = (CM == KM_COORD_GRID) ? (R)0 : mp[k];  // grid mode has no matrix
     }
     const int spad = (g.pad == KM_PAD_FILL) ? KM_PAD_ZEROS : g.pad;
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
             const R v = km_base_y<R, CM>(g, i);
             KmCoord<R> cd;
             km_gen_coord<R, CM>(m, u, v, cd);
+            if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, i, j, cd);
             R mx, my, gdx = 1, gdy = 1;
             R x = km_unnormalize(cd.gx, g.W, g.align, mx);
             R y = km_unnormalize(cd.gy, g.H, g.align, my);
@@ -415,7 +421,13 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
                 giy = giy * my;
             }
 
-            if (want_gm) {
+            if (want_gg) {
+                // d loss / d grid[b, i, j, :] (zero for nearest: ATen returns a zero grid gradient there)
+                R* gp = a.ggrid + (((size_t)b * g.h + i) * g.w + j) * 2;
+                gp[0] = (INTERP == KM_INTERP_NEAREST) ? (R)0 : gix;
+                gp[1] = (INTERP == KM_INTERP_NEAREST) ? (R)0 : giy;
+            }
+            if (CM != KM_COORD_GRID && want_gm) {
                 if (CM == KM_COORD_PERSPECTIVE) {
                     const R inv = (R)1 / cd.den;
                     const R ax = gix * inv, ay = giy * inv;
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
         }
     }
 
-    if (want_gm) {  // block-uniform
+    if (CM != KM_COORD_GRID && want_gm) {  // block-uniform
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const double s = km_wave_sum((double)gm[k]);
@@ -500,7 +512,7 @@ static int km_warp_dispatch_interp(bool bwd, const KmWarpArgs<T>& a, hipStream_t
 template <typename T>
 static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, const void* gout, void* gsrc, double* gmat,
                        int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp,
-                       int pad, int align, const void* fill, hipStream_t s) {
+                       int pad, int align, const void* fill, hipStream_t s, const void* grid = nullptr, void* ggrid = nullptr) {
     typedef typename KmTraits<T>::R R;
     KmWarpArgs<T> a;
     a.src = (const T*)src;
@@ -510,6 +522,8 @@ static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, co
     a.gsrc = (R*)gsrc;
     a.gmat = gmat;
     a.fill = (const R*)fill;
+    a.grid = (const T*)grid;
+    a.ggrid = (R*)ggrid;
     KmWarpGeom<R>& g = a.g;
     g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
     g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = interp; g.pad = pad; g.align = align;
@@ -523,13 +537,14 @@ static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, co
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return km_warp_dispatch_interp<T, KM_COORD_PERSPECTIVE>(bwd, a, s);
         case KM_COORD_AFFINE: return km_warp_dispatch_interp<T, KM_COORD_AFFINE>(bwd, a, s);
+        case KM_COORD_GRID: return km_warp_dispatch_interp<T, KM_COORD_GRID>(bwd, a, s);
         default: return km_warp_dispatch_interp<T, KM_COORD_HOMOGRAPHY>(bwd, a, s);
     }
 }
 
 static int km_warp_validate(const char* fn, const void* src, const void* mat, int B, int C, int H, int W, int h, int w,
                             int B_M, int coord_mode, int interp, int pad, const void* fill, int dtype) {
-    KM_REQUIRE(src && mat, "%s: null pointer", fn);
+    KM_REQUIRE(src && mat, "%s: null pointer", fn);  // (grid mode passes the grid as `mat`)
     KM_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && h >= 0 && w >= 0, "%s: bad shape B=%d C=%d H=%d W=%d h=%d w=%d", fn, B, C, H, W, h, w);
     KM_REQUIRE((int64_t)H * W < (1ll << 31) && (int64_t)h * w < (1ll << 31), "%s: image plane exceeds 2^31 elements", fn);
     KM_REQUIRE(B_M == 1 || B_M == B, "%s: matrix batch %d must be 1 or %d", fn, B_M, B);
@@ -605,6 +620,42 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
         case KM_F64: return km_warp_run<double>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         case KM_BF16: return km_warp_run<km_bf16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         default: return km_warp_run<km_f16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+    }
+}
+
+// ---- explicit sampling grid: replaces F.grid_sample(input, grid) as called by remap (imgwarp.py:702) and
+// HomographyWarper's cached-grid forward (homography_warper.py:182).
+//   grid (B_G,h,w,2) normalised (x, y) pairs in the IMAGE dtype, B_G in {1, B}; pad 0 zeros / 1 border / 2 reflection.
+int km_grid_sample2d_fwd(const void* src, const void* grid, void* dst, int B, int C, int H, int W, int h, int w, int B_G,
+                         int interp, int pad, int align, int dtype, void* stream) {
+    if (B == 0 || C == 0 || h == 0 || w == 0) return 0;
+    if (km_warp_validate("km_grid_sample2d_fwd", src, grid, B, C, H, W, h, w, B_G, 0, interp, pad, nullptr, dtype)) return -1;
+    KM_REQUIRE(dst, "km_grid_sample2d_fwd: null dst");
+    KM_REQUIRE(pad != KM_PAD_FILL, "km_grid_sample2d_fwd: pad must be zeros / border / reflection");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return km_warp_run<float>(false, src, grid, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid);
+        case KM_F64: return km_warp_run<double>(false, src, grid, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid);
+        case KM_BF16: return km_warp_run<km_bf16>(false, src, grid, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid);
+        default: return km_warp_run<km_f16>(false, src, grid, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid);
+    }
+}
+
+// gsrc (B,C,H,W) compute dtype, PRE-ZEROED (fp32 atomics), nullable; ggrid (B,h,w,2) compute dtype, written, nullable
+// (with B_G == 1 the caller sums it over the batch, as autograd does for the reference's expand()).
+int km_grid_sample2d_bwd(const void* gout, const void* src, const void* grid, void* gsrc, void* ggrid, int B, int C, int H, int W,
+                         int h, int w, int B_G, int interp, int pad, int align, int dtype, void* stream) {
+    if (B == 0 || C == 0 || h == 0 || w == 0) return 0;
+    if (km_warp_validate("km_grid_sample2d_bwd", src, grid, B, C, H, W, h, w, B_G, 0, interp, pad, nullptr, dtype)) return -1;
+    KM_REQUIRE(gout, "km_grid_sample2d_bwd: null gout");
+    KM_REQUIRE(pad != KM_PAD_FILL, "km_grid_sample2d_bwd: pad must be zeros / border / reflection");
+    if (!gsrc && !ggrid) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return km_warp_run<float>(true, src, grid, nullptr, gout, gsrc, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid, ggrid);
+        case KM_F64: return km_warp_run<double>(true, src, grid, nullptr, gout, gsrc, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid, ggrid);
+        case KM_BF16: return km_warp_run<km_bf16>(true, src, grid, nullptr, gout, gsrc, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid, ggrid);
+        default: return km_warp_run<km_f16>(true, src, grid, nullptr, gout, gsrc, nullptr, B, C, H, W, h, w, B_G, KM_COORD_GRID, 0, interp, pad, align, nullptr, s, grid, ggrid);
     }
 }
 

@@ -5,6 +5,7 @@ from .conversions import (
     convert_points_to_homogeneous,
     normal_transform_pixel,
     normalize_homography,
+    normalize_pixel_coordinates,
 )
 from .grid import create_meshgrid
 from .linalg import transform_points
@@ -17,7 +18,9 @@ from .transform import (
     get_rotation_matrix2d,
     get_shear_matrix2d,
     get_translation_matrix2d,
+    grid_sample,
     homography_warp,
+    remap,
     warp_affine,
     warp_grid,
     warp_perspective,

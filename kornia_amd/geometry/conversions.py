@@ -119,3 +119,18 @@ def convert_points_to_homogeneous(points: torch.Tensor) -> torch.Tensor:
     if len(points.shape) < 2:
         raise ValueError(f"Input must be at least a 2D tensor. Got {points.shape}")
     return F.pad(points, [0, 1], "constant", 1.0)
+
+
+def normalize_pixel_coordinates(pixel_coordinates: torch.Tensor, height: int, width: int, eps: float = 1e-8) -> torch.Tensor:
+    """(*,2) pixel (x, y) -> [-1, 1]: ``2 / (size - 1).clamp(eps) * p - 1`` (conversions.py:1455-1500).
+    Elementwise O(N) tensor expression kept in PyTorch: it defines the bits of the grid ``remap`` samples with."""
+    if pixel_coordinates.shape[-1] != 2:
+        raise ValueError(f"Input pixel_coordinates must be of shape (*, 2). Got {pixel_coordinates.shape}")
+    hw = torch.stack(
+        [
+            torch.tensor(width, device=pixel_coordinates.device, dtype=pixel_coordinates.dtype),
+            torch.tensor(height, device=pixel_coordinates.device, dtype=pixel_coordinates.dtype),
+        ]
+    )
+    factor = torch.tensor(2.0, device=pixel_coordinates.device, dtype=pixel_coordinates.dtype) / (hw - 1).clamp(eps)
+    return factor * pixel_coordinates - 1

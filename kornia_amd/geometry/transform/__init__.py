@@ -8,7 +8,7 @@ from .builders import (
     get_translation_matrix2d,
 )
 from .homography_warper import HomographyWarper
-from .imgwarp import homography_warp, warp_affine, warp_grid, warp_perspective
+from .imgwarp import grid_sample, homography_warp, remap, warp_affine, warp_grid, warp_perspective
 
 __all__ = [
     "HomographyWarper",
@@ -19,7 +19,9 @@ __all__ = [
     "get_rotation_matrix2d",
     "get_shear_matrix2d",
     "get_translation_matrix2d",
+    "grid_sample",
     "homography_warp",
+    "remap",
     "warp_affine",
     "warp_grid",
     "warp_perspective",

@@ -17,7 +17,7 @@ import torch
 from ... import _native as N
 from ..linalg import transform_points
 
-__all__ = ["homography_warp", "warp_affine", "warp_grid", "warp_perspective"]
+__all__ = ["grid_sample", "homography_warp", "remap", "warp_affine", "warp_grid", "warp_perspective"]
 
 COORD_PERSPECTIVE, COORD_AFFINE, COORD_HOMOGRAPHY = 0, 1, 2
 _INTERP = {"nearest": 0, "bilinear": 1, "bicubic": 2}
@@ -112,6 +112,94 @@ class _Warp2dFunction(torch.autograd.Function):
         if gsrc is not None and gsrc.dtype != x.dtype:
             gsrc = gsrc.to(x.dtype)
         return gsrc, gmat, None, None
+
+
+class _GridSampleFunction(torch.autograd.Function):
+    """input (B,C,H,W), grid (B_G,h,w,2) normalised (x, y) in the input dtype, B_G in {1, B}."""
+
+    @staticmethod
+    def forward(ctx, input: torch.Tensor, grid: torch.Tensor, interp: int, pad: int, align: int):
+        lib = N.lib()
+        dev = input.device
+        x = input.detach().contiguous()
+        gr = grid.detach().contiguous()
+        B, C, H, W = x.shape
+        B_G, h, w, _ = gr.shape
+        out = torch.empty(B, C, h, w, device=dev, dtype=x.dtype)
+        with torch.cuda.device(dev):
+            N.check(lib.km_grid_sample2d_fwd(x.data_ptr(), gr.data_ptr(), out.data_ptr(), B, C, H, W, h, w, B_G, interp, pad, align,
+                                             N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_grid_sample2d_fwd")
+        ctx.save_for_backward(x, gr)
+        ctx.cfg = (interp, pad, align)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: torch.Tensor):
+        x, gr = ctx.saved_tensors
+        interp, pad, align = ctx.cfg
+        lib = N.lib()
+        dev = x.device
+        cdt = N.compute_dtype(x.dtype)
+        B, C, H, W = x.shape
+        B_G, h, w, _ = gr.shape
+        g = gout.detach().to(x.dtype).contiguous()
+        gsrc = torch.zeros(B, C, H, W, device=dev, dtype=cdt) if ctx.needs_input_grad[0] else None
+        ggrid = torch.empty(B, h, w, 2, device=dev, dtype=cdt) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dev):
+            N.check(lib.km_grid_sample2d_bwd(g.data_ptr(), x.data_ptr(), gr.data_ptr(), N.ptr(gsrc), N.ptr(ggrid), B, C, H, W, h, w, B_G,
+                                             interp, pad, align, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_grid_sample2d_bwd")
+        if gsrc is not None and gsrc.dtype != x.dtype:
+            gsrc = gsrc.to(x.dtype)
+        if ggrid is not None:
+            if B_G == 1 and B > 1:
+                ggrid = ggrid.sum(0, keepdim=True)
+            ggrid = ggrid.to(gr.dtype)
+        return gsrc, ggrid, None, None, None
+
+
+def grid_sample(input: torch.Tensor, grid: torch.Tensor, mode: str = "bilinear", padding_mode: str = "zeros",
+                align_corners: Optional[bool] = None) -> torch.Tensor:
+    """``F.grid_sample`` for 4-D inputs on the native sampler (call sites imgwarp.py:702, homography_warper.py:182).
+
+    ``grid`` is ``(B,h,w,2)`` (or ``(1,h,w,2)``, shared by the batch without being expanded in memory),
+    normalised ``(x, y)``, same dtype as ``input``; differentiable in both arguments.
+    """
+    N.require_device(input, "input")
+    if input.dim() != 4 or grid.dim() != 4 or grid.shape[-1] != 2:
+        raise ValueError(f"grid_sample: expected 4-D input and a (B,h,w,2) grid, got {tuple(input.shape)} and {tuple(grid.shape)}")
+    if grid.dtype != input.dtype:
+        raise RuntimeError(f"grid_sampler(): expected input and grid to have same dtype, but input has {input.dtype} and grid has {grid.dtype}")
+    if grid.device != input.device:
+        raise RuntimeError(f"grid_sampler(): expected input and grid to be on same device, but input is on {input.device} and grid is on {grid.device}")
+    if not (grid.shape[0] == input.shape[0] or grid.shape[0] == 1):
+        raise RuntimeError(
+            f"grid_sampler(): expected grid and input to have same batch size, but got input with sizes {list(input.shape)} "
+            f"and grid with sizes {list(grid.shape)}"
+        )
+    interp, pad = _mode_codes(mode, padding_mode)
+    if pad == _PAD["fill"]:
+        raise ValueError("nn.functional.grid_sample(): expected padding_mode to be 'zeros', 'border', or 'reflection', but got: 'fill'")
+    return _GridSampleFunction.apply(input, grid, interp, pad, int(bool(align_corners)))
+
+
+def remap(image: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "bilinear", padding_mode: str = "zeros",
+          align_corners: Optional[bool] = None, normalized_coordinates: bool = False) -> torch.Tensor:
+    r"""``dst(x, y) = src(map_x(x, y), map_y(x, y))`` (kornia/geometry/transform/imgwarp.py:625-702).
+
+    ``image`` (B,C,H,W); ``map_x`` / ``map_y`` (B,H,W) or (1,H,W) in pixels unless ``normalized_coordinates``;
+    ``align_corners=None`` resolves to False.  A single map is shared by the batch without being expanded in HBM.
+    """
+    from ...core.check import KORNIA_CHECK_SHAPE
+    from ..conversions import normalize_pixel_coordinates
+
+    KORNIA_CHECK_SHAPE(image, ["B", "C", "H", "W"])
+    KORNIA_CHECK_SHAPE(map_x, ["B", "H", "W"])
+    KORNIA_CHECK_SHAPE(map_y, ["B", "H", "W"])
+    _, _, height, width = image.shape
+    map_xy = torch.stack([map_x, map_y], -1)
+    if not normalized_coordinates:
+        map_xy = normalize_pixel_coordinates(map_xy, height, width)
+    return grid_sample(image, map_xy.to(image.dtype), mode, padding_mode, bool(align_corners))
 
 
 def _prepare_fill(fill_value: torch.Tensor, C: int, device, cdt) -> torch.Tensor:

@@ -26,6 +26,7 @@ _NATIVE = {
         "warp_affine": _g.warp_affine,
         "homography_warp": _g.homography_warp,
         "warp_grid": _g.warp_grid,
+        "remap": _g.remap,
     },
     "kornia.geometry.linalg": {"transform_points": _g.transform_points},
     "kornia.geometry.conversions": {"normalize_homography": _g.normalize_homography},

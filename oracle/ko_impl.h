@@ -299,6 +299,11 @@ static inline void KO(ko_gen_coord)(const REAL* m, int coord_mode, int align, in
         o->u = u; o->v = v; o->den = 1;
         o->gx = (m[0] * u + m[1] * v) + m[2];
         o->gy = (m[3] * u + m[4] * v) + m[5];
+    } else if (coord_mode == 3) {
+        /* explicit sampling grid (remap, imgwarp.py:625-702 / F.grid_sample): m points at this image's (h,w,2) grid */
+        o->u = 0; o->v = 0; o->den = 1;
+        o->gx = m[((size_t)i * w + j) * 2 + 0];
+        o->gy = m[((size_t)i * w + j) * 2 + 1];
     } else {
         REAL u, v;
         if (norm_coords) { u = KO(ko_mesh_real)(j, w); v = KO(ko_mesh_real)(i, h); }
@@ -320,6 +325,7 @@ static inline void KO(ko_gen_coord)(const REAL* m, int coord_mode, int align, in
 
 /* ------------------------------------------------------------------------------------------
  * Warp forward.  src (B,C,H,W) contiguous, mat (B_M,9), out (B,C,h,w).
+ *   coord_mode 0 perspective 1 affine 2 homography 3 explicit grid (mat = (B_M,h,w,2) normalised grid, gmat must be NULL)
  *   interp 0 nearest 1 bilinear 2 bicubic ; pad 0 zeros 1 border 2 reflection 3 fill
  *   fill (C values, used when pad == 3): imgwarp.py:293-320 (_fill_and_warp)
  * ---------------------------------------------------------------------------------------- */
@@ -329,7 +335,8 @@ void KO(ko_warp2d_fwd)(const REAL* src, const REAL* mat, REAL* out, int B, int C
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < h; ++i) {
-            const REAL* m = mat + 9 * (size_t)(B_M == 1 ? 0 : b);
+            const size_t mstride = (coord_mode == 3) ? (size_t)2 * h * w : (size_t)9;  /* mode 3: mat is the (B_M,h,w,2) grid */
+            const REAL* m = mat + mstride * (size_t)(B_M == 1 ? 0 : b);
             for (int j = 0; j < w; ++j) {
                 KO(ko_coord_t) cd;
                 KO(ko_gen_coord)(m, coord_mode, align, norm_coords, i, j, h, w, &cd);
@@ -426,7 +433,8 @@ void KO(ko_warp2d_bwd)(const REAL* gout, const REAL* src, const REAL* mat, REAL*
     if (gsrc) memset(gsrc, 0, (size_t)B * C * H * W * sizeof(REAL));
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
-        const REAL* m = mat + 9 * (size_t)(B_M == 1 ? 0 : b);
+        const size_t mstride = (coord_mode == 3) ? (size_t)2 * h * w : (size_t)9;  /* mode 3: mat is the (B_M,h,w,2) grid */
+        const REAL* m = mat + mstride * (size_t)(B_M == 1 ? 0 : b);
         double* gm = gm_all + 9 * (size_t)b;
         for (int i = 0; i < h; ++i)
             for (int j = 0; j < w; ++j) {

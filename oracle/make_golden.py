@@ -212,6 +212,32 @@ def main():
     save("builders", **db)
 
 
+    # ---- explicit-grid sampling: F.grid_sample / remap -----------------------------
+    import torch.nn.functional as Fn
+
+    dgs = {}
+    xs = torch.rand(2, 3, 13, 20, generator=g)
+    grid = torch.rand(2, 9, 12, 2, generator=g) * 2.6 - 1.3
+    gos = torch.rand(2, 3, 9, 12, generator=g)
+    dgs["x"], dgs["grid"], dgs["go"] = xs, grid, gos
+    for mode in MODES:
+        for pad in ("zeros", "border", "reflection"):
+            for al in (False, True):
+                xg, gg = xs.clone().requires_grad_(), grid.clone().requires_grad_()
+                y = Fn.grid_sample(xg, gg, mode=mode, padding_mode=pad, align_corners=al)
+                y.backward(gos)
+                tag = f"{mode}_{pad}_{int(al)}"
+                dgs["y_" + tag], dgs["gx_" + tag], dgs["gg_" + tag] = y, xg.grad, gg.grad
+    mx = torch.rand(2, 9, 12, generator=g) * 21 - 1
+    my = torch.rand(2, 9, 12, generator=g) * 14 - 1
+    dgs["map_x"], dgs["map_y"] = mx, my
+    dgs["remap"] = T.remap(xs, mx, my)
+    dgs["remap_ac"] = T.remap(xs, mx, my, align_corners=True)
+    dgs["remap_bcast_nearest"] = T.remap(xs, mx[:1], my[:1], mode="nearest", padding_mode="border")
+    dgs["remap_norm"] = T.remap(xs, grid[..., 0], grid[..., 1], normalized_coordinates=True, padding_mode="reflection")
+    save("grid_sample", **dgs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     main()
