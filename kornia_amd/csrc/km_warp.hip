@@ -18,7 +18,9 @@
 
 #include "km_sampler.h"
 
+#ifndef KM_ROWS
 #define KM_ROWS 4   // output rows per thread
+#endif
 #define KM_TILE_W 64
 #define KM_TILE_H (4 * KM_ROWS)
 

@@ -235,7 +235,8 @@ def _tiled_case(oracle, x, M, ds, kind="perspective", align=True, pad="zeros", s
 
 
 @pytest.mark.parametrize("align", [True, False])
-@pytest.mark.parametrize("shape", [(2, 3, 100, 150, 90, 140), (2, 5, 70, 130, 33, 47), (1, 1, 40, 48, 200, 230), (2, 9, 33, 65, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 3, 100, 150, 90, 140), (2, 5, 70, 130, 33, 47), (1, 1, 40, 48, 200, 230), (2, 9, 33, 65, 64, 64),
+                                   (1, 2, 24, 28, 300, 310), (2, 3, 300, 316, 20, 24), (1, 4, 130, 68, 129, 67)])
 def test_tiled_backward_perspective(oracle, shape, align):
     B, C, H, W, h, w = shape
     g = torch.Generator().manual_seed(11)
