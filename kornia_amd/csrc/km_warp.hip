@@ -23,6 +23,10 @@
 #endif
 #define KM_TILE_W 64
 #define KM_TILE_H (4 * KM_ROWS)
+#ifndef KM_PATCH_W
+#define KM_PATCH_W 32  // output columns covered by one wave instruction of the specialised forward (64, 32 or 16);
+                       // measured at 256x3x512^2: 64 -> 0.434 ms (0.78 at 20 deg rotation), 32 -> 0.422 (0.67), 16 -> 0.492 (0.64)
+#endif
 
 template <typename T>
 struct KmWarpArgs {
@@ -219,9 +223,14 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
+    // One wave instruction covers a KM_PATCH_W x (64 / KM_PATCH_W) patch of the output rather than a 64 x 1 row: under
+    // rotation the taps of a 64 x 1 row are spread over up to 64 * sin(angle) source rows (one cache line each), a
+    // squarer patch keeps them within ~(PW sin + PH cos) rows.  Stores stay KM_PATCH_W * 4-byte contiguous runs.
+    constexpr int PW = KM_PATCH_W, PH = 64 / PW, WA = 64 / PW;  // patch, waves across the 64-wide tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = (int)tx * KM_TILE_W + lane;
-    const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
+    const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
+    const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // row inside the tile of this thread's row r: li_base + r * PH
+    const int i_base = (int)ty * KM_TILE_H + li_base;
     __shared__ R s_v[KM_TILE_H];
     if (threadIdx.x < KM_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KM_TILE_H + (int)threadIdx.x);
     __syncthreads();
@@ -242,10 +251,10 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
 
 #pragma unroll
     for (int r = 0; r < KM_ROWS; ++r) {
-        const int i = i_base + r;
+        const int i = i_base + r * PH;
         const bool row_ok = i < g.h;
         KmCoord<R> cd;
-        km_gen_coord<R, CM>(m, u, s_v[wave * KM_ROWS + r], cd);
+        km_gen_coord<R, CM>(m, u, s_v[li_base + r * PH], cd);
         if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, row_ok ? i : 0, j, cd);
         R mx, my;
         const R x = km_unnormalize(cd.gx, W, align, mx);
