@@ -92,6 +92,21 @@ int km_grid_sample2d_fwd(const void* src, const void* grid, void* dst, int B, in
 int km_grid_sample2d_bwd(const void* gout, const void* src, const void* grid, void* gsrc, void* ggrid, int B, int C, int H,
                          int W, int h, int w, int B_G, int interp, int pad, int align, int dtype, void* stream);
 
+/* ---- fused ColorJitter ---------------------------------------------------------------------------
+ * Replaces the per-stage elementwise chains of ColorJitter.apply_transform
+ * (kornia/augmentation/_2d/intensity/color_jitter.py:126-159): adjust_brightness_accumulative
+ * (kornia/enhance/adjust.py:542-593), adjust_contrast_with_mean_subtraction (:414-469),
+ * adjust_saturation_with_gray_subtraction (:80-134), adjust_hue (:212-254; rgb_to_hsv / hsv_to_rgb
+ * kornia/color/hsv.py:27-131).
+ *   x, y (B,3,H,W) RGB, dtype f32 / bf16 / f16; params (B,4) fp32 DEVICE: brightness, contrast, saturation
+ *   factors and the hue shift in radians; stages: HOST int array, n_stages <= 4 ids in application order
+ *   (0 brightness, 1 contrast, 2 saturation, 3 hue; contrast at most once); gray_sum (B) fp64 DEVICE
+ *   workspace zeroed by the caller, required iff a contrast stage is present; enable (4) uint8 DEVICE, indexed by
+ *   stage id, 0 = skip that kind of stage (the reference's `(factor != neutral).any()` guards, evaluated on the
+ *   device so that no host sync is needed), nullable = all stages on. */
+int km_color_jitter_fwd(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const int* stages,
+                        int n_stages, int B, int H, int W, int dtype, void* stream);
+
 /* ---- filters -------------------------------------------------------------------------------
  * Replaces F.pad + F.conv2d(groups = Bk*C) of filter2d (kornia/filters/filter.py:131-150).
  *   x (B,C,H,W) dtype; k (Bk,kH,kW) prepared taps (flipped for 'conv', normalised, rounded to the

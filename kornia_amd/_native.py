@@ -44,6 +44,7 @@ _PROTOTYPES = {
     "km_spatial_gradient_fwd": [_P, _P, _P, _P] + [_I] * 6 + [c_double, _I, _P],
     "km_spatial_gradient_bwd": [_P, _P, _P] + [_I] * 6 + [_I, _P],
     "km_filter2d_sep_supported": [_I, _I, _I, _I],
+    "km_color_jitter_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
     "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
 }

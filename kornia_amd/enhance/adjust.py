@@ -1,0 +1,120 @@
+"""ColorJitter's four adjustments on one fused gfx950 kernel.
+
+Reference functions mirrored (names, argument meaning, output range):
+  adjust_brightness_accumulative            kornia/enhance/adjust.py:542-593   clamp(x * f, 0, 1)
+  adjust_contrast_with_mean_subtraction     kornia/enhance/adjust.py:414-469   clamp(x * f + mean_gray * (1 - f), 0, 1)
+  adjust_saturation_with_gray_subtraction   kornia/enhance/adjust.py:80-134    clamp((1 - f) * gray + f * x, 0, 1)
+  adjust_hue                                kornia/enhance/adjust.py:212-254   rgb -> hsv, h = fmod(h + f, 2 pi), hsv -> rgb
+and ``color_jitter`` = the sequence ColorJitter.apply_transform runs
+(kornia/augmentation/_2d/intensity/color_jitter.py:126-159) in ONE pass over the image.
+
+Forward only (augmentation): tensors that require grad are refused rather than silently detached.
+RGB ``(B,3,H,W)`` / ``(3,H,W)`` inputs on a HIP device; there is no PyTorch/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Sequence, Union
+
+import torch
+
+from .. import _native as N
+
+__all__ = [
+    "adjust_brightness_accumulative",
+    "adjust_contrast_with_mean_subtraction",
+    "adjust_hue",
+    "adjust_saturation_with_gray_subtraction",
+    "color_jitter",
+]
+
+BRIGHTNESS, CONTRAST, SATURATION, HUE = 0, 1, 2, 3
+_NEUTRAL = (1.0, 1.0, 1.0, 0.0)
+Factor = Union[float, torch.Tensor, None]
+
+
+def _factor_column(f: Factor, B: int, device, neutral: float) -> torch.Tensor:
+    if f is None:
+        return torch.full((B,), neutral, device=device, dtype=torch.float32)
+    if isinstance(f, (int, float)):
+        return torch.full((B,), float(f), device=device, dtype=torch.float32)
+    if not isinstance(f, torch.Tensor):
+        raise TypeError(f"Factor should be float or torch.Tensor. Got {type(f)}")
+    f = f.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    if f.numel() == 1:
+        return f.expand(B)
+    if f.numel() != B:
+        raise ValueError(f"factor has {f.numel()} elements, expected 1 or the batch size {B}")
+    return f
+
+
+def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], enable: Optional[torch.Tensor] = None) -> torch.Tensor:
+    N.require_device(image, "image")
+    if not isinstance(image, torch.Tensor):
+        raise TypeError(f"Input type is not a torch.Tensor. Got {type(image)}")
+    if image.dim() < 3 or image.shape[-3] != 3:
+        raise ValueError(f"Input size must have a shape of (*, 3, H, W). Got {image.shape}")
+    if image.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise TypeError(f"color adjustments run in float32 / bfloat16 / float16 on the native path. Got {image.dtype}")
+    if image.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("kornia_amd.enhance: the fused colour kernels are forward-only (augmentation); detach the input")
+    stages = [int(s) for s in stages]
+    if len(stages) > 4 or any(s not in (0, 1, 2, 3) for s in stages) or stages.count(CONTRAST) > 1:
+        raise ValueError(f"`order` entries must be in 0..3 (brightness, contrast, saturation, hue), contrast at most once. Got {stages}")
+    shape = image.shape
+    x = image.detach().reshape(-1, 3, shape[-2], shape[-1]).contiguous()
+    B, _, H, W = x.shape
+    dev = x.device
+    params = torch.stack([_factor_column(f, B, dev, n) for f, n in zip(factors, _NEUTRAL)], dim=1).contiguous()
+    out = torch.empty_like(x)
+    gray_sum = torch.zeros(B, device=dev, dtype=torch.float64) if CONTRAST in stages else None
+    arr = (ctypes.c_int * max(len(stages), 1))(*stages)
+    if enable is not None:
+        enable = enable.detach().to(device=dev).reshape(4).ne(0).to(torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
+                                            N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
+    return out.reshape(shape)
+
+
+def adjust_brightness_accumulative(image: torch.Tensor, factor: Union[float, torch.Tensor], clip_output: bool = True) -> torch.Tensor:
+    """``clamp(image * factor, 0, 1)`` with a per-image factor."""
+    if not clip_output:
+        raise NotImplementedError("clip_output=False is not on the native path")
+    return _run(image, (factor, None, None, None), (BRIGHTNESS,))
+
+
+def adjust_contrast_with_mean_subtraction(image: torch.Tensor, factor: Union[float, torch.Tensor]) -> torch.Tensor:
+    """``clamp(image * factor + mean * (1 - factor), 0, 1)``, mean = per-image mean of the grayscale image."""
+    return _run(image, (None, factor, None, None), (CONTRAST,))
+
+
+def adjust_saturation_with_gray_subtraction(image: torch.Tensor, factor: Union[float, torch.Tensor]) -> torch.Tensor:
+    """``clamp((1 - factor) * gray(image) + factor * image, 0, 1)``."""
+    return _run(image, (None, None, factor, None), (SATURATION,))
+
+
+def adjust_hue(image: torch.Tensor, factor: Union[float, torch.Tensor]) -> torch.Tensor:
+    """Shift the hue channel by ``factor`` radians (in [-pi, pi]) through HSV."""
+    return _run(image, (None, None, None, factor), (HUE,))
+
+
+def color_jitter(image: torch.Tensor, brightness_factor: Factor = None, contrast_factor: Factor = None, saturation_factor: Factor = None,
+                 hue_factor: Factor = None, order: Optional[Sequence[int]] = None, enable: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The ColorJitter sequence in one kernel.
+
+    Factors follow ``ColorJitterGenerator`` (per-image tensors of shape (B,) or floats; ``None`` skips the stage):
+    brightness / contrast / saturation are multiplicative, ``hue_factor`` is in turns (the module multiplies it by
+    2 pi before ``adjust_hue``, color_jitter.py:147).  ``order`` is the application order as stage ids
+    0 brightness, 1 contrast, 2 saturation, 3 hue (default 0,1,2,3); stages whose factor is ``None`` are dropped.
+    ``enable``: optional (4,) device tensor indexed by stage id; a zero entry skips that stage - this is how the
+    module's ``(factor != neutral).any()`` guards are honoured without a host synchronisation.
+    """
+    given = {BRIGHTNESS: brightness_factor, CONTRAST: contrast_factor, SATURATION: saturation_factor, HUE: hue_factor}
+    order = [0, 1, 2, 3] if order is None else [int(i) for i in (order.tolist() if isinstance(order, torch.Tensor) else order)]
+    stages = [s for s in order if given.get(s) is not None]
+    hue = hue_factor
+    if hue is not None:
+        hue = hue * (2.0 * math.pi) if not isinstance(hue, torch.Tensor) else hue.float() * (2.0 * math.pi)
+    return _run(image, (brightness_factor, contrast_factor, saturation_factor, hue), stages, enable)

@@ -17,6 +17,7 @@ from typing import Callable
 
 import torch
 
+from . import enhance as _e
 from . import filters as _f
 from . import geometry as _g
 
@@ -33,9 +34,19 @@ _NATIVE = {
     "kornia.filters.filter": {"filter2d": _f.filter2d, "filter2d_separable": _f.filter2d_separable},
     "kornia.filters.gaussian": {"gaussian_blur2d": _f.gaussian_blur2d},
     "kornia.filters.sobel": {"spatial_gradient": _f.spatial_gradient, "sobel": _f.sobel},
+    # forward-only fused colour kernels (the ColorJitter leg)
+    "kornia.enhance.adjust": {
+        "adjust_brightness_accumulative": _e.adjust_brightness_accumulative,
+        "adjust_contrast_with_mean_subtraction": _e.adjust_contrast_with_mean_subtraction,
+        "adjust_saturation_with_gray_subtraction": _e.adjust_saturation_with_gray_subtraction,
+        "adjust_hue": _e.adjust_hue,
+    },
 }
+_FORWARD_ONLY = {id(f) for f in _NATIVE["kornia.enhance.adjust"].values()}
+_COLOR_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 _SUPPORTED = (torch.float32, torch.float64, torch.bfloat16, torch.float16)
 _patched: dict = {}  # id(original) -> (original, dispatcher)
+_patched_methods: list = []  # (class, attribute name, original function)
 
 
 def _use_native(args, kwargs) -> bool:
@@ -47,16 +58,55 @@ def _use_native(args, kwargs) -> bool:
     return all(t.is_cuda and t.dtype in _SUPPORTED for t in tensors if t.is_floating_point()) and any(t.is_cuda for t in tensors)
 
 
+def _use_native_color(args, kwargs) -> bool:
+    """The fused colour kernels: RGB float32/bfloat16/float16 images that do not need gradients, default options."""
+    if not _use_native(args, kwargs) or kwargs.get("clip_output", True) is not True:
+        return False
+    image = args[0] if args else kwargs.get("image")
+    if not isinstance(image, torch.Tensor) or image.dim() < 3 or image.shape[-3] != 3 or image.dtype not in _COLOR_DTYPES:
+        return False
+    tensors = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor)]
+    return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+
+
 def _dispatcher(original: Callable, native: Callable) -> Callable:
+    accept = _use_native_color if id(native) in _FORWARD_ONLY else _use_native
+
     @functools.wraps(original)
     def wrapper(*args, **kwargs):
-        if _use_native(args, kwargs):
+        if accept(args, kwargs):
             return native(*args, **kwargs)
         return original(*args, **kwargs)
 
     wrapper.__wrapped__ = original
     wrapper.__kornia_amd_native__ = native
     return wrapper
+
+
+def _color_jitter_apply(original: Callable) -> Callable:
+    """ColorJitter.apply_transform (kornia/augmentation/_2d/intensity/color_jitter.py:126-159) as ONE fused pass.
+
+    The module's per-stage ``torch.where((factor != neutral).any(), fn(img), img)`` guards become a (4,) device flag
+    vector read by the kernel, so nothing synchronises beyond what the reference's own loop over ``order`` does."""
+
+    @functools.wraps(original)
+    def apply_transform(self, input, params, flags, transform=None):
+        keys = ("brightness_factor", "contrast_factor", "saturation_factor", "hue_factor")
+        ok = (
+            isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 4 and input.shape[1] == 3
+            and input.dtype in _COLOR_DTYPES and not (torch.is_grad_enabled() and input.requires_grad)
+            and all(isinstance(params.get(k), torch.Tensor) for k in keys)
+            and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
+        )
+        if not ok:
+            return original(self, input, params, flags, transform)
+        bf, cf, sf, hf = (params[k].to(input.device) for k in keys)
+        order = self._fixed_order if getattr(self, "_fixed_order", None) is not None else params["order"].tolist()
+        enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
+        return _e.color_jitter(input, bf, cf, sf, hf, order, enable=enable)
+
+    apply_transform.__wrapped__ = original
+    return apply_transform
 
 
 def patch() -> int:
@@ -79,7 +129,13 @@ def patch() -> int:
             if hit is not None and value is hit[0]:
                 setattr(mod, attr, hit[1])
                 count += 1
-    return count
+    # ColorJitter instances bind the four adjust functions at construction and wrap each in a torch.where:
+    # replace the method so that the whole sequence is one kernel
+    cj_mod = importlib.import_module("kornia.augmentation._2d.intensity.color_jitter")
+    original = cj_mod.ColorJitter.apply_transform
+    cj_mod.ColorJitter.apply_transform = _color_jitter_apply(original)
+    _patched_methods.append((cj_mod.ColorJitter, "apply_transform", original))
+    return count + 1
 
 
 def unpatch() -> int:
@@ -96,6 +152,10 @@ def unpatch() -> int:
             if orig is not None:
                 setattr(mod, attr, orig)
                 count += 1
+    for cls, name, original in _patched_methods:
+        setattr(cls, name, original)
+        count += 1
+    _patched_methods.clear()
     _patched.clear()
     return count
 

@@ -238,6 +238,43 @@ def main():
     save("grid_sample", **dgs)
 
 
+    # ---- ColorJitter arithmetic: the reference's own functions, sequenced as apply_transform does ----
+    from kornia.constants import pi as kpi
+    from kornia.enhance.adjust import (
+        adjust_brightness_accumulative,
+        adjust_contrast_with_mean_subtraction,
+        adjust_hue,
+        adjust_saturation_with_gray_subtraction,
+    )
+
+    dc = {}
+    xc = torch.rand(4, 3, 20, 28, generator=g)
+    xc[0, :, :4, :4] = 0.5  # a grey patch: zero saturation / delta == 0 branch of rgb_to_hsv
+    xc[1, :, 0, 0] = torch.tensor([1.0, 0.0, 0.0])
+    bf = 0.6 + 0.8 * torch.rand(4, generator=g)
+    cf = 0.6 + 0.8 * torch.rand(4, generator=g)
+    sf = 0.6 + 0.8 * torch.rand(4, generator=g)
+    hf = (torch.rand(4, generator=g) - 0.5) * 0.4  # turns
+    dc.update(x=xc, bf=bf, cf=cf, sf=sf, hf=hf)
+    dc["brightness"] = adjust_brightness_accumulative(xc, bf)
+    dc["contrast"] = adjust_contrast_with_mean_subtraction(xc, cf)
+    dc["saturation"] = adjust_saturation_with_gray_subtraction(xc, sf)
+    dc["hue"] = adjust_hue(xc, hf * 2 * kpi)
+    fns = [lambda im: adjust_brightness_accumulative(im, bf), lambda im: adjust_contrast_with_mean_subtraction(im, cf),
+           lambda im: adjust_saturation_with_gray_subtraction(im, sf), lambda im: adjust_hue(im, hf * 2 * kpi)]
+    for order in ([0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 3, 0, 2]):
+        out = xc
+        for i in order:
+            out = fns[i](out)
+        dc["seq_" + "".join(map(str, order))] = out
+    # the module itself with replayed parameters (what config 3 runs)
+    aug = K.augmentation.ColorJitter(0.2, 0.2, 0.2, 0.1, p=1.0)
+    params = {"brightness_factor": bf, "contrast_factor": cf, "saturation_factor": sf, "hue_factor": hf,
+              "order": torch.tensor([2, 0, 3, 1]), "batch_prob": torch.ones(4, dtype=torch.bool), "forward_input_shape": torch.tensor(xc.shape)}
+    dc["module_2031"] = aug(xc, params=params)
+    save("color_jitter", **dc)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     main()

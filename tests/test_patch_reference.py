@@ -34,6 +34,14 @@ def test_patch_and_unpatch():
         aug = K.augmentation.RandomAffine(degrees=10.0, p=1.0)
         assert aug(x).shape == x.shape
         assert torch.equal(K.filters.sobel(x), K.filters.sobel.__wrapped__(x))
+        # ColorJitter: the method is replaced, CPU tensors still run Kornia's own loop (same result as unpatched)
+        import kornia.augmentation._2d.intensity.color_jitter as cj_mod
+
+        assert cj_mod.ColorJitter.apply_transform.__wrapped__ is not None
+        assert K.enhance.adjust.adjust_hue.__wrapped__ is not None
+        cj = K.augmentation.ColorJitter(0.2, 0.2, 0.2, 0.1, p=1.0)
+        y = cj(x)
+        assert torch.equal(y, cj_mod.ColorJitter.apply_transform.__wrapped__(cj, x, cj._params, cj.flags))
     finally:
         assert P.unpatch() == n
     assert aff_mod.warp_affine is orig and not P.is_patched()
