@@ -79,6 +79,16 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
  * 0 if it overwrites gsrc completely (tile-owner path: bilinear, zeros/fill padding, dtype != f64). */
 int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype);
 
+/* ---- augmentation parameters -> matrix ---------------------------------------------------------
+ * Replaces get_affine_matrix2d (kornia/geometry/transform/imgwarp.py:746-787; get_rotation_matrix2d :529-622,
+ * get_shear_matrix2d :815-869, angle_to_rotation_matrix kornia/geometry/conversions.py:1652-1688) as called by
+ * RandomAffine.compute_transformation (kornia/augmentation/_2d/geometric/affine.py:125-141): one launch, one
+ * thread per matrix, instead of ~45 elementwise / bmm launches.
+ *   translations, center, scale (B,2); angle (B) degrees; sx, sy (B) shear angles in radians or NULL;
+ *   out (B,3,3) pixel matrix; dtype KM_F32 or KM_F64 (all operands in that dtype). */
+int km_affine_matrix2d_fwd(const void* translations, const void* center, const void* scale, const void* angle, const void* sx,
+                           const void* sy, void* out, int B, int dtype, void* stream);
+
 /* ---- explicit sampling grid ------------------------------------------------------------------
  * Replaces F.grid_sample(input, grid, mode, padding_mode, align_corners) as called by remap
  * (kornia/geometry/transform/imgwarp.py:702) and by HomographyWarper's cached-grid forward

@@ -167,6 +167,75 @@ static int km_chain_run(bool bwd, const void* M, int rows, void* A, void* m, con
     return km_check_launch(bwd ? "km_homography_chain_bwd" : "km_homography_chain_fwd");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// get_affine_matrix2d (kornia/geometry/transform/imgwarp.py:746-787) in one launch: the matrix RandomAffine builds
+// from (translations, center, scale, angle, shear) with ~45 tiny PyTorch launches
+// (kornia/augmentation/_2d/geometric/affine.py:125-141 -> get_rotation_matrix2d :529-622 -> angle_to_rotation_matrix
+// conversions.py:1652-1688, get_shear_matrix2d :815-869).  One thread per matrix, the reference's own sequence:
+//   R = (T(c) @ Rot(-angle)) @ S(scale) @ T(-c), R[:, 2] += t, optionally @ Shear(c, sx, sy); 3x3 products as the
+//   k-ordered mul/add chain of km_mm3; degrees -> radians with the float32 pi the reference uses.
+template <typename R>
+struct KmAffineArgs {
+    const R* trans;   // (B,2)
+    const R* center;  // (B,2)
+    const R* scale;   // (B,2)
+    const R* angle;   // (B) degrees, clockwise-positive (negated before the rotation, imgwarp.py:778)
+    const R* sx;      // (B) radians, nullable
+    const R* sy;      // (B) radians, nullable
+    R* out;           // (B,9)
+    int B;
+};
+
+__device__ __forceinline__ float km_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double km_sin(double x) { return sin(x); }
+__device__ __forceinline__ float km_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double km_cos(double x) { return cos(x); }
+__device__ __forceinline__ float km_tan(float x) { return tanf(x); }
+__device__ __forceinline__ double km_tan(double x) { return tan(x); }
+
+template <typename R>
+__global__ __launch_bounds__(64) void km_affine_matrix2d_kernel(const KmAffineArgs<R> a) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const R cx = a.center[2 * b], cy = a.center[2 * b + 1];
+    // deg2rad(-angle): tensor * pi.type(dtype) / 180 with pi a float32 constant (conversions.py:148, constants.py:25)
+    const R pi32 = (R)3.14159265358979323846f;
+    const R rad = ((-a.angle[b]) * pi32) / (R)180.0;
+    const R c = km_cos(rad), s = km_sin(rad);
+    const R shift[9] = {1, 0, cx, 0, 1, cy, 0, 0, 1};
+    const R shift_inv[9] = {1, 0, -cx, 0, 1, -cy, 0, 0, 1};
+    const R rot[9] = {c, s, 0, -s, c, 0, 0, 0, 1};
+    const R scl[9] = {a.scale[2 * b], 0, 0, 0, a.scale[2 * b + 1], 0, 0, 0, 1};
+    R t0[9], t1[9], m[9];
+    km_mm3(shift, rot, t0);
+    km_mm3(t0, scl, t1);
+    km_mm3(t1, shift_inv, m);
+    m[2] = m[2] + a.trans[2 * b];
+    m[5] = m[5] + a.trans[2 * b + 1];
+    m[6] = 0; m[7] = 0; m[8] = 1;  // convert_affinematrix_to_homography of the (2,3) block
+    if (a.sx || a.sy) {
+        const R tx = a.sx ? km_tan(a.sx[b]) : km_tan((R)0), ty = a.sy ? km_tan(a.sy[b]) : km_tan((R)0);
+        const R sh[9] = {1, -tx, tx * cy, -ty, (R)1 + tx * ty, ty * (cx - tx * cy), 0, 0, 1};
+        R o[9];
+        km_mm3(m, sh, o);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.out[(size_t)b * 9 + k] = m[k];
+}
+
+template <typename R>
+static int km_affine_run(const void* trans, const void* center, const void* scale, const void* angle, const void* sx, const void* sy,
+                         void* out, int B, hipStream_t s) {
+    KmAffineArgs<R> a;
+    a.trans = (const R*)trans; a.center = (const R*)center; a.scale = (const R*)scale; a.angle = (const R*)angle;
+    a.sx = (const R*)sx; a.sy = (const R*)sy; a.out = (R*)out; a.B = B;
+    hipLaunchKernelGGL(km_affine_matrix2d_kernel<R>, dim3((B + 63) / 64), dim3(64), 0, s, a);
+    return km_check_launch("km_affine_matrix2d_fwd");
+}
+
 extern "C" {
 
 // M: (B,rows,3) pixel src->dst matrix, rows in {2,3}; A_out/m_out: (B,9), either may be null.
@@ -191,6 +260,17 @@ int km_homography_chain_bwd(const void* M, int rows, const double* gm, void* gM,
     KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_homography_chain_bwd: dtype must be f32/f64");
     if (dtype == KM_F32) return km_chain_run<float>(true, M, rows, nullptr, nullptr, gm, gM, B, Hs, Ws, hd, wd, (hipStream_t)stream);
     return km_chain_run<double>(true, M, rows, nullptr, nullptr, gm, gM, B, Hs, Ws, hd, wd, (hipStream_t)stream);
+}
+
+// translations / center / scale (B,2), angle (B) degrees, sx / sy (B) radians or null -> out (B,3,3); dtype f32 / f64.
+int km_affine_matrix2d_fwd(const void* translations, const void* center, const void* scale, const void* angle, const void* sx,
+                           const void* sy, void* out, int B, int dtype, void* stream) {
+    if (B == 0) return 0;
+    KM_REQUIRE(translations && center && scale && angle && out, "km_affine_matrix2d_fwd: null pointer");
+    KM_REQUIRE(B > 0, "km_affine_matrix2d_fwd: bad batch size %d", B);
+    KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_affine_matrix2d_fwd: dtype must be f32/f64");
+    if (dtype == KM_F32) return km_affine_run<float>(translations, center, scale, angle, sx, sy, out, B, (hipStream_t)stream);
+    return km_affine_run<double>(translations, center, scale, angle, sx, sy, out, B, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -166,6 +166,32 @@ def get_shear_matrix2d(
     return _to_homography(A)
 
 
+def _affine_matrix2d_native(translations, center, scale, angle, sx, sy):
+    from ... import _native as N
+
+    tensors = [t for t in (translations, center, scale, angle, sx, sy) if t is not None]
+    if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) or not N.is_built():
+        return None
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return None
+    dtype = translations.dtype
+    if dtype not in (torch.float32, torch.float64, torch.bfloat16, torch.float16) or any(t.dtype != dtype for t in tensors):
+        return None
+    B = translations.shape[0]
+    if translations.shape != (B, 2) or center.shape != (B, 2) or scale.shape != (B, 2) or angle.shape != (B,):
+        return None
+    if any(t is not None and t.shape != (B,) for t in (sx, sy)):
+        return None
+    cdt = torch.float64 if dtype == torch.float64 else torch.float32
+    dev = translations.device
+    args = [None if t is None else t.detach().to(cdt).contiguous() for t in (translations, center, scale, angle, sx, sy)]
+    out = torch.empty(B, 3, 3, device=dev, dtype=cdt)
+    with torch.cuda.device(dev):
+        N.check(N.lib().km_affine_matrix2d_fwd(*[N.ptr(t) for t in args], out.data_ptr(), B, N.dtype_code(cdt), N.stream_ptr(dev)),
+                "km_affine_matrix2d_fwd")
+    return out.to(dtype)
+
+
 def get_affine_matrix2d(
     translations: torch.Tensor,
     center: torch.Tensor,
@@ -175,7 +201,13 @@ def get_affine_matrix2d(
     sy: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """(B,3,3) pixel affine: rotation by ``-angle`` (clockwise-positive) and scale about ``center``, then
-    translation, optionally right-multiplied by the shear about ``center``."""
+    translation, optionally right-multiplied by the shear about ``center``.
+
+    HIP tensors that need no gradient are built by ``km_affine_matrix2d_fwd`` (one launch, the reference's own
+    operation sequence); anything else takes the closed-form tensor expression below."""
+    native = _affine_matrix2d_native(translations, center, scale, angle, sx, sy)
+    if native is not None:
+        return native
     A = get_rotation_matrix2d(center, -angle, scale)
     A = torch.cat([A[..., :2], A[..., 2:] + translations[..., None]], dim=-1)
     H = _to_homography(A)
