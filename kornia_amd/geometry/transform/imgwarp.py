@@ -4,7 +4,8 @@ Same signatures, defaults, argument meaning and error behaviour as the reference
 (kornia/geometry/transform/imgwarp.py:69-174, :177-290, :323-353, :1476-1549).  What differs is the
 execution: one HIP launch for the 3x3 chain and one for coordinate generation + sampling, instead
 of ~25 elementwise launches that build a (B,h,w,2) grid in HBM followed by ``F.grid_sample``; the
-backward is one launch for both gradients plus the tiny chain adjoint.
+backward is one launch per gradient (image: tile-owner scatter; matrix: forward-shaped reduction) plus the tiny chain
+adjoint.
 
 There is no PyTorch/CPU fallback: tensors must live on a HIP device.
 """
