@@ -249,57 +249,69 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
     T* __restrict__ dst_b = a.dst + (size_t)b * C * dst_plane;
     const R u = km_base_x<R, CM>(g, j);
 
+    // The kernel is bound by memory latency, not bandwidth or ALU (38 VGPRs, one row's 6 loads in flight per wave when the
+    // rows are processed one after the other): all KM_ROWS sampling positions are computed first, then - when every lane of
+    // the wave samples inside the image for all of them - all their loads are issued back to back before the first use.
+    KmBilin<R> t[KM_ROWS];
+    bool row_ok[KM_ROWS];
+    bool inside = true;
 #pragma unroll
     for (int r = 0; r < KM_ROWS; ++r) {
         const int i = i_base + r * PH;
-        const bool row_ok = i < g.h;
+        row_ok[r] = i < g.h;
         KmCoord<R> cd;
         km_gen_coord<R, CM>(m, u, s_v[li_base + r * PH], cd);
-        if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, row_ok ? i : 0, j, cd);
+        if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, row_ok[r] ? i : 0, j, cd);
         R mx, my;
         const R x = km_unnormalize(cd.gx, W, align, mx);
         const R y = km_unnormalize(cd.gy, H, align, my);
-        KmBilin<R> t;
-        km_bilinear_setup(x, y, W, H, t);
-        T* __restrict__ out_px = dst_b + (size_t)(row_ok ? i : 0) * g.w + j;
-        if (__all(t.b00 && t.b01 && t.b10 && t.b11)) {
-            if (NC == 3) {
-                R a00, a01, a10, a11, b00, b01, b10, b11, c00, c01, c10, c11;
-                km_ld2(src_b + t.i00, a00, a01);
-                km_ld2(src_b + t.i10, a10, a11);
-                km_ld2(src_b + src_plane + t.i00, b00, b01);
-                km_ld2(src_b + src_plane + t.i10, b10, b11);
-                km_ld2(src_b + 2 * src_plane + t.i00, c00, c01);
-                km_ld2(src_b + 2 * src_plane + t.i10, c10, c11);
-                const R ra = km_fma(a11, t.w11, km_fma(a10, t.w10, km_fma(a01, t.w01, km_fma(a00, t.w00, (R)0))));
-                const R rb = km_fma(b11, t.w11, km_fma(b10, t.w10, km_fma(b01, t.w01, km_fma(b00, t.w00, (R)0))));
-                const R rc = km_fma(c11, t.w11, km_fma(c10, t.w10, km_fma(c01, t.w01, km_fma(c00, t.w00, (R)0))));
-                if (row_ok) {
-                    km_st(out_px, ra);
-                    km_st(out_px + dst_plane, rb);
-                    km_st(out_px + 2 * dst_plane, rc);
-                }
-            } else {
-                for (int c = 0; c < C; ++c) {
-                    const T* img = src_b + (size_t)c * src_plane;
-                    R v00, v01, v10, v11;
-                    km_ld2(img + t.i00, v00, v01);
-                    km_ld2(img + t.i10, v10, v11);
-                    const R acc = km_fma(v11, t.w11, km_fma(v10, t.w10, km_fma(v01, t.w01, km_fma(v00, t.w00, (R)0))));
-                    if (row_ok) km_st(out_px + (size_t)c * dst_plane, acc);
-                }
+        km_bilinear_setup(x, y, W, H, t[r]);
+        inside = inside && t[r].b00 && t[r].b01 && t[r].b10 && t[r].b11;
+    }
+    if (NC == 3 && __all(inside)) {
+        R v[KM_ROWS][3][4];
+#pragma unroll
+        for (int r = 0; r < KM_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                km_ld2(src_b + c * src_plane + t[r].i00, v[r][c][0], v[r][c][1]);
+                km_ld2(src_b + c * src_plane + t[r].i10, v[r][c][2], v[r][c][3]);
+            }
+#pragma unroll
+        for (int r = 0; r < KM_ROWS; ++r) {
+            T* __restrict__ out_px = dst_b + (size_t)(row_ok[r] ? i_base + r * PH : 0) * g.w + j;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const R acc = km_fma(v[r][c][3], t[r].w11, km_fma(v[r][c][2], t[r].w10, km_fma(v[r][c][1], t[r].w01, km_fma(v[r][c][0], t[r].w00, (R)0))));
+                if (row_ok[r]) km_st(out_px + c * dst_plane, acc);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < KM_ROWS; ++r) {
+        T* __restrict__ out_px = dst_b + (size_t)(row_ok[r] ? i_base + r * PH : 0) * g.w + j;
+        const KmBilin<R>& tr = t[r];
+        if (__all(tr.b00 && tr.b01 && tr.b10 && tr.b11)) {
+            for (int c = 0; c < C; ++c) {
+                const T* img = src_b + (size_t)c * src_plane;
+                R v00, v01, v10, v11;
+                km_ld2(img + tr.i00, v00, v01);
+                km_ld2(img + tr.i10, v10, v11);
+                const R acc = km_fma(v11, tr.w11, km_fma(v10, tr.w10, km_fma(v01, tr.w01, km_fma(v00, tr.w00, (R)0))));
+                if (row_ok[r]) km_st(out_px + (size_t)c * dst_plane, acc);
             }
         } else {
             for (int c = 0; c < C; ++c) {
                 const T* img = src_b + (size_t)c * src_plane;
-                const R v00 = km_ld(img + t.i00), v01 = km_ld(img + t.i01);
-                const R v10 = km_ld(img + t.i10), v11 = km_ld(img + t.i11);
+                const R v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01);
+                const R v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
                 R acc = 0;
-                acc = t.b00 ? km_fma(v00, t.w00, acc) : acc;
-                acc = t.b01 ? km_fma(v01, t.w01, acc) : acc;
-                acc = t.b10 ? km_fma(v10, t.w10, acc) : acc;
-                acc = t.b11 ? km_fma(v11, t.w11, acc) : acc;
-                if (row_ok) km_st(out_px + (size_t)c * dst_plane, acc);
+                acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
+                acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
+                acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
+                acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+                if (row_ok[r]) km_st(out_px + (size_t)c * dst_plane, acc);
             }
         }
     }
