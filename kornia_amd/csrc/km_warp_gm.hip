@@ -22,6 +22,9 @@
 #define KMG_ROWS 16
 #endif
 #define KMG_TILE_W 64
+#ifndef KMG_GROUP
+#define KMG_GROUP 2   // rows whose loads are in flight together
+#endif
 #ifndef KMG_PATCH_W
 #define KMG_PATCH_W 32  // measured at 256x3x512^2: 64 -> 0.375 ms (0.83 at 20 deg, 1.32 at 45 deg), 32 -> 0.368 (0.60, 0.84), 16 -> 0.412 (0.57, 0.68)
 #endif
@@ -77,78 +80,93 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
     // thread's rows and multiply by u once at the end
     R S[3] = {0, 0, 0}, Sv[3] = {0, 0, 0};
 
-#pragma unroll 2
-    for (int r = 0; r < KMG_ROWS; ++r) {
-        const int i = i_base + r * PH;
-        const bool ok = col_ok && (i < g.h);
-        KmCoord<R> cd;
-        km_gen_coord<R, CM>(m, u, s_v[li_base + r * PH], cd);
-        R mx, my;
-        const R x = km_unnormalize(cd.gx, W, align, mx);
-        const R y = km_unnormalize(cd.gy, H, align, my);
-        KmBilin<R> t;
-        km_bilinear_setup(x, y, W, H, t);
-        const uint32_t go_off = ok ? (uint32_t)i * (uint32_t)g.w + (uint32_t)j : 0u;
-        R gix = 0, giy = 0;
-        if (__all(t.b00 && t.b01 && t.b10 && t.b11)) {
-            // the whole wave samples inside the image: (x0, x0 + 1) come with one load per row
-            if (NC == 3) {
-                const R g0 = (R)km_ld(km_at(gout_b, go_off)), g1 = (R)km_ld(km_at(gout_b + dst_plane, go_off));
-                const R g2 = (R)km_ld(km_at(gout_b + 2 * dst_plane, go_off));
-                R a00, a01, a10, a11, b00, b01, b10, b11, c00, c01, c10, c11;
-                km_ld2(km_at(src_b, (uint32_t)t.i00), a00, a01);
-                km_ld2(km_at(src_b, (uint32_t)t.i10), a10, a11);
-                km_ld2(km_at(src_b + src_plane, (uint32_t)t.i00), b00, b01);
-                km_ld2(km_at(src_b + src_plane, (uint32_t)t.i10), b10, b11);
-                km_ld2(km_at(src_b + 2 * src_plane, (uint32_t)t.i00), c00, c01);
-                km_ld2(km_at(src_b + 2 * src_plane, (uint32_t)t.i10), c10, c11);
-                if (is_fill) {  // same rounding sequence as the oracle: (v - fill) first
-                    const R f0 = a.fill[0], f1 = a.fill[1], f2 = a.fill[2];
-                    a00 -= f0; a01 -= f0; a10 -= f0; a11 -= f0;
-                    b00 -= f1; b01 -= f1; b10 -= f1; b11 -= f1;
-                    c00 -= f2; c01 -= f2; c10 -= f2; c11 -= f2;
+    // rows are taken KMG_GROUP at a time: all their sampling positions first, then - when every lane samples inside the
+    // image for all of them - all their loads back to back before the first use (memory-latency bound otherwise)
+    for (int r0 = 0; r0 < KMG_ROWS; r0 += KMG_GROUP) {
+        KmCoord<R> cd[KMG_GROUP];
+        KmBilin<R> t[KMG_GROUP];
+        R mx[KMG_GROUP], my[KMG_GROUP], gix[KMG_GROUP], giy[KMG_GROUP];
+        uint32_t go_off[KMG_GROUP];
+        bool ok[KMG_GROUP];
+        bool inside = true;
+#pragma unroll
+        for (int q = 0; q < KMG_GROUP; ++q) {
+            const int i = i_base + (r0 + q) * PH;
+            ok[q] = col_ok && (i < g.h);
+            km_gen_coord<R, CM>(m, u, s_v[li_base + (r0 + q) * PH], cd[q]);
+            const R x = km_unnormalize(cd[q].gx, W, align, mx[q]);
+            const R y = km_unnormalize(cd[q].gy, H, align, my[q]);
+            km_bilinear_setup(x, y, W, H, t[q]);
+            go_off[q] = ok[q] ? (uint32_t)i * (uint32_t)g.w + (uint32_t)j : 0u;
+            inside = inside && t[q].b00 && t[q].b01 && t[q].b10 && t[q].b11;
+            gix[q] = 0;
+            giy[q] = 0;
+        }
+        if (NC == 3 && __all(inside)) {
+            R go[KMG_GROUP][3], v[KMG_GROUP][3][4];
+#pragma unroll
+            for (int q = 0; q < KMG_GROUP; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    go[q][c] = (R)km_ld(km_at(gout_b + c * dst_plane, go_off[q]));
+                    km_ld2(km_at(src_b + c * src_plane, (uint32_t)t[q].i00), v[q][c][0], v[q][c][1]);
+                    km_ld2(km_at(src_b + c * src_plane, (uint32_t)t[q].i10), v[q][c][2], v[q][c][3]);
                 }
-                gix = km_fma(g0, km_fma(a01 - a00, t.wy1, (a11 - a10) * t.wy0), gix);
-                giy = km_fma(g0, km_fma(a10 - a00, t.wx1, (a11 - a01) * t.wx0), giy);
-                gix = km_fma(g1, km_fma(b01 - b00, t.wy1, (b11 - b10) * t.wy0), gix);
-                giy = km_fma(g1, km_fma(b10 - b00, t.wx1, (b11 - b01) * t.wx0), giy);
-                gix = km_fma(g2, km_fma(c01 - c00, t.wy1, (c11 - c10) * t.wy0), gix);
-                giy = km_fma(g2, km_fma(c10 - c00, t.wx1, (c11 - c01) * t.wx0), giy);
-            } else {
-                for (int c = 0; c < C; ++c) {
-                    const R go = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off));
-                    const T* img = src_b + (size_t)c * src_plane;
-                    R s00, s01, s10, s11;
-                    km_ld2(km_at(img, (uint32_t)t.i00), s00, s01);
-                    km_ld2(km_at(img, (uint32_t)t.i10), s10, s11);
-                    if (is_fill) {
+#pragma unroll
+            for (int q = 0; q < KMG_GROUP; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    R s00 = v[q][c][0], s01 = v[q][c][1], s10 = v[q][c][2], s11 = v[q][c][3];
+                    if (is_fill) {  // same rounding sequence as the oracle: (v - fill) first
                         const R f = a.fill[c];
                         s00 -= f; s01 -= f; s10 -= f; s11 -= f;
                     }
-                    gix = km_fma(go, km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-                    giy = km_fma(go, km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
+                    gix[q] = km_fma(go[q][c], km_fma(s01 - s00, t[q].wy1, (s11 - s10) * t[q].wy0), gix[q]);
+                    giy[q] = km_fma(go[q][c], km_fma(s10 - s00, t[q].wx1, (s11 - s01) * t[q].wx0), giy[q]);
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < KMG_GROUP; ++q) {
+                const KmBilin<R>& tq = t[q];
+                if (__all(tq.b00 && tq.b01 && tq.b10 && tq.b11)) {
+                    // the whole wave samples inside the image for this row: (x0, x0 + 1) come with one load per row
+                    for (int c = 0; c < C; ++c) {
+                        const R gv = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off[q]));
+                        const T* img = src_b + (size_t)c * src_plane;
+                        R s00, s01, s10, s11;
+                        km_ld2(km_at(img, (uint32_t)tq.i00), s00, s01);
+                        km_ld2(km_at(img, (uint32_t)tq.i10), s10, s11);
+                        if (is_fill) {
+                            const R f = a.fill[c];
+                            s00 -= f; s01 -= f; s10 -= f; s11 -= f;
+                        }
+                        gix[q] = km_fma(gv, km_fma(s01 - s00, tq.wy1, (s11 - s10) * tq.wy0), gix[q]);
+                        giy[q] = km_fma(gv, km_fma(s10 - s00, tq.wx1, (s11 - s01) * tq.wx0), giy[q]);
+                    }
+                } else {
+                    for (int c = 0; c < C; ++c) {
+                        const R gv = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off[q]));
+                        const T* img = src_b + (size_t)c * src_plane;
+                        const R f = is_fill ? a.fill[c] : (R)0;
+                        // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
+                        const R v00 = (R)km_ld(img + tq.i00), v01 = (R)km_ld(img + tq.i01), v10 = (R)km_ld(img + tq.i10), v11 = (R)km_ld(img + tq.i11);
+                        const R s00 = tq.b00 ? v00 - f : (R)0, s01 = tq.b01 ? v01 - f : (R)0;
+                        const R s10 = tq.b10 ? v10 - f : (R)0, s11 = tq.b11 ? v11 - f : (R)0;
+                        gix[q] = km_fma(gv, km_fma(s01 - s00, tq.wy1, (s11 - s10) * tq.wy0), gix[q]);
+                        giy[q] = km_fma(gv, km_fma(s10 - s00, tq.wx1, (s11 - s01) * tq.wx0), giy[q]);
+                    }
                 }
             }
-        } else {
-            for (int c = 0; c < C; ++c) {
-                const R go = (R)km_ld(km_at(gout_b + (size_t)c * dst_plane, go_off));
-                const T* img = src_b + (size_t)c * src_plane;
-                const R f = is_fill ? a.fill[c] : (R)0;
-                // unconditional loads (clamped indices); out-of-bounds taps do not exist in the reference's sum
-                const R v00 = (R)km_ld(img + t.i00), v01 = (R)km_ld(img + t.i01), v10 = (R)km_ld(img + t.i10), v11 = (R)km_ld(img + t.i11);
-                const R s00 = t.b00 ? v00 - f : (R)0, s01 = t.b01 ? v01 - f : (R)0;
-                const R s10 = t.b10 ? v10 - f : (R)0, s11 = t.b11 ? v11 - f : (R)0;
-                gix = km_fma(go, km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-                giy = km_fma(go, km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
-            }
         }
-        // pixels outside the output (padding lanes / rows of the last tiles) contribute nothing
-        gix = ok ? gix * mx : (R)0;
-        giy = ok ? giy * my : (R)0;
-        R ax, ay, az;
-        km_gm_terms<CM>(cd, gix, giy, ax, ay, az);
-        S[0] += ax; S[1] += ay; S[2] += az;
-        Sv[0] = km_fma(ax, cd.v, Sv[0]); Sv[1] = km_fma(ay, cd.v, Sv[1]); Sv[2] = km_fma(az, cd.v, Sv[2]);
+#pragma unroll
+        for (int q = 0; q < KMG_GROUP; ++q) {
+            // pixels outside the output (padding lanes / rows of the last tiles) contribute nothing
+            const R gx_ = ok[q] ? gix[q] * mx[q] : (R)0, gy_ = ok[q] ? giy[q] * my[q] : (R)0;
+            R ax, ay, az;
+            km_gm_terms<CM>(cd[q], gx_, gy_, ax, ay, az);
+            S[0] += ax; S[1] += ay; S[2] += az;
+            Sv[0] = km_fma(ax, cd[q].v, Sv[0]); Sv[1] = km_fma(ay, cd[q].v, Sv[1]); Sv[2] = km_fma(az, cd[q].v, Sv[2]);
+        }
     }
     R gm[9];
 #pragma unroll
