@@ -267,16 +267,20 @@ __device__ __forceinline__ void kmt_coord(const float (&m)[9], const float4 cu, 
 
 // one output pixel of the scatter pass.  Branch-free up to the (exec-masked) atomics: every load is unconditional
 // so that the loads of the pixels processed back to back can be in flight together.
-template <typename T, int CM, int ALIGN>
-__device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const float (&m)[9], int qi, int qj, bool valid, int j0, int ib,
-                                             const float4* s_u4, const float4* s_v4, int* s_acc, bool finite, float scale,
-                                             int cc, const T* const (&gout_c)[KMT_CC], int X0, int TWc, int Y0, int THc, uint32_t& seen_bits) {
-    typedef float R;
-    const int jj = j0 + qj, ii = ib + qi;
-    const uint32_t off = (uint32_t)ii * (uint32_t)g.w + (uint32_t)jj;  // the host guarantees 4 * h * w < 2^32
-    R go[KMT_CC];
+// grad_out of one output pixel, all channels of the chunk (issued for every pixel of an unrolled group before any is used)
+template <typename T>
+__device__ __forceinline__ void kmt_load_go(const KmWarpGeom<float>& g, int qi, int qj, int j0, int ib, const T* const (&gout_c)[KMT_CC],
+                                           float (&go)[KMT_CC]) {
+    const uint32_t off = (uint32_t)(ib + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);  // the host guarantees 4 * h * w < 2^32
 #pragma unroll
-    for (int c = 0; c < KMT_CC; ++c) go[c] = (R)km_ld(km_at(gout_c[c], off));  // channels >= cc alias channel cc-1 (never used)
+    for (int c = 0; c < KMT_CC; ++c) go[c] = (float)km_ld(km_at(gout_c[c], off));  // channels >= cc alias channel cc-1 (never used)
+}
+
+template <typename T, int CM, int ALIGN>
+__device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const float (&m)[9], int qi, int qj, bool valid, const float (&go)[KMT_CC],
+                                             const float4* s_u4, const float4* s_v4, int* s_acc, bool finite, float scale,
+                                             int cc, int X0, int TWc, int Y0, int THc, uint32_t& seen_bits) {
+    typedef float R;
     // the fixed-point scale was chosen for |grad_out| <= bound: remember the largest magnitude seen, as an integer
     // (sign cleared, IEEE bit patterns order like unsigned integers and NaN / inf sort above every finite value)
     {
@@ -509,17 +513,25 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
                         if (qj >= bwb) { qi += 1; qj -= bwb; }
                         int base = 0;
                         for (; base + KMT_UNROLL * KMT_NT <= nq; base += KMT_UNROLL * KMT_NT) {
+                            int pqi[KMT_UNROLL], pqj[KMT_UNROLL];
+                            R go[KMT_UNROLL][KMT_CC];
 #pragma unroll
-                            for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {
-                                kmt_scatter_q<T, CM, ALIGN>(g, m, qi, qj, true, jb, ib, s_u4, s_v4, s_acc, finite, scale, cc, gout_c, X0, TWc, Y0, THc,
-                                                            seen_bits);
+                            for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {  // all loads of the group first
+                                pqi[s4] = qi; pqj[s4] = qj;
+                                kmt_load_go<T>(g, qi, qj, jb, ib, gout_c, go[s4]);
                                 kmt_advance(qi, qj, di, dj, bwb);
                             }
+#pragma unroll
+                            for (int s4 = 0; s4 < KMT_UNROLL; ++s4)
+                                kmt_scatter_q<T, CM, ALIGN>(g, m, pqi[s4], pqj[s4], true, go[s4], s_u4, s_v4, s_acc, finite, scale, cc, X0, TWc, Y0, THc,
+                                                            seen_bits);
                         }
                         for (; base < nq; base += KMT_NT) {
                             const bool valid = base + tid < nq;
-                            kmt_scatter_q<T, CM, ALIGN>(g, m, valid ? qi : 0, valid ? qj : 0, valid, jb, ib, s_u4, s_v4, s_acc, finite, scale, cc, gout_c,
-                                                        X0, TWc, Y0, THc, seen_bits);
+                            const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
+                            R go[KMT_CC];
+                            kmt_load_go<T>(g, vqi, vqj, jb, ib, gout_c, go);
+                            kmt_scatter_q<T, CM, ALIGN>(g, m, vqi, vqj, valid, go, s_u4, s_v4, s_acc, finite, scale, cc, X0, TWc, Y0, THc, seen_bits);
                             kmt_advance(qi, qj, di, dj, bwb);
                         }
                     }
