@@ -351,47 +351,79 @@ __device__ __forceinline__ int km_preimages(int p, int n, int l, int r, int bord
 
 #define KM_MAX_PRE 64
 
+// adjoint of the padded correlation at one input pixel (py, px) of plane bc: every padded coordinate that the border
+// map sends to (py, px) (the pixel itself + its pre-images) collects  sum_{p,q} k[p][q] * gy[s + pad - (p,q)]
+template <typename T>
+__device__ __forceinline__ typename KmTraits<T>::R km_f2d_adjoint_pixel(const KmFullArgs<T>& a, uint32_t bc, int py, int px) {
+    typedef typename KmTraits<T>::R R;
+    const KmFilterGeom& g = a.g;
+    const int b = bc / g.C;
+    const T* gy = a.gy + (size_t)bc * g.Ho * g.Wo;
+    const R* kk = a.k + (size_t)(b % g.Bk) * g.kH * g.kW;
+    const int rb = g.same ? g.kH - 1 - g.pt : 0, rr = g.same ? g.kW - 1 - g.pl : 0;
+    int sxs[KM_MAX_PRE], sys[KM_MAX_PRE];
+    const int nsx = km_preimages(px, g.W, g.pl, rr, g.border, g.same, sxs, KM_MAX_PRE);
+    const int nsy = km_preimages(py, g.H, g.pt, rb, g.border, g.same, sys, KM_MAX_PRE);
+    R acc = 0;
+    for (int iy = 0; iy < nsy; ++iy)
+        for (int ix = 0; ix < nsx; ++ix) {
+            // G[sy][sx] = sum_{p,q} k[p][q] * gy0[sy + pt - p][sx + pl - q]
+            const int sy = sys[iy], sx = sxs[ix];
+            for (int p = 0; p < g.kH; ++p) {
+                const int oy = sy + g.pt - p;
+                if (oy < 0 || oy >= g.Ho) continue;
+                for (int q = 0; q < g.kW; ++q) {
+                    const int ox = sx + g.pl - q;
+                    if (ox < 0 || ox >= g.Wo) continue;
+                    acc = km_fma(kk[p * g.kW + q], (R)km_ld(gy + (size_t)oy * g.Wo + ox), acc);
+                }
+            }
+        }
+    return acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void km_filter2d_bwd_input_kernel(const KmFullArgs<T> a) {
-    typedef typename KmTraits<T>::R R;
     const KmFilterGeom& g = a.g;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t bc = bid / a.tiles_y;
-    const int b = bc / g.C;
     const int px = tx * 64 + (threadIdx.x & 63);
     const int py0 = ty * 16 + (threadIdx.x >> 6) * 4;
     if (px >= g.W) return;
-    const T* gy = a.gy + (size_t)bc * g.Ho * g.Wo;
     T* gx = a.y + (size_t)bc * g.H * g.W;
-    const R* kk = a.k + (size_t)(b % g.Bk) * g.kH * g.kW;
-    const int rb = g.same ? g.kH - 1 - g.pt : 0, rr = g.same ? g.kW - 1 - g.pl : 0;
-    int sxs[KM_MAX_PRE];
-    const int nsx = km_preimages(px, g.W, g.pl, rr, g.border, g.same, sxs, KM_MAX_PRE);
     for (int r = 0; r < 4; ++r) {
         const int py = py0 + r;
         if (py >= g.H) break;
-        int sys[KM_MAX_PRE];
-        const int nsy = km_preimages(py, g.H, g.pt, rb, g.border, g.same, sys, KM_MAX_PRE);
-        R acc = 0;
-        for (int iy = 0; iy < nsy; ++iy)
-            for (int ix = 0; ix < nsx; ++ix) {
-                // G[sy][sx] = sum_{p,q} k[p][q] * gy0[sy + pt - p][sx + pl - q]
-                const int sy = sys[iy], sx = sxs[ix];
-                for (int p = 0; p < g.kH; ++p) {
-                    const int oy = sy + g.pt - p;
-                    if (oy < 0 || oy >= g.Ho) continue;
-                    for (int q = 0; q < g.kW; ++q) {
-                        const int ox = sx + g.pl - q;
-                        if (ox < 0 || ox >= g.Wo) continue;
-                        acc = km_fma(kk[p * g.kW + q], (R)km_ld(gy + (size_t)oy * g.Wo + ox), acc);
-                    }
-                }
-            }
-        km_st(gx + (size_t)py * g.W + px, acc);
+        km_st(gx + (size_t)py * g.W + px, km_f2d_adjoint_pixel<T>(a, bc, py, px));
     }
+}
+
+// The adjoint differs from "correlate the zero-extended gradient with the rotated taps" only within pad pixels of an
+// image edge (where padded coordinates fold back).  This kernel recomputes exactly that frame (pd = pad + 1 pixels wide:
+// 2*pd*(W + H - 2*pd) pixels per plane) - after the register-tiled kernel (km_filter2d_fast.hip) has produced the interior.
+template <typename T>
+__global__ __launch_bounds__(256) void km_filter2d_bwd_frame_kernel(const KmFullArgs<T> a, int pd, uint32_t frame_px, uint32_t blocks_per_plane) {
+    const KmFilterGeom& g = a.g;
+    const uint32_t bc = blockIdx.x / blocks_per_plane;
+    const uint32_t idx = (blockIdx.x % blocks_per_plane) * 256u + threadIdx.x;
+    if (idx >= frame_px) return;
+    const uint32_t band = 2u * (uint32_t)pd * (uint32_t)g.W;  // top + bottom rows, full width
+    int py, px;
+    if (idx < band) {
+        const int rr = (int)(idx / (uint32_t)g.W);
+        px = (int)(idx % (uint32_t)g.W);
+        py = rr < pd ? rr : g.H - 2 * pd + rr;
+    } else {
+        const uint32_t i2 = idx - band;
+        const int cc = (int)(i2 % (uint32_t)(2 * pd));
+        py = pd + (int)(i2 / (uint32_t)(2 * pd));
+        px = cc < pd ? cc : g.W - 2 * pd + cc;
+    }
+    T* gx = a.y + (size_t)bc * g.H * g.W;
+    km_st(gx + (size_t)py * g.W + px, km_f2d_adjoint_pixel<T>(a, bc, py, px));
 }
 
 // gradient wrt the taps: gk[b % Bk][p][q] += sum_{i,j} gy[b,c,i,j] * xpad[b,c,i+p,j+q]
@@ -502,9 +534,27 @@ static int km_full_run(int which, const void* x, const void* gy, const void* k, 
     return km_check_launch(which == 0 ? "km_filter2d_fwd" : "km_filter2d_bwd_input");
 }
 
+template <typename T>
+static int km_full_frame_run(const void* gy, const void* k, void* gx, const KmFilterGeom& g, int pd, hipStream_t s) {
+    typedef typename KmTraits<T>::R R;
+    KmFullArgs<T> a;
+    a.x = nullptr; a.gy = (const T*)gy; a.y = (T*)gx; a.k = (const R*)k; a.gk = nullptr; a.g = g;
+    a.tiles_x = a.tiles_y = a.nblocks = 0;
+    const uint64_t frame = 2ull * pd * g.W + 2ull * pd * (uint64_t)(g.H - 2 * pd);
+    const uint32_t bpp = (uint32_t)((frame + 255) / 256);
+    const uint64_t nb = (uint64_t)bpp * g.B * g.C;
+    KM_REQUIRE(nb < (1ull << 31), "km_filter2d_bwd_input: grid too large");
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(km_filter2d_bwd_frame_kernel<T>, dim3((uint32_t)nb), dim3(256), 0, s, a, pd, (uint32_t)frame, bpp);
+    return km_check_launch("km_filter2d_bwd_input(frame)");
+}
+
 // register-tiled full kH x kW forward for square odd 3/5/7 kernels (km_filter2d_fast.hip)
+int km_filter2d_fast_tapgrad_run(const void* gy, const void* x, double* gk, int B, int C, int H, int W, int Bk, int K, int border, int dtype,
+                                 hipStream_t s);
 int km_filter2d_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype);
-int km_filter2d_fast_run(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int K, int border, int dtype, hipStream_t s);
+int km_filter2d_fast_run(const void* x, const void* k, void* y, int B, int C, int H, int W, int Bk, int K, int border, int flip, int dtype,
+                         hipStream_t s);
 
 // register-tiled fast path for small square odd kernels (km_blur_fast.hip)
 int km_blur_fast_supported(const void* x, const void* y, int H, int W, int kH, int kW, int border, int same, int dtype);
@@ -538,7 +588,7 @@ int km_filter2d_fwd(const void* x, const void* k, void* y, int B, int C, int H, 
     if (km_filter_validate("km_filter2d_fwd", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(x && k && y, "km_filter2d_fwd: null pointer");
     if (km_sep_algo() == 0 && km_filter2d_fast_supported(x, y, H, W, kH, kW, border, same, dtype))
-        return km_filter2d_fast_run(x, k, y, B, C, H, W, Bk, kH, border, dtype, (hipStream_t)stream);
+        return km_filter2d_fast_run(x, k, y, B, C, H, W, Bk, kH, border, 0, dtype, (hipStream_t)stream);
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
 #define CALL(T) km_full_run<T>(0, x, nullptr, k, y, nullptr, g, (hipStream_t)stream)
     KM_DISPATCH_DTYPE(dtype, CALL)
@@ -553,6 +603,19 @@ int km_filter2d_bwd_input(const void* gy, const void* k, void* gx, int B, int C,
     KM_REQUIRE(gy && k && gx, "km_filter2d_bwd_input: null pointer");
     KM_REQUIRE(!same || ((kH - 1 - (kH - 1) / 2) < KM_MAX_PRE && (kW - 1 - (kW - 1) / 2) < KM_MAX_PRE), "km_filter2d_bwd_input: kernel too large");
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
+    {
+        // square odd 3/5/7 kernels: interior by the register-tiled kernel on the zero-extended gradient with the rotated taps
+        // (for constant padding that is the whole adjoint), then the pad-wide frame by the exact pre-image kernel
+        // frame width: reflect folds padded coordinate -p onto pixel p for p = 1..pad, so pixels 0..pad are affected
+        const int pd = (kH - 1) / 2 + 1;
+        if (km_sep_algo() == 0 && km_filter2d_fast_supported(gy, gx, H, W, kH, kW, border, same, dtype) && H > 2 * pd && W > 2 * pd) {
+            const int rc = km_filter2d_fast_run(gy, k, gx, B, C, H, W, Bk, kH, KM_BORDER_CONSTANT, 1, dtype, (hipStream_t)stream);
+            if (rc != 0 || border == KM_BORDER_CONSTANT) return rc;
+#define CALLF(T) km_full_frame_run<T>(gy, k, gx, g, pd, (hipStream_t)stream)
+            KM_DISPATCH_DTYPE(dtype, CALLF)
+#undef CALLF
+        }
+    }
 #define CALL(T) km_full_run<T>(1, nullptr, gy, k, gx, nullptr, g, (hipStream_t)stream)
     KM_DISPATCH_DTYPE(dtype, CALL)
 #undef CALL
@@ -564,6 +627,8 @@ int km_filter2d_bwd_kernel(const void* gy, const void* x, void* gk, int B, int C
     if (B == 0 || C == 0) return 0;  // empty batch
     if (km_filter_validate("km_filter2d_bwd_kernel", B, C, H, W, Bk, kH, kW, border, same, dtype)) return -1;
     KM_REQUIRE(gy && x && gk, "km_filter2d_bwd_kernel: null pointer");
+    if (km_sep_algo() == 0 && km_filter2d_fast_supported(x, gy, H, W, kH, kW, border, same, dtype))  // one pass instead of kH*kW
+        return km_filter2d_fast_tapgrad_run(gy, x, (double*)gk, B, C, H, W, Bk, kH, border, dtype, (hipStream_t)stream);
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
 #define CALL(T) km_full_run<T>(2, x, gy, nullptr, nullptr, (double*)gk, g, (hipStream_t)stream)
     KM_DISPATCH_DTYPE(dtype, CALL)

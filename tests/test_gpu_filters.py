@@ -175,6 +175,16 @@ def test_register_tiled_filter2d(oracle, border, K, shape):
         ref = oracle.filter2d(x, k, border)
         out = K_.filter2d(x.cuda(), k.cuda(), border)
         assert torch.equal(out.cpu(), ref), f"max |d| = {(out.cpu() - ref).abs().max().item():.3e}"
+    # adjoint: rotated-tap interior from the register-tiled kernel + exact pad-wide frame (km_filter2d_bwd_frame_kernel)
+    if True:
+        for nb in (1, B):
+            k = torch.rand(nb, K, K, generator=g) - 0.3
+            go = torch.rand(B, C, H, W, generator=g)
+            xg, kg = x.cuda().requires_grad_(), k.cuda().requires_grad_()
+            K_.filter2d(xg, kg, border).backward(go.cuda())
+            gx_o, gk_o = oracle.filter2d_backward(go, x, k, border)
+            assert torch.allclose(xg.grad.cpu(), gx_o, atol=2e-5, rtol=1e-5), (xg.grad.cpu() - gx_o).abs().max()
+            assert torch.allclose(kg.grad.cpu(), gk_o, atol=2e-3, rtol=1e-4)
     kb = torch.rand(1, K, K, generator=g)
     ob = K_.filter2d(x.bfloat16().cuda(), kb.cuda(), border).float().cpu()
     assert torch.allclose(ob, oracle.filter2d(x.bfloat16().float(), kb.bfloat16().float(), border), atol=3e-2, rtol=2e-2)
