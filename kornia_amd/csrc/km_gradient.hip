@@ -67,8 +67,32 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_fwd_kernel(const KmGr
 // adjoint wrt input (gather form): gx[p] = sum_o sum_{s in pre(p)} sum_{t} k_o[t] * gout_o[s + pd - t]
 // replicate pre-images: p itself, plus every s < 0 for p == 0 and every s >= n for p == n-1.
 template <typename T>
-__global__ __launch_bounds__(256) void km_spatial_gradient_bwd_kernel(const KmGradArgs<T> a) {
+__device__ __forceinline__ typename KmTraits<T>::R km_sg_adjoint_pixel(const KmGradArgs<T>& a, uint32_t bc, int py, int px) {
     typedef typename KmTraits<T>::R R;
+    const int pd = a.kS / 2;
+    const size_t plane = (size_t)a.H * a.W;
+    const int sx_lo = (px == 0) ? -pd : px, sx_hi = (px == a.W - 1) ? a.W - 1 + pd : px;
+    const int sy_lo = (py == 0) ? -pd : py, sy_hi = (py == a.H - 1) ? a.H - 1 + pd : py;
+    R acc = 0;
+    for (int o = 0; o < a.n_out; ++o) {
+        const T* go = a.gout + ((size_t)bc * a.n_out + o) * plane;
+        for (int sy = sy_lo; sy <= sy_hi; ++sy)
+            for (int sx = sx_lo; sx <= sx_hi; ++sx)
+                for (int p = 0; p < a.kS; ++p) {
+                    const int oy = sy + pd - p;
+                    if (oy < 0 || oy >= a.H) continue;
+                    for (int q = 0; q < a.kS; ++q) {
+                        const int ox = sx + pd - q;
+                        if (ox < 0 || ox >= a.W) continue;
+                        acc = km_fma(a.kern[(o * a.kS + p) * a.kS + q], (R)km_ld(go + (size_t)oy * a.W + ox), acc);
+                    }
+                }
+    }
+    return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void km_spatial_gradient_bwd_kernel(const KmGradArgs<T> a) {
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
@@ -77,32 +101,32 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_bwd_kernel(const KmGr
     const int px = tx * 64 + (threadIdx.x & 63);
     const int py0 = ty * 16 + (threadIdx.x >> 6) * 4;
     if (px >= a.W) return;
-    const int pd = a.kS / 2;
     const size_t plane = (size_t)a.H * a.W;
-    const int sx_lo = (px == 0) ? -pd : px, sx_hi = (px == a.W - 1) ? a.W - 1 + pd : px;
     for (int r = 0; r < 4; ++r) {
         const int py = py0 + r;
         if (py >= a.H) break;
-        const int sy_lo = (py == 0) ? -pd : py, sy_hi = (py == a.H - 1) ? a.H - 1 + pd : py;
-        R acc = 0;
-        for (int o = 0; o < a.n_out; ++o) {
-            const T* go = a.gout + ((size_t)bc * a.n_out + o) * plane;
-            for (int sy = sy_lo; sy <= sy_hi; ++sy)
-                for (int sx = sx_lo; sx <= sx_hi; ++sx)
-                    for (int p = 0; p < a.kS; ++p) {
-                        const int oy = sy + pd - p;
-                        if (oy < 0 || oy >= a.H) continue;
-                        for (int q = 0; q < a.kS; ++q) {
-                            const int ox = sx + pd - q;
-                            if (ox < 0 || ox >= a.W) continue;
-                            acc = km_fma(a.kern[(o * a.kS + p) * a.kS + q], (R)km_ld(go + (size_t)oy * a.W + ox), acc);
-                        }
-                    }
-        }
-        km_st(a.out + (size_t)bc * plane + (size_t)py * a.W + px, acc);
+        km_st(a.out + (size_t)bc * plane + (size_t)py * a.W + px, km_sg_adjoint_pixel<T>(a, bc, py, px));
     }
 }
 
+// replicate padding folds every padded coordinate outside the image onto the border pixels, so the adjoint differs from
+// "correlate the zero-extended gradients with the rotated stacks" only on the 1-pixel frame: recomputed here exactly
+template <typename T>
+__global__ __launch_bounds__(256) void km_spatial_gradient_bwd_frame_kernel(const KmGradArgs<T> a, uint32_t frame_px, uint32_t blocks_per_plane) {
+    const uint32_t bc = blockIdx.x / blocks_per_plane;
+    const uint32_t idx = (blockIdx.x % blocks_per_plane) * 256u + threadIdx.x;
+    if (idx >= frame_px) return;
+    int py, px;
+    if (idx < 2u * (uint32_t)a.W) {
+        px = (int)(idx % (uint32_t)a.W);
+        py = idx < (uint32_t)a.W ? 0 : a.H - 1;
+    } else {
+        const uint32_t i2 = idx - 2u * (uint32_t)a.W;
+        py = 1 + (int)(i2 >> 1);
+        px = (i2 & 1u) ? a.W - 1 : 0;
+    }
+    km_st(a.out + (size_t)bc * a.H * a.W + (size_t)py * a.W + px, km_sg_adjoint_pixel<T>(a, bc, py, px));
+}
 
 // ------------------------------------------------------------------------------------------------
 // Register-tiled forward for the shapes the reference produces (3x3 or 5x5 stacks, 2 or 3 outputs): the same
@@ -221,6 +245,114 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_reg_kernel(const KmGr
     }
 }
 
+
+// interior of the adjoint: gx = sum_o correlate(zero-extended gout_o, k_o rotated by 180 degrees), register-tiled like the forward
+template <typename T, int KS, int NOUT>
+__global__ __launch_bounds__(256) void km_spatial_gradient_bwd_reg_kernel(const KmGradArgs<T> a) {
+    constexpr int PD = KS / 2, NV = 4 + 2 * PD;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t tby = bid % a.tiles_y;
+    const uint32_t bc = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = (int)tbx * 64 + lane;
+    const int r0 = ((int)tby * 4 + wave) * KM_SG_ROWS;
+    const int H = a.H, W = a.W;
+    if (gx * 4 >= W || r0 >= H) return;
+    const int c0 = gx * 4;
+    const size_t plane = (size_t)H * W;
+    // halo columns: zero outside the image
+    int hl[PD], hr[PD];
+    bool okl[PD], okr[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+        const int il = c0 - PD + q, ir = c0 + 4 + q;
+        okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
+        okr[q] = ir < W; hr[q] = okr[q] ? ir : 0;
+    }
+    float k[NOUT][KS][KS];  // rotated by 180 degrees
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int p = 0; p < KS; ++p)
+#pragma unroll
+            for (int q = 0; q < KS; ++q) k[o][p][q] = a.kern[(o * KS + (KS - 1 - p)) * KS + (KS - 1 - q)];
+
+    float ring[NOUT][KS][NV];
+    const int n_rows = (r0 + KM_SG_ROWS <= H ? KM_SG_ROWS : H - r0);
+    const int total = n_rows + KS - 1;
+    for (int it0 = 0; it0 < total; it0 += KS) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int it = it0 + kk;
+            if (it < total) {
+                const int rin = r0 - PD + it;
+                const bool rv = (rin >= 0 && rin < H);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    if (rv) {
+                        const T* rowp = a.gout + ((size_t)bc * NOUT + o) * plane + (size_t)rin * W;
+                        float o4[4];
+                        km_sg_ld4(rowp + c0, o4);
+#pragma unroll
+                        for (int q = 0; q < PD; ++q) {
+                            const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
+                            ring[o][kk][q] = okl[q] ? vl : 0.f;
+                            ring[o][kk][PD + 4 + q] = okr[q] ? vr : 0.f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ring[o][kk][PD + q] = o4[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NV; ++q) ring[o][kk][q] = 0.f;
+                    }
+                }
+                if (it >= KS - 1) {
+                    const int r = r0 + it - (KS - 1);
+                    float acc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                            for (int p = 0; p < KS; ++p)
+#pragma unroll
+                                for (int q = 0; q < KS; ++q) sacc = km_fma(k[o][p][q], ring[o][(kk + 1 + p) % KS][c + q], sacc);
+                        acc[c] = sacc;
+                    }
+                    km_sg_st4(a.out + (size_t)bc * plane + (size_t)r * W + c0, acc);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int km_sg_fast_bwd_launch(const KmGradArgs<T>& a0, hipStream_t s) {
+    KmGradArgs<T> a = a0;
+    a.tiles_x = (uint32_t)((a.W / 4 + 63) / 64);
+    a.tiles_y = (uint32_t)((a.H + 4 * KM_SG_ROWS - 1) / (4 * KM_SG_ROWS));
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)a.BC;
+    KM_REQUIRE(nb < (1ull << 31), "km_spatial_gradient: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (a.kS == 3 && a.n_out == 2)
+        hipLaunchKernelGGL((km_spatial_gradient_bwd_reg_kernel<T, 3, 2>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else if (a.kS == 3)
+        hipLaunchKernelGGL((km_spatial_gradient_bwd_reg_kernel<T, 3, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_spatial_gradient_bwd_reg_kernel<T, 5, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    int rc = km_check_launch("km_spatial_gradient_bwd(reg)");
+    if (rc) return rc;
+    const uint64_t frame = 2ull * a.W + 2ull * (uint64_t)(a.H - 2);
+    const uint32_t bpp = (uint32_t)((frame + 255) / 256);
+    hipLaunchKernelGGL(km_spatial_gradient_bwd_frame_kernel<T>, dim3(bpp * (uint32_t)a.BC), dim3(256), 0, s, a, (uint32_t)frame, bpp);
+    return km_check_launch("km_spatial_gradient_bwd(frame)");
+}
+template <>
+int km_sg_fast_bwd_launch<double>(const KmGradArgs<double>&, hipStream_t) { return -1; }
+
 // 1 if the register-tiled forward handles this problem
 template <typename T>
 static bool km_sg_fast_ok(const void* x, const void* out, const void* mag, int H, int W, int n_out, int kS) {
@@ -269,6 +401,7 @@ static int km_grad_run(bool bwd, const void* x, const void* gout, const void* ke
         static int generic = -1;
         if (generic < 0) { const char* e = getenv("KM_SG_ALGO"); generic = (e && e[0] == 'g') ? 1 : 0; }  // "generic": A/B timing
         if (!bwd && !generic && sizeof(T) != 8 && km_sg_fast_ok<T>(x, out, mag, H, W, n_out, kS)) return km_sg_fast_launch<T>(a, s);
+        if (bwd && !generic && sizeof(T) != 8 && H > 2 && km_sg_fast_ok<T>(gout, out, nullptr, H, W, n_out, kS)) return km_sg_fast_bwd_launch<T>(a, s);
     }
     if (bwd)
         hipLaunchKernelGGL(km_spatial_gradient_bwd_kernel<T>, dim3(a.nblocks), dim3(256), 0, s, a);

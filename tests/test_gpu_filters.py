@@ -152,6 +152,12 @@ def test_register_tiled_spatial_gradient(oracle, mode, order, shape):
     out = K.spatial_gradient(x.cuda(), mode, order, True)
     assert out.shape == ref.shape and out.is_contiguous()
     assert torch.equal(out.cpu(), ref), f"max |d| = {(out.cpu() - ref).abs().max().item():.3e}"
+    # adjoint: rotated-stack interior (km_spatial_gradient_bwd_reg_kernel) + exact 1-pixel frame
+    go = torch.rand(ref.shape, generator=g)
+    xg = x.cuda().requires_grad_()
+    K.spatial_gradient(xg, mode, order, True).backward(go.cuda())
+    gx_o = oracle.spatial_gradient_backward(go, x, mode, order, True)
+    assert torch.allclose(xg.grad.cpu(), gx_o, atol=1e-5, rtol=1e-5), (xg.grad.cpu() - gx_o).abs().max()
     if mode == "sobel" and order == 1:
         assert torch.equal(K.sobel(x.cuda()).cpu(), oracle.sobel(x))
         xb = x.bfloat16()
