@@ -135,7 +135,8 @@ int km_filter2d_sep_fwd(const void* x, const void* kx, const void* ky, void* y, 
                         int kW, int border, int same, int dtype, void* stream);
 int km_filter2d_sep_bwd_input(const void* gy, const void* kx, const void* ky, void* gx, int B, int C, int H, int W, int Bk,
                               int kH, int kW, int border, int same, int dtype, void* stream);
-/* 1 if the fused separable kernels accept this kernel size (LDS budget), else 0 */
+/* which fused separable kernels accept this kernel size (LDS budget): bit 0 = km_filter2d_sep_fwd, bit 1 =
+ * km_filter2d_sep_bwd_input (without it the caller runs the adjoint as two km_filter2d_bwd_input passes) */
 int km_filter2d_sep_supported(int kH, int kW, int same, int dtype);
 
 /* ---- spatial gradient / sobel --------------------------------------------------------------

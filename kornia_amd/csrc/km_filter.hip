@@ -549,6 +549,11 @@ static int km_full_frame_run(const void* gy, const void* k, void* gx, const KmFi
     return km_check_launch("km_filter2d_bwd_input(frame)");
 }
 
+// large separable kernels, forward (km_filter_sep_big.hip)
+int km_filter_sep_big_supported(int kH, int kW, int dtype);
+int km_filter_sep_big_run(const void* x, const void* kx, const void* ky, void* y, int B, int C, int H, int W, int Bk, int kH, int kW,
+                          int border, int same, int dtype, hipStream_t s);
+
 // register-tiled full kH x kW forward for square odd 3/5/7 kernels (km_filter2d_fast.hip)
 int km_filter2d_fast_tapgrad_run(const void* gy, const void* x, double* gk, int B, int C, int H, int W, int Bk, int K, int border, int dtype,
                                  hipStream_t s);
@@ -643,6 +648,8 @@ int km_filter2d_sep_fwd(const void* x, const void* kx, const void* ky, void* y, 
     KM_REQUIRE(x && kx && ky && y, "km_filter2d_sep_fwd: null pointer");
     if (km_sep_algo() == 0 && km_blur_fast_supported(x, y, H, W, kH, kW, border, same, dtype))
         return km_blur_fast_run(false, x, kx, ky, y, B, C, H, W, Bk, kH, border, dtype, (hipStream_t)stream);
+    if (km_sep_algo() == 0 && km_filter_sep_big_supported(kH, kW, dtype))  // k >= 10: sliding-window LDS kernel
+        return km_filter_sep_big_run(x, kx, ky, y, B, C, H, W, Bk, kH, kW, border, same, dtype, (hipStream_t)stream);
     const KmFilterGeom g = km_filter_geom(B, C, H, W, Bk, kH, kW, border, same);
 #define CALL(T) km_sep_run<T>(false, x, kx, ky, y, g, (hipStream_t)stream)
     KM_DISPATCH_DTYPE(dtype, CALL)
@@ -663,12 +670,18 @@ int km_filter2d_sep_bwd_input(const void* gy, const void* kx, const void* ky, vo
 #undef CALL
 }
 
-// 1 if the fused separable kernels can take this kernel size (LDS budget), else 0
+// Which fused separable kernels can take this kernel size (LDS budgets): bit 0 = forward (km_filter2d_sep_fwd),
+// bit 1 = gradient wrt the input (km_filter2d_sep_bwd_input).  A caller without bit 1 runs the adjoint as two
+// km_filter2d_bwd_input passes (column kernel, then row kernel).
 int km_filter2d_sep_supported(int kH, int kW, int same, int dtype) {
-    if (kH - 1 > KM_FS_TH || kW - 1 > KM_FS_TW) return 0;
+    int mask = 0;
+    if (km_filter_sep_big_supported(kH, kW, dtype)) mask |= 1;
+    if (kH - 1 > KM_FS_TH || kW - 1 > KM_FS_TW) return mask;
     const size_t f = dtype == KM_F64 ? km_sep_fwd_lds<double>(kH, kW) : km_sep_fwd_lds<float>(kH, kW);
     const size_t b = dtype == KM_F64 ? km_sep_bwd_lds<double>(kH, kW, same) : km_sep_bwd_lds<float>(kH, kW, same);
-    return (f <= KM_LDS_LIMIT && b <= KM_LDS_LIMIT) ? 1 : 0;
+    if (f <= KM_LDS_LIMIT) mask |= 1;
+    if (b <= KM_LDS_LIMIT) mask |= 2;
+    return mask;
 }
 
 }  // extern "C"

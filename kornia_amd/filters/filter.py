@@ -110,10 +110,20 @@ class _Filter2dSepFunction(torch.autograd.Function):
         kH = kyc.shape[1]
         g = gy.detach().to(dtype).contiguous()
         gx = torch.empty(B, C, H, W, device=g.device, dtype=dtype)
+        lib = N.lib()
+        code, stream = N.dtype_code(dtype), N.stream_ptr(g.device)
         with torch.cuda.device(g.device):
-            N.check(N.lib().km_filter2d_sep_bwd_input(g.data_ptr(), kxc.data_ptr(), kyc.data_ptr(), gx.data_ptr(), B, C, H, W, Bk, kH,
-                                                      kW, border, same, N.dtype_code(dtype), N.stream_ptr(g.device)),
-                    "km_filter2d_sep_bwd_input")
+            if lib.km_filter2d_sep_supported(kH, kW, same, code) & 2:
+                N.check(lib.km_filter2d_sep_bwd_input(g.data_ptr(), kxc.data_ptr(), kyc.data_ptr(), gx.data_ptr(), B, C, H, W, Bk, kH,
+                                                      kW, border, same, code, stream), "km_filter2d_sep_bwd_input")
+            else:
+                # large kernels: the fused adjoint does not fit in LDS - adjoint of the column pass, then of the row pass
+                Wo = W if same else W - kW + 1
+                gt = torch.empty(B, C, H, Wo, device=g.device, dtype=dtype)
+                N.check(lib.km_filter2d_bwd_input(g.data_ptr(), kyc.data_ptr(), gt.data_ptr(), B, C, H, Wo, Bk, kH, 1, border, same, code,
+                                                  stream), "km_filter2d_bwd_input")
+                N.check(lib.km_filter2d_bwd_input(gt.data_ptr(), kxc.data_ptr(), gx.data_ptr(), B, C, H, W, Bk, 1, kW, border, same, code,
+                                                  stream), "km_filter2d_bwd_input")
         return gx, None, None, None, None
 
 
@@ -204,7 +214,7 @@ def filter2d_separable(
         B, C, H, W = input.shape
         kW, kH = kernel_x.shape[1], kernel_y.shape[1]
         same = int(str(padding).lower() == "same")
-        fused = bool(N.lib().km_filter2d_sep_supported(kH, kW, same, N.dtype_code(input.dtype)))
+        fused = bool(N.lib().km_filter2d_sep_supported(kH, kW, same, N.dtype_code(input.dtype)) & 1)
     if not fused:
         out_x = filter2d(input, kernel_x[..., None, :], border_type, normalized, padding)
         return filter2d(out_x, kernel_y[..., None], border_type, normalized, padding)

@@ -44,7 +44,9 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert rc < 0 and b"must divide" in lib.km_last_error()
     rc = lib.km_homography_chain_fwd(buf, 4, buf, buf, 1, 8, 8, 8, 8, 0, None)
     assert rc < 0 and b"rows must be 2 or 3" in lib.km_last_error()
-    assert lib.km_filter2d_sep_supported(5, 5, 1, 0) == 1 and lib.km_filter2d_sep_supported(99, 5, 1, 0) == 0
+    # bit 0: fused forward, bit 1: fused adjoint;  23x23 (SimCLR-style blur): forward only;  99 taps: neither
+    assert lib.km_filter2d_sep_supported(5, 5, 1, 0) == 3 and lib.km_filter2d_sep_supported(23, 23, 1, 0) == 1
+    assert lib.km_filter2d_sep_supported(99, 5, 1, 0) == 0
     assert lib.km_warp2d_bwd_needs_zero_init(1, 0, 0) == 0 and lib.km_warp2d_bwd_needs_zero_init(2, 0, 0) == 1
 
 

@@ -196,6 +196,35 @@ def test_register_tiled_filter2d(oracle, border, K, shape):
     assert torch.allclose(ob, oracle.filter2d(x.bfloat16().float(), kb.bfloat16().float(), border), atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 70, 90), (1, 2, 224, 224), (2, 1, 33, 150)])
+@pytest.mark.parametrize("ksize", [(11, 11), (23, 23), (15, 10), (33, 13), (12, 31)])
+@pytest.mark.parametrize("border", BORDERS)
+def test_large_separable_kernels(oracle, border, ksize, shape):
+    """k >= 10 takes km_filter_sep_big_fwd_kernel (sliding-window LDS kernel): bit-identical to the oracle; the adjoint runs
+    as two generic passes when the fused one does not fit in LDS."""
+    import kornia_amd as K_
+
+    B, C, H, W = shape
+    kH, kW = ksize
+    if border == "reflect" and ((kH - 1) // 2 + (1 - kH % 2) >= H or (kW - 1) // 2 + (1 - kW % 2) >= W):
+        pytest.skip("reflect pad wider than the image")
+    x, g = _x(*shape, seed=13)
+    kx, ky = torch.rand(1, kW, generator=g), torch.rand(B, kH, generator=g)[: (1 if kH % 2 else B)]
+    kx = kx.expand(ky.shape[0], -1).contiguous()
+    ref = oracle.filter2d_separable(x, kx, ky, border)
+    xg = x.cuda().requires_grad_()
+    out = K_.filter2d_separable(xg, kx.cuda(), ky.cuda(), border)
+    assert torch.equal(out.detach().cpu(), ref), f"max |d| = {(out.detach().cpu() - ref).abs().max().item():.3e}"
+    go = torch.rand(ref.shape, generator=g)
+    out.backward(go.cuda())
+    gx_o = oracle.filter2d_separable_backward(go, x, kx, ky, border)
+    assert torch.allclose(xg.grad.cpu(), gx_o, atol=5e-5, rtol=1e-4), (xg.grad.cpu() - gx_o).abs().max()
+    if ksize == (23, 23):
+        refv = oracle.filter2d_separable(x, kx, ky, border, padding="valid")
+        assert torch.equal(K_.filter2d_separable(x.cuda(), kx.cuda(), ky.cuda(), border, padding="valid").cpu(), refv)
+        assert torch.equal(K_.gaussian_blur2d(x.cuda(), (23, 23), (2.3, 3.1), border).cpu(), oracle.gaussian_blur2d(x, (23, 23), (2.3, 3.1), border))
+
+
 def test_sobel(oracle):
     import kornia_amd as K
 
