@@ -129,3 +129,25 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device: torch.device):
+    """``torch.cuda.device(device)`` only when it is not already the current device (the common case costs ~1 us
+    instead of two device switches per native call)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)

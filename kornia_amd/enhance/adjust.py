@@ -72,7 +72,7 @@ def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], 
     arr = (ctypes.c_int * max(len(stages), 1))(*stages)
     if enable is not None:
         enable = enable.detach().to(device=dev).reshape(4).ne(0).to(torch.uint8).contiguous()
-    with torch.cuda.device(dev):
+    with N.device_guard(dev):
         N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
                                             N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
     return out.reshape(shape)

@@ -53,7 +53,7 @@ class _Filter2dFunction(torch.autograd.Function):
         B, C, H, W = xc.shape
         Bk, kH, kW = kc.shape
         out = torch.empty(B, C, H if same else H - kH + 1, W if same else W - kW + 1, device=x.device, dtype=x.dtype)
-        with torch.cuda.device(x.device):
+        with N.device_guard(x.device):
             N.check(N.lib().km_filter2d_fwd(xc.data_ptr(), kc.data_ptr(), out.data_ptr(), B, C, H, W, Bk, kH, kW, border, same,
                                             N.dtype_code(x.dtype), N.stream_ptr(x.device)), "km_filter2d_fwd")
         ctx.save_for_backward(xc, kc)
@@ -69,7 +69,7 @@ class _Filter2dFunction(torch.autograd.Function):
         g = gy.detach().to(xc.dtype).contiguous()
         gx = gk = None
         lib = N.lib()
-        with torch.cuda.device(xc.device):
+        with N.device_guard(xc.device):
             stream = N.stream_ptr(xc.device)
             if ctx.needs_input_grad[0]:
                 gx = torch.empty_like(xc)
@@ -95,7 +95,7 @@ class _Filter2dSepFunction(torch.autograd.Function):
         Bk, kW = kxc.shape
         kH = kyc.shape[1]
         out = torch.empty(B, C, H if same else H - kH + 1, W if same else W - kW + 1, device=x.device, dtype=x.dtype)
-        with torch.cuda.device(x.device):
+        with N.device_guard(x.device):
             N.check(N.lib().km_filter2d_sep_fwd(xc.data_ptr(), kxc.data_ptr(), kyc.data_ptr(), out.data_ptr(), B, C, H, W, Bk, kH, kW,
                                                 border, same, N.dtype_code(x.dtype), N.stream_ptr(x.device)), "km_filter2d_sep_fwd")
         ctx.save_for_backward(kxc, kyc)
@@ -112,7 +112,7 @@ class _Filter2dSepFunction(torch.autograd.Function):
         gx = torch.empty(B, C, H, W, device=g.device, dtype=dtype)
         lib = N.lib()
         code, stream = N.dtype_code(dtype), N.stream_ptr(g.device)
-        with torch.cuda.device(g.device):
+        with N.device_guard(g.device):
             if lib.km_filter2d_sep_supported(kH, kW, same, code) & 2:
                 N.check(lib.km_filter2d_sep_bwd_input(g.data_ptr(), kxc.data_ptr(), kyc.data_ptr(), gx.data_ptr(), B, C, H, W, Bk, kH,
                                                       kW, border, same, code, stream), "km_filter2d_sep_bwd_input")

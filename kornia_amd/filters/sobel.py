@@ -35,7 +35,7 @@ class _SpatialGradientFunction(torch.autograd.Function):
         B, C, H, W = xc.shape
         k, n_out, kS = _host_kernel(mode, order, normalized, x.dtype)
         out = torch.empty(B, C, n_out, H, W, device=x.device, dtype=x.dtype)
-        with torch.cuda.device(x.device):
+        with N.device_guard(x.device):
             N.check(N.lib().km_spatial_gradient_fwd(xc.data_ptr(), k.data_ptr(), out.data_ptr(), None, B, C, H, W, n_out, kS,
                                                     ctypes.c_double(0.0), N.dtype_code(x.dtype), N.stream_ptr(x.device)),
                     "km_spatial_gradient_fwd")
@@ -48,7 +48,7 @@ class _SpatialGradientFunction(torch.autograd.Function):
         k, n_out, kS = _host_kernel(mode, order, normalized, dtype)
         g = gout.detach().to(dtype).contiguous()
         gx = torch.empty(B, C, H, W, device=g.device, dtype=dtype)
-        with torch.cuda.device(g.device):
+        with N.device_guard(g.device):
             N.check(N.lib().km_spatial_gradient_bwd(g.data_ptr(), k.data_ptr(), gx.data_ptr(), B, C, H, W, n_out, kS,
                                                     N.dtype_code(dtype), N.stream_ptr(g.device)), "km_spatial_gradient_bwd")
         return gx, None, None, None
@@ -77,7 +77,7 @@ def sobel(input: torch.Tensor, normalized: bool = True, eps: float = 1e-6) -> to
     B, C, H, W = xc.shape
     k, n_out, kS = _host_kernel("sobel", 1, normalized, input.dtype)
     mag = torch.empty_like(xc)
-    with torch.cuda.device(xc.device):
+    with N.device_guard(xc.device):
         N.check(N.lib().km_spatial_gradient_fwd(xc.data_ptr(), k.data_ptr(), None, mag.data_ptr(), B, C, H, W, n_out, kS,
                                                 ctypes.c_double(float(eps)), N.dtype_code(xc.dtype), N.stream_ptr(xc.device)),
                 "km_spatial_gradient_fwd")

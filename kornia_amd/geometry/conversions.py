@@ -47,7 +47,7 @@ class _ChainFunction(torch.autograd.Function):
         Mc = M.detach().to(cdt).contiguous()
         B, rows = Mc.shape[0], Mc.shape[1]
         out = torch.empty(B, 9, device=M.device, dtype=cdt)
-        with torch.cuda.device(M.device):
+        with N.device_guard(M.device):
             rc = N.lib().km_homography_chain_fwd(
                 Mc.data_ptr(), rows, None if want_inverse else out.data_ptr(), out.data_ptr() if want_inverse else None,
                 B, int(src_size[0]), int(src_size[1]), int(dst_size[0]), int(dst_size[1]), N.dtype_code(cdt),
@@ -71,7 +71,7 @@ class _ChainFunction(torch.autograd.Function):
         B, rows = Mc.shape[0], Mc.shape[1]
         gm = g.detach().to(torch.float64).contiguous().view(B, 9)
         gM = torch.empty_like(Mc)
-        with torch.cuda.device(Mc.device):
+        with N.device_guard(Mc.device):
             rc = N.lib().km_homography_chain_bwd(
                 Mc.data_ptr(), rows, gm.data_ptr(), gM.data_ptr(), B, int(src_size[0]), int(src_size[1]),
                 int(dst_size[0]), int(dst_size[1]), N.dtype_code(Mc.dtype), N.stream_ptr(Mc.device))

@@ -15,7 +15,7 @@ class _TransformPointsFunction(torch.autograd.Function):
         # T (B_T,D+1,D+1), pts (B,N,D), same compute dtype, contiguous
         B, Np, D = pts.shape
         out = torch.empty_like(pts)
-        with torch.cuda.device(pts.device):
+        with N.device_guard(pts.device):
             rc = N.lib().km_transform_points_fwd(T.data_ptr(), pts.data_ptr(), out.data_ptr(), B, Np, D, T.shape[0],
                                                  N.dtype_code(pts.dtype), N.stream_ptr(pts.device))
         N.check(rc, "km_transform_points_fwd")
@@ -29,7 +29,7 @@ class _TransformPointsFunction(torch.autograd.Function):
         g = g.contiguous()
         gpts = torch.empty_like(pts) if ctx.needs_input_grad[1] else None
         gT = torch.zeros(T.shape[0], (D + 1) * (D + 1), device=pts.device, dtype=torch.float64) if ctx.needs_input_grad[0] else None
-        with torch.cuda.device(pts.device):
+        with N.device_guard(pts.device):
             rc = N.lib().km_transform_points_bwd(g.data_ptr(), T.data_ptr(), pts.data_ptr(), N.ptr(gpts), N.ptr(gT), B, Np, D,
                                                  T.shape[0], N.dtype_code(pts.dtype), N.stream_ptr(pts.device))
         N.check(rc, "km_transform_points_bwd")

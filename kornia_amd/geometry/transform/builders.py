@@ -186,7 +186,7 @@ def _affine_matrix2d_native(translations, center, scale, angle, sx, sy):
     dev = translations.device
     args = [None if t is None else t.detach().to(cdt).contiguous() for t in (translations, center, scale, angle, sx, sy)]
     out = torch.empty(B, 3, 3, device=dev, dtype=cdt)
-    with torch.cuda.device(dev):
+    with N.device_guard(dev):
         N.check(N.lib().km_affine_matrix2d_fwd(*[N.ptr(t) for t in args], out.data_ptr(), B, N.dtype_code(cdt), N.stream_ptr(dev)),
                 "km_affine_matrix2d_fwd")
     return out.to(dtype)

@@ -64,7 +64,7 @@ class _Warp2dFunction(torch.autograd.Function):
         B_M = Mc.shape[0]
         stream = N.stream_ptr(dev)
         out = torch.empty(B, C, h, w, device=dev, dtype=src.dtype)
-        with torch.cuda.device(dev):
+        with N.device_guard(dev):
             if cfg.coord_mode == COORD_HOMOGRAPHY:
                 m = Mc.view(B_M, 9)
             else:
@@ -98,7 +98,7 @@ class _Warp2dFunction(torch.autograd.Function):
             gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
         gm = torch.zeros(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
         gmat = None
-        with torch.cuda.device(dev):
+        with N.device_guard(dev):
             N.check(lib.km_warp2d_bwd(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
                                       B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),
                                       N.dtype_code(x.dtype), stream), "km_warp2d_bwd")
@@ -127,7 +127,7 @@ class _GridSampleFunction(torch.autograd.Function):
         B, C, H, W = x.shape
         B_G, h, w, _ = gr.shape
         out = torch.empty(B, C, h, w, device=dev, dtype=x.dtype)
-        with torch.cuda.device(dev):
+        with N.device_guard(dev):
             N.check(lib.km_grid_sample2d_fwd(x.data_ptr(), gr.data_ptr(), out.data_ptr(), B, C, H, W, h, w, B_G, interp, pad, align,
                                              N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_grid_sample2d_fwd")
         ctx.save_for_backward(x, gr)
@@ -146,7 +146,7 @@ class _GridSampleFunction(torch.autograd.Function):
         g = gout.detach().to(x.dtype).contiguous()
         gsrc = torch.zeros(B, C, H, W, device=dev, dtype=cdt) if ctx.needs_input_grad[0] else None
         ggrid = torch.empty(B, h, w, 2, device=dev, dtype=cdt) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(dev):
+        with N.device_guard(dev):
             N.check(lib.km_grid_sample2d_bwd(g.data_ptr(), x.data_ptr(), gr.data_ptr(), N.ptr(gsrc), N.ptr(ggrid), B, C, H, W, h, w, B_G,
                                              interp, pad, align, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_grid_sample2d_bwd")
         if gsrc is not None and gsrc.dtype != x.dtype:
