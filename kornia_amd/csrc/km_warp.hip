@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
 
+    // 32 x 2 output patch per wave instruction (see km_warp_fwd_bz_kernel): compact gathers under rotation
+    constexpr int PW = KM_PATCH_W, PH = 64 / PW, WA = 64 / PW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = (int)tx * KM_TILE_W + lane;
-    const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
+    const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
+    const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // this thread's row r sits at tile row li_base + r * PH
+    const int i_base = (int)ty * KM_TILE_H + li_base;
     __shared__ R s_v[KM_TILE_H];
     if (threadIdx.x < KM_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KM_TILE_H + (int)threadIdx.x);
     __syncthreads();
@@ -76,9 +79,9 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
 
 #pragma unroll
     for (int r = 0; r < KM_ROWS; ++r) {
-        const int i = i_base + r;
+        const int i = i_base + r * PH;
         if (i >= g.h) break;
-        const R v = s_v[wave * KM_ROWS + r];  // row base coordinate (one IEEE divide per row per block, not per lane)
+        const R v = s_v[li_base + r * PH];  // row base coordinate (one IEEE divide per row per block, not per lane)
         KmCoord<R> cd;
         km_gen_coord<R, CM>(m, u, v, cd);
         if (CM == KM_COORD_GRID) km_grid_coord(a.grid, g, b, i, j, cd);
@@ -338,9 +341,10 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
 
+    constexpr int PW = KM_PATCH_W, PH = 64 / PW, WA = 64 / PW;  // 32 x 2 output patch per wave instruction
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = (int)tx * KM_TILE_W + lane;
-    const int i_base = (int)ty * KM_TILE_H + wave * KM_ROWS;
+    const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
+    const int i_base = (int)ty * KM_TILE_H + (wave / WA) * (PH * KM_ROWS) + lane / PW;
     const bool want_gg = (CM == KM_COORD_GRID) && (a.ggrid != nullptr);  // gradient wrt the explicit grid
     const bool want_gm = ((a.gmat != nullptr) || want_gg) && (INTERP != KM_INTERP_NEAREST);  // needs d out / d (x, y)
     const bool want_gs = (a.gsrc != nullptr);
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
         const R u = km_base_x<R, CM>(g, j);
 #pragma unroll
         for (int r = 0; r < KM_ROWS; ++r) {
-            const int i = i_base + r;
+            const int i = i_base + r * PH;
             if (i >= g.h) break;
             const R v = km_base_y<R, CM>(g, i);
             KmCoord<R> cd;
