@@ -62,6 +62,36 @@ def test_no_cpu_fallback():
         K.spatial_gradient(x)
     with pytest.raises(K.NativeLibraryError):
         K.transform_points(torch.eye(3)[None], torch.rand(1, 4, 2))
+    with pytest.raises(K.NativeLibraryError):
+        K.remap(x, torch.zeros(1, 8, 8), torch.zeros(1, 8, 8))
+    with pytest.raises(K.NativeLibraryError):
+        K.grid_sample(x, torch.zeros(1, 4, 4, 2))
+    with pytest.raises(K.NativeLibraryError):
+        K.enhance.color_jitter(x, 1.1, 0.9, 1.2, 0.05)
+    with pytest.raises(K.NativeLibraryError):
+        K.enhance.adjust_hue(x, 0.3)
+
+
+def test_host_side_argument_checks_of_the_next_rows():
+    """remap / grid_sample / colour ops validate on the host before touching the library; the matrix builders are plain
+    tensor expressions off-device (and differentiable)."""
+    import kornia_amd as K
+    from kornia_amd.core.exceptions import ShapeError
+
+    x = torch.rand(2, 3, 8, 8)
+    with pytest.raises(ShapeError):
+        K.remap(x, torch.zeros(8, 8), torch.zeros(2, 8, 8))
+    with pytest.raises(ValueError, match="pixel_coordinates must be of shape"):
+        K.geometry.normalize_pixel_coordinates(torch.zeros(4, 3), 8, 8)
+    n = K.geometry.normalize_pixel_coordinates(torch.tensor([[0.0, 0.0], [7.0, 7.0]]), 8, 8)
+    assert torch.allclose(n, torch.tensor([[-1.0, -1.0], [1.0, 1.0]]))
+    t = torch.zeros(2, 2, requires_grad=True)
+    M = K.get_affine_matrix2d(t, torch.full((2, 2), 3.5), torch.ones(2, 2), torch.tensor([10.0, -20.0]))
+    assert M.shape == (2, 3, 3) and M.requires_grad
+    M.sum().backward()
+    assert t.grad is not None and torch.allclose(t.grad, torch.ones(2, 2))
+    Hm = K.get_perspective_transform(torch.tensor([[[0.0, 0], [1, 0], [1, 1], [0, 1]]]), torch.tensor([[[0.0, 0], [2, 0], [2, 2], [0, 2]]]))
+    assert torch.allclose(Hm, torch.diag(torch.tensor([2.0, 2.0, 1.0]))[None], atol=1e-6)
 
 
 def test_validation_matches_reference_conventions():
