@@ -89,6 +89,11 @@ int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype);
 int km_affine_matrix2d_fwd(const void* translations, const void* center, const void* scale, const void* angle, const void* sx,
                            const void* sy, void* out, int B, int dtype, void* stream);
 
+/* Replaces get_perspective_transform (kornia/geometry/transform/imgwarp.py:397-525, Heckbert closed form) as called by
+ * RandomPerspective.compute_transformation (kornia/augmentation/_2d/geometric/perspective.py): one launch instead of ~40.
+ *   points_src, points_dst (B,4,2) -> out (B,3,3) with out[2][2] == 1; dtype KM_F32 or KM_F64. */
+int km_perspective_transform_fwd(const void* points_src, const void* points_dst, void* out, int B, int dtype, void* stream);
+
 /* ---- explicit sampling grid ------------------------------------------------------------------
  * Replaces F.grid_sample(input, grid, mode, padding_mode, align_corners) as called by remap
  * (kornia/geometry/transform/imgwarp.py:702) and by HomographyWarper's cached-grid forward

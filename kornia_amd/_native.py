@@ -31,6 +31,7 @@ _I = c_int
 _PROTOTYPES = {
     "km_homography_chain_fwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "km_homography_chain_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "km_perspective_transform_fwd": [_P, _P, _P, _I, _I, _P],
     "km_affine_matrix2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "km_warp2d_fwd": [_P, _P, _P] + [_I] * 12 + [_P, _I, _P],
     "km_warp2d_bwd": [_P, _P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],

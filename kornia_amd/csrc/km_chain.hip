@@ -236,6 +236,43 @@ static int km_affine_run(const void* trans, const void* center, const void* scal
     return km_check_launch("km_affine_matrix2d_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// get_perspective_transform (kornia/geometry/transform/imgwarp.py:397-525) in one launch: the homography taking four source
+// points onto four destination points, H = Q_dst * adj(Q_src) normalised by H[2][2], with Q the unit-square -> quad map of
+// Heckbert's closed form ("Fundamentals of Texture Mapping and Image Warping", 1989, ch. 2).  One thread per matrix;
+// same formulas as kornia_amd/geometry/transform/builders.py (the differentiable tensor expression).
+template <typename R>
+__device__ __forceinline__ void km_square_to_quad(const R* q, R (&o)[8]) {
+    const R x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
+    const R ex1 = x1 - x2, ex2 = x3 - x2, ey1 = y1 - y2, ey2 = y3 - y2;
+    const R sx = (x0 - x1) + (x2 - x3), sy = (y0 - y1) + (y2 - y3);
+    const R det = ex1 * ey2 - ex2 * ey1;
+    const R g = (sx * ey2 - ex2 * sy) / det, h = (ex1 * sy - sx * ey1) / det;
+    o[0] = (x1 - x0) + g * x1; o[1] = (x3 - x0) + h * x3; o[2] = x0;
+    o[3] = (y1 - y0) + g * y1; o[4] = (y3 - y0) + h * y3; o[5] = y0;
+    o[6] = g; o[7] = h;
+}
+
+template <typename R>
+__global__ __launch_bounds__(64) void km_perspective_transform_kernel(const R* src, const R* dst, R* out, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    R s[8], d[8];
+    km_square_to_quad<R>(src + (size_t)b * 8, s);
+    km_square_to_quad<R>(dst + (size_t)b * 8, d);
+    const R a = s[0], bb = s[1], c = s[2], dd = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+    // adjugate of [[a,b,c],[d,e,f],[g,h,1]]
+    const R j00 = e - f * h, j01 = c * h - bb, j02 = bb * f - c * e;
+    const R j10 = f * g - dd, j11 = a - c * g, j12 = c * dd - a * f;
+    const R j20 = dd * h - e * g, j21 = bb * g - a * h, j22 = a * e - bb * dd;
+    R m[9];
+    m[0] = d[0] * j00 + d[1] * j10 + d[2] * j20; m[1] = d[0] * j01 + d[1] * j11 + d[2] * j21; m[2] = d[0] * j02 + d[1] * j12 + d[2] * j22;
+    m[3] = d[3] * j00 + d[4] * j10 + d[5] * j20; m[4] = d[3] * j01 + d[4] * j11 + d[5] * j21; m[5] = d[3] * j02 + d[4] * j12 + d[5] * j22;
+    m[6] = d[6] * j00 + d[7] * j10 + j20; m[7] = d[6] * j01 + d[7] * j11 + j21; m[8] = d[6] * j02 + d[7] * j12 + j22;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[(size_t)b * 9 + k] = m[k] / m[8];
+}
+
 extern "C" {
 
 // M: (B,rows,3) pixel src->dst matrix, rows in {2,3}; A_out/m_out: (B,9), either may be null.
@@ -271,6 +308,21 @@ int km_affine_matrix2d_fwd(const void* translations, const void* center, const v
     KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_affine_matrix2d_fwd: dtype must be f32/f64");
     if (dtype == KM_F32) return km_affine_run<float>(translations, center, scale, angle, sx, sy, out, B, (hipStream_t)stream);
     return km_affine_run<double>(translations, center, scale, angle, sx, sy, out, B, (hipStream_t)stream);
+}
+
+// points_src / points_dst (B,4,2) -> out (B,3,3), H[2][2] == 1; dtype f32 / f64.
+int km_perspective_transform_fwd(const void* points_src, const void* points_dst, void* out, int B, int dtype, void* stream) {
+    if (B == 0) return 0;
+    KM_REQUIRE(points_src && points_dst && out, "km_perspective_transform_fwd: null pointer");
+    KM_REQUIRE(B > 0, "km_perspective_transform_fwd: bad batch size %d", B);
+    KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_perspective_transform_fwd: dtype must be f32/f64");
+    if (dtype == KM_F32)
+        hipLaunchKernelGGL(km_perspective_transform_kernel<float>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)points_src,
+                           (const float*)points_dst, (float*)out, B);
+    else
+        hipLaunchKernelGGL(km_perspective_transform_kernel<double>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double*)points_src,
+                           (const double*)points_dst, (double*)out, B);
+    return km_check_launch("km_perspective_transform_fwd");
 }
 
 }  // extern "C"

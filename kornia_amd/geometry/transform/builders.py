@@ -88,6 +88,17 @@ def get_perspective_transform(points_src: torch.Tensor, points_dst: torch.Tensor
     KORNIA_CHECK(points_src.dtype == points_dst.dtype, "Source data type must match Destination data type.")
     dtype = points_src.dtype
     work = dtype if dtype in (torch.float32, torch.float64) else torch.float32
+    if points_src.is_cuda and points_dst.is_cuda and not (torch.is_grad_enabled() and (points_src.requires_grad or points_dst.requires_grad)):
+        from ... import _native as N
+
+        if N.is_built() and dtype in (torch.float32, torch.float64, torch.bfloat16, torch.float16):
+            # one launch (km_perspective_transform_fwd, same formulas); inputs that need gradients take the expression below
+            ps, pd = points_src.detach().to(work).contiguous(), points_dst.detach().to(work).contiguous()
+            out = torch.empty(ps.shape[0], 3, 3, device=ps.device, dtype=work)
+            with N.device_guard(ps.device):
+                N.check(N.lib().km_perspective_transform_fwd(ps.data_ptr(), pd.data_ptr(), out.data_ptr(), ps.shape[0], N.dtype_code(work),
+                                                             N.stream_ptr(ps.device)), "km_perspective_transform_fwd")
+            return out.to(dtype)
     a, b, c, d, e, f, g, h = _square_to_quad(points_src.to(work))
     A, Bq, C, D, E, Fq, G, Hq = _square_to_quad(points_dst.to(work))
     # adjugate of [[a,b,c],[d,e,f],[g,h,1]]

@@ -29,6 +29,7 @@ _NATIVE = {
         "warp_grid": _g.warp_grid,
         "remap": _g.remap,
         "get_affine_matrix2d": _g.get_affine_matrix2d,  # RandomAffine.compute_transformation: one launch instead of ~45
+        "get_perspective_transform": _g.get_perspective_transform,  # RandomPerspective / crops: one launch instead of ~40
     },
     "kornia.geometry.linalg": {"transform_points": _g.transform_points},
     "kornia.geometry.conversions": {"normalize_homography": _g.normalize_homography},

@@ -108,3 +108,18 @@ def test_native_affine_matrix_kernel_matches_reference_and_tensor_expression():
     ref64 = T.get_affine_matrix2d(tr.double().cpu(), c.double().cpu(), s.double().cpu(), a.double().cpu(), sx.double().cpu(), sy.double().cpu())
     torch.testing.assert_close(out64.cpu(), ref64, rtol=1e-10, atol=1e-9)
     assert T.get_affine_matrix2d(tr.bfloat16(), c.bfloat16(), s.bfloat16(), a.bfloat16()).dtype == torch.bfloat16
+
+
+@pytest.mark.gpu
+def test_native_perspective_transform_kernel():
+    """km_perspective_transform_fwd vs the reference fixture, the tensor expression (grad path) and the point mapping."""
+    d = golden("builders")
+    ps, pd = _t(d, "ps", "cuda"), _t(d, "pd", "cuda")
+    H = T.get_perspective_transform(ps, pd)
+    torch.testing.assert_close(H.cpu(), _t(d, "H"), rtol=2e-4, atol=2e-5)
+    H_expr = T.get_perspective_transform(ps.clone().requires_grad_(), pd)
+    assert H_expr.requires_grad
+    torch.testing.assert_close(H, H_expr.detach(), rtol=2e-5, atol=2e-6)
+    H64 = T.get_perspective_transform(ps.double(), pd.double())
+    torch.testing.assert_close(H64.cpu(), _t(d, "H64"), rtol=1e-9, atol=1e-11)
+    assert T.get_perspective_transform(ps.half(), pd.half()).dtype == torch.float16
