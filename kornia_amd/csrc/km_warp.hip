@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
 // rows predicated instead of early-exited, (x0, x0+1) fetched with one load when the whole wave samples
 // inside the image.  Ablation on MI355X (256x3x512^2): ALU/issue alone 0.29 ms, loads +0.12, stores +0.11,
 // barely overlapped in the generic kernel - instruction count is what bounds this kernel, not HBM.
-template <typename T, int CM, int NC>  // NC = 3: RGB unrolled ; NC = 0: runtime channel loop
+template <typename T, int CM, int NC>  // NC = 3 / 1: RGB / grey unrolled ; NC = 0: runtime channel loop
 __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T> a) {
     typedef typename KmTraits<T>::R R;
     const KmWarpGeom<R>& g = a.g;
@@ -271,12 +271,13 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
         km_bilinear_setup(x, y, W, H, t[r]);
         inside = inside && t[r].b00 && t[r].b01 && t[r].b10 && t[r].b11;
     }
-    if (NC == 3 && __all(inside)) {
-        R v[KM_ROWS][3][4];
+    if (NC > 0 && __all(inside)) {
+        constexpr int NCC = NC > 0 ? NC : 1;
+        R v[KM_ROWS][NCC][4];
 #pragma unroll
         for (int r = 0; r < KM_ROWS; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < NCC; ++c) {
                 km_ld2(src_b + c * src_plane + t[r].i00, v[r][c][0], v[r][c][1]);
                 km_ld2(src_b + c * src_plane + t[r].i10, v[r][c][2], v[r][c][3]);
             }
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
         for (int r = 0; r < KM_ROWS; ++r) {
             T* __restrict__ out_px = dst_b + (size_t)(row_ok[r] ? i_base + r * PH : 0) * g.w + j;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < NCC; ++c) {
                 const R acc = km_fma(v[r][c][3], t[r].w11, km_fma(v[r][c][2], t[r].w10, km_fma(v[r][c][1], t[r].w01, km_fma(v[r][c][0], t[r].w00, (R)0))));
                 if (row_ok[r]) km_st(out_px + c * dst_plane, acc);
             }
@@ -520,6 +521,8 @@ static int km_warp_launch(bool bwd, const KmWarpArgs<T>& a, hipStream_t s) {
     else if (INTERP == KM_INTERP_BILINEAR && a.g.pad == KM_PAD_ZEROS && a.g.W >= 2 && !km_fwd_generic_forced()) {
         if (a.g.C == 3)
             hipLaunchKernelGGL((km_warp_fwd_bz_kernel<T, CM, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+        else if (a.g.C == 1)
+            hipLaunchKernelGGL((km_warp_fwd_bz_kernel<T, CM, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((km_warp_fwd_bz_kernel<T, CM, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
     } else

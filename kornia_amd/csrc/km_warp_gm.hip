@@ -41,7 +41,7 @@ struct KmWarpGmArgs {
     uint32_t tiles_x, tiles_y, nblocks;
 };
 
-template <typename T, int CM, int NC>  // NC = 3: RGB unrolled ; NC = 0: runtime channel loop
+template <typename T, int CM, int NC>  // NC = 3 / 1: RGB / grey unrolled ; NC = 0: runtime channel loop
 __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a) {
     typedef float R;
     const KmWarpGeom<R>& g = a.g;
@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
             gix[q] = 0;
             giy[q] = 0;
         }
-        if (NC == 3 && __all(inside)) {
-            R go[KMG_GROUP][3], v[KMG_GROUP][3][4];
+        if (NC > 0 && __all(inside)) {
+            constexpr int NCC = NC > 0 ? NC : 1;
+            R go[KMG_GROUP][NCC], v[KMG_GROUP][NCC][4];
 #pragma unroll
             for (int q = 0; q < KMG_GROUP; ++q)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < NCC; ++c) {
                     go[q][c] = (R)km_ld(km_at(gout_b + c * dst_plane, go_off[q]));
                     km_ld2(km_at(src_b + c * src_plane, (uint32_t)t[q].i00), v[q][c][0], v[q][c][1]);
                     km_ld2(km_at(src_b + c * src_plane, (uint32_t)t[q].i10), v[q][c][2], v[q][c][3]);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a
 #pragma unroll
             for (int q = 0; q < KMG_GROUP; ++q)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < NCC; ++c) {
                     R s00 = v[q][c][0], s01 = v[q][c][1], s10 = v[q][c][2], s11 = v[q][c][3];
                     if (is_fill) {  // same rounding sequence as the oracle: (v - fill) first
                         const R f = a.fill[c];
@@ -193,6 +194,8 @@ template <typename T, int CM>
 static int kmg_launch(const KmWarpGmArgs<T>& a, hipStream_t s) {
     if (a.g.C == 3)
         hipLaunchKernelGGL((km_warp_gm_kernel<T, CM, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else if (a.g.C == 1)
+        hipLaunchKernelGGL((km_warp_gm_kernel<T, CM, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((km_warp_gm_kernel<T, CM, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
     return km_check_launch("km_warp2d_bwd(matrix gradient)");
