@@ -30,3 +30,11 @@ def oracle():
 
     _oracle.build()
     return _oracle
+
+
+@pytest.fixture(autouse=True)
+def _seed_everything():
+    """Every test starts from the same RNG state (host and every HIP device): tensors drawn without an explicit generator
+    are reproducible, so a tolerance that holds once holds on every run."""
+    torch.manual_seed(1234)
+    yield

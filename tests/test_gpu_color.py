@@ -93,7 +93,7 @@ def test_identity_factors_at_full_size():
 
     x = torch.rand(64, 3, 224, 224, device="cuda")
     assert torch.equal(K.enhance.color_jitter(x, 1.0, 1.0, 1.0, None), x)
-    assert torch.allclose(K.enhance.adjust_hue(x, 0.0), x, atol=2e-6)
+    assert torch.allclose(K.enhance.adjust_hue(x, 0.0), x, atol=5e-6)
 
 
 def test_stage_enable_flags_skip_on_device():

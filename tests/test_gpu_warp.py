@@ -193,9 +193,10 @@ def test_half_precision_against_fp32_oracle(oracle, dtype, tol):
 def test_identity_is_exact_and_errors():
     import kornia_amd as K
 
-    x = torch.rand(2, 3, 16, 20).cuda()
+    x = torch.rand(2, 3, 16, 20, generator=torch.Generator().manual_seed(0)).cuda()
     eye = torch.eye(3)[None].expand(2, 3, 3).contiguous().cuda()
-    assert torch.allclose(K.warp_perspective(x, eye, (16, 20)), x, atol=1e-6)
+    # the sampling positions of an identity warp are integers up to one fp32 ulp of the coordinate (2e-6 at x = 19)
+    assert torch.allclose(K.warp_perspective(x, eye, (16, 20)), x, atol=5e-6)
     with pytest.raises(TypeError):
         K.warp_perspective(x, [1, 2, 3], (4, 4))
     with pytest.raises(ValueError):
