@@ -1,3 +1,4 @@
+from .affwarp import affine, rotate, scale, shear, translate
 from .builders import (
     angle_to_rotation_matrix,
     deg2rad,
@@ -7,11 +8,21 @@ from .builders import (
     get_shear_matrix2d,
     get_translation_matrix2d,
 )
+from .crop2d import center_crop, crop_and_resize, crop_by_boxes, crop_by_transform_mat
 from .homography_warper import HomographyWarper
 from .imgwarp import grid_sample, homography_warp, remap, warp_affine, warp_grid, warp_perspective
 
 __all__ = [
     "HomographyWarper",
+    "affine",
+    "center_crop",
+    "crop_and_resize",
+    "crop_by_boxes",
+    "crop_by_transform_mat",
+    "rotate",
+    "scale",
+    "shear",
+    "translate",
     "angle_to_rotation_matrix",
     "deg2rad",
     "get_affine_matrix2d",

@@ -275,6 +275,39 @@ def main():
     save("color_jitter", **dc)
 
 
+    # ---- callers of the warps: affwarp.py / crop2d.py helpers --------------------------------
+    dh = {}
+    xh = torch.rand(3, 2, 21, 30, generator=g)
+    ang = torch.tensor([12.0, -35.0, 80.0])
+    trn = torch.tensor([[2.5, -1.0], [0.0, 3.25], [-4.0, 1.5]])
+    scl = torch.tensor([[1.2, 0.8], [0.7, 0.7], [1.0, 1.5]])
+    shr = torch.tensor([[0.2, 0.0], [0.0, -0.3], [0.15, 0.1]])
+    Aff = rotation_affines(3, 21, 30, g)
+    dh.update(x=xh, angle=ang, trans=trn, scale_in=scl, shear_in=shr, A=Aff)
+    dh["rotate"] = T.rotate(xh, ang)
+    dh["rotate_center_nearest"] = T.rotate(xh, ang, center=torch.tensor([[10.0, 5.0]]).expand(3, -1), mode="nearest", padding_mode="border")
+    dh["translate"] = T.translate(xh, trn)
+    dh["scale"] = T.scale(xh, scl)
+    dh["scale_iso"] = T.scale(xh, torch.tensor([1.3]))
+    dh["shear"] = T.shear(xh, shr)
+    dh["affine"] = T.affine(xh, Aff)
+    dh["affine_unbatched"] = T.affine(xh[0], Aff[:1])
+    boxes = torch.tensor([[[3.0, 2.0], [20.0, 4.0], [22.0, 15.0], [2.0, 13.0]],
+                          [[5.0, 5.0], [25.0, 5.0], [25.0, 18.0], [5.0, 18.0]],
+                          [[0.0, 0.0], [29.0, 0.0], [29.0, 20.0], [0.0, 20.0]]])
+    dh["boxes"] = boxes
+    dh["crop_and_resize"] = T.crop_and_resize(xh, boxes, (9, 14))
+    dh["crop_and_resize_ac0"] = T.crop_and_resize(xh, boxes, (9, 14), align_corners=False)
+    dh["center_crop"] = T.center_crop(xh, (10, 16))
+    dh["center_crop_odd_nearest"] = T.center_crop(xh, (7, 9), mode="nearest")
+    dstb = torch.tensor([[[0.0, 0.0], [11.0, 0.0], [11.0, 7.0], [0.0, 7.0]]]).expand(3, -1, -1)
+    dh["crop_by_boxes"] = T.crop_by_boxes(xh, boxes, dstb)
+    Mc = T.get_perspective_transform(boxes, dstb)
+    dh["crop_by_transform_mat"] = T.crop_by_transform_mat(xh, Mc, (8, 12))
+    dh["crop_by_transform_mat_affine"] = T.crop_by_transform_mat(xh, Aff, (8, 12), align_corners=False)
+    save("warp_callers", **dh)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     main()
