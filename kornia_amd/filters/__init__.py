@@ -1,3 +1,13 @@
+from .blur import (
+    BoxBlur,
+    Laplacian,
+    box_blur,
+    get_box_kernel1d,
+    get_box_kernel2d,
+    get_laplacian_kernel1d,
+    get_laplacian_kernel2d,
+    laplacian,
+)
 from .filter import filter2d, filter2d_separable
 from .gaussian import GaussianBlur2d, gaussian_blur2d
 from .kernels import (

@@ -307,6 +307,17 @@ def main():
     dh["crop_by_transform_mat_affine"] = T.crop_by_transform_mat(xh, Aff, (8, 12), align_corners=False)
     save("warp_callers", **dh)
 
+    # ---- callers of filter2d: box_blur / laplacian -----------------------------------------------------------------
+    db2 = {}
+    xb2 = torch.rand(2, 3, 20, 28, generator=g)
+    db2["x"] = xb2
+    db2["box3"] = F.box_blur(xb2, 3)
+    db2["box35_sep_replicate"] = F.box_blur(xb2, (3, 5), "replicate", separable=True)
+    db2["box57_constant"] = F.box_blur(xb2, (5, 7), "constant")
+    db2["lap3"] = F.laplacian(xb2, 3)
+    db2["lap5_unnorm_circular"] = F.laplacian(xb2, 5, "circular", normalized=False)
+    save("filter_callers", **db2)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

@@ -79,3 +79,32 @@ def test_on_device_against_reference_fixtures():
 
     d = golden("warp_callers")
     _compare(_run_all(K.geometry.transform, d, "cuda"), d)
+
+
+def _run_filter_callers(F, x):
+    return {"box3": F.box_blur(x, 3), "box35_sep_replicate": F.box_blur(x, (3, 5), "replicate", separable=True),
+            "box57_constant": F.box_blur(x, (5, 7), "constant"), "lap3": F.laplacian(x, 3),
+            "lap5_unnorm_circular": F.Laplacian(5, "circular", normalized=False)(x)}
+
+
+def test_filter_callers_host_logic(oracle, monkeypatch):
+    """box_blur / laplacian: tap construction + dispatch, with the oracle's filter2d standing in for the device op."""
+    import kornia_amd as K
+    from kornia_amd.filters import blur
+
+    monkeypatch.setattr(blur, "filter2d", lambda x, k, border="reflect": oracle.filter2d(x, k, border))
+    monkeypatch.setattr(blur, "filter2d_separable", lambda x, kx, ky, border="reflect": oracle.filter2d_separable(x, kx, ky, border))
+    d = golden("filter_callers")
+    for k, v in _run_filter_callers(K.filters, _t(d, "x")).items():
+        assert torch.equal(v, _t(d, k)), k
+    assert torch.equal(K.filters.get_laplacian_kernel1d(5), torch.tensor([1.0, 1.0, -4.0, 1.0, 1.0]))
+    assert K.filters.get_box_kernel2d((3, 5)).shape == (1, 3, 5)
+
+
+@pytest.mark.gpu
+def test_filter_callers_on_device():
+    import kornia_amd as K
+
+    d = golden("filter_callers")
+    for k, v in _run_filter_callers(K.filters, _t(d, "x", "cuda")).items():
+        assert torch.equal(v.cpu(), _t(d, k)), k
