@@ -1,12 +1,14 @@
 from .blur import (
     BoxBlur,
     Laplacian,
+    UnsharpMask,
     box_blur,
     get_box_kernel1d,
     get_box_kernel2d,
     get_laplacian_kernel1d,
     get_laplacian_kernel2d,
     laplacian,
+    unsharp_mask,
 )
 from .filter import filter2d, filter2d_separable
 from .gaussian import GaussianBlur2d, gaussian_blur2d

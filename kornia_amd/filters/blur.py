@@ -15,7 +15,7 @@ from ..core.check import KORNIA_CHECK_IS_TENSOR
 from .filter import filter2d, filter2d_separable
 from .kernels import _check_kernel_size, _unpack_2d_ks, normalize_kernel2d
 
-__all__ = ["BoxBlur", "Laplacian", "box_blur", "get_box_kernel1d", "get_box_kernel2d", "get_laplacian_kernel1d", "get_laplacian_kernel2d",
+__all__ = ["BoxBlur", "Laplacian", "UnsharpMask", "box_blur", "unsharp_mask", "get_box_kernel1d", "get_box_kernel2d", "get_laplacian_kernel1d", "get_laplacian_kernel2d",
            "laplacian"]
 
 
@@ -63,6 +63,27 @@ def laplacian(input: torch.Tensor, kernel_size, border_type: str = "reflect", no
     if normalized:
         kernel = normalize_kernel2d(kernel)
     return filter2d(input, kernel, border_type)
+
+
+def unsharp_mask(input: torch.Tensor, kernel_size, sigma, border_type: str = "reflect") -> torch.Tensor:
+    """``blur + 2 * (input - blur)`` with a Gaussian blur (kornia/filters/unsharp.py:28-61: ``torch.lerp(blur, input, 2)``).
+    The blur is the native kernel; the lerp is one elementwise pass left to PyTorch (not yet folded into the blur's epilogue)."""
+    from .gaussian import gaussian_blur2d
+
+    return torch.lerp(gaussian_blur2d(input, kernel_size, sigma, border_type), input, weight=2.0)
+
+
+class UnsharpMask(nn.Module):
+    """Module form of :func:`unsharp_mask`."""
+
+    def __init__(self, kernel_size, sigma, border_type: str = "reflect") -> None:
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.sigma = sigma
+        self.border_type = border_type
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return unsharp_mask(input, self.kernel_size, self.sigma, self.border_type)
 
 
 class BoxBlur(nn.Module):

@@ -316,6 +316,7 @@ def main():
     db2["box57_constant"] = F.box_blur(xb2, (5, 7), "constant")
     db2["lap3"] = F.laplacian(xb2, 3)
     db2["lap5_unnorm_circular"] = F.laplacian(xb2, 5, "circular", normalized=False)
+    db2["unsharp"] = F.unsharp_mask(xb2, (5, 5), (1.5, 1.5))
     save("filter_callers", **db2)
 
 
