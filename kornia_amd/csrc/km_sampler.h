@@ -17,6 +17,7 @@ enum { KM_COORD_PERSPECTIVE = 0, KM_COORD_AFFINE = 1, KM_COORD_HOMOGRAPHY = 2, K
 enum { KM_INTERP_NEAREST = 0, KM_INTERP_BILINEAR = 1, KM_INTERP_BICUBIC = 2 };
 enum { KM_PAD_ZEROS = 0, KM_PAD_BORDER = 1, KM_PAD_REFLECTION = 2, KM_PAD_FILL = 3 };
 
+// [host-testable begin: coords]  (tests/test_tile_box_spec.py compiles this span for the host with g++)
 // Per-launch geometry shared by forward and backward.
 template <typename R>
 struct KmWarpGeom {
@@ -65,6 +66,7 @@ __device__ __forceinline__ R km_base_y(const KmWarpGeom<R>& g, int i) {
     if (CM == KM_COORD_AFFINE) return km_linspace<R>(g.lin_lo_y, g.lin_hi_y, g.lin_step_y, g.h, i);
     return g.norm_coords ? km_mesh<R>(i, g.h) : (R)i;
 }
+// [host-testable end: coords]
 
 template <typename R, int CM>
 __device__ __forceinline__ void km_gen_coord(const R (&m)[9], R u, R v, KmCoord<R>& c) {

@@ -52,6 +52,7 @@ struct KmWarpTiledArgs {
     uint32_t tiles_x, tiles_y, nblocks;
 };
 
+// [host-testable begin: tile_box]  (tests/test_tile_box_spec.py compiles this span for the host with g++)
 template <int CM>
 __device__ __forceinline__ void kmt_index_affine(const KmWarpGeom<float>& g, int n, float lo, float step, float& scale, float& offs) {
     // base coordinate u -> output index:  idx = scale * u + offs   (inverse of km_base_x / km_base_y)
@@ -209,6 +210,7 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
     o.fixed_ok = o.mult <= 256.f;  // beyond ~7x magnification the head-room would eat the mantissa: float path
     return o;
 }
+// [host-testable end: tile_box]
 
 // block-uniform values computed with VALU float math live in VGPRs unless moved to SGPRs explicitly
 __device__ __forceinline__ float kmt_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }

@@ -1,0 +1,236 @@
+"""CPU: executable specification of the owner-tile box (kmt_tile_box, kornia_amd/csrc/km_warp_bwd_tiled.hip).
+
+The backward scatter is only correct if the box of output pixels a workgroup visits contains EVERY output pixel whose
+bilinear footprint touches its source tile.  The kernel source between the `[host-testable ...]` markers is extracted
+verbatim, compiled for the host with g++ (the same -ffp-contract=off), and checked against brute force: for random
+homographies (any rotation, 0.3x-3x scale, translation, perspective) every output pixel's fp32 sampling position is
+recomputed with the forward's arithmetic, and all pixels touching the tile must lie inside the box.  Also bounds the
+over-scan, so the margins cannot silently degrade into "visit everything"."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kornia_amd", "csrc")
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+SHIM = r"""
+#include <algorithm>
+#include <cmath>
+#define __device__
+#define __forceinline__ inline
+using std::max;
+using std::min;
+enum { KM_COORD_PERSPECTIVE = 0, KM_COORD_AFFINE = 1, KM_COORD_HOMOGRAPHY = 2, KM_COORD_GRID = 3 };
+static inline float km_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline double km_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+"""
+
+WRAP = r"""
+template <int CM>
+static void run(const float* m9, int H, int W, int h, int w, int align, int norm, int X0, int X1, int Y0, int Y1, int* out) {
+    KmWarpGeom<float> g;
+    g.B = 1; g.C = 1; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = 1;
+    g.coord_mode = CM; g.norm_coords = norm; g.interp = 1; g.pad = 0; g.align = align;
+    if (align) { g.lin_lo_x = -1.0f; g.lin_hi_x = 1.0f; g.lin_lo_y = -1.0f; g.lin_hi_y = 1.0f; }
+    else {
+        g.lin_lo_x = (float)(-1.0 + 1.0 / w); g.lin_hi_x = (float)(1.0 - 1.0 / w);
+        g.lin_lo_y = (float)(-1.0 + 1.0 / h); g.lin_hi_y = (float)(1.0 - 1.0 / h);
+    }
+    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (float)(w - 1) : 0.0f;
+    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (float)(h - 1) : 0.0f;
+    float m[9];
+    for (int k = 0; k < 9; ++k) m[k] = m9[k];
+    const KmtBox b = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
+    out[0] = b.j0; out[1] = b.j1; out[2] = b.i0; out[3] = b.i1; out[4] = b.fixed_ok ? 1 : 0; out[5] = (int)b.mult;
+}
+extern "C" void tile_box(int cm, const float* m9, int H, int W, int h, int w, int align, int norm, int X0, int X1, int Y0, int Y1, int* out) {
+    if (cm == 0) run<KM_COORD_PERSPECTIVE>(m9, H, W, h, w, align, norm, X0, X1, Y0, Y1, out);
+    else if (cm == 1) run<KM_COORD_AFFINE>(m9, H, W, h, w, align, norm, X0, X1, Y0, Y1, out);
+    else run<KM_COORD_HOMOGRAPHY>(m9, H, W, h, w, align, norm, X0, X1, Y0, Y1, out);
+}
+"""
+
+
+def _span(path, tag):
+    text = open(path).read()
+    m = re.search(r"// \[host-testable begin: %s\][^\n]*\n(.*?)// \[host-testable end: %s\]" % (tag, tag), text, re.S)
+    assert m, f"markers for {tag} not found in {path}"
+    return m.group(1)
+
+
+def _build(name, mutate=None):
+    os.makedirs(BUILD, exist_ok=True)
+    src = os.path.join(BUILD, name + ".cpp")
+    so = os.path.join(BUILD, "lib" + name + ".so")
+    box = _span(os.path.join(CSRC, "km_warp_bwd_tiled.hip"), "tile_box")
+    if mutate is not None:
+        box = mutate(box)
+    code = SHIM + _span(os.path.join(CSRC, "km_sampler.h"), "coords") + "\n#define KMT_TIGHT_BOX 1\n" + box + WRAP
+    open(src, "w").write(code)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", src, "-o", so], check=True)
+    lib = ctypes.CDLL(so)
+    lib.tile_box.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_float)] + [ctypes.c_int] * 10 + [ctypes.POINTER(ctypes.c_int)]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def boxlib():
+    return _build("tile_box_host")
+
+
+f32 = np.float32
+
+
+def _linspace(lo, hi, n):
+    """torch.linspace's two-sided fused formula (km_linspace), in fp32."""
+    lo, hi = f32(lo), f32(hi)
+    step = (hi - lo) / f32(n - 1)
+    i = np.arange(n)
+    a = (step.astype(np.float64) * i + lo).astype(f32)
+    b = (hi - step.astype(np.float64) * (n - 1 - i)).astype(f32)
+    return np.where(i < n // 2, a, b)
+
+
+def _fma(a, b, c):
+    return (a.astype(np.float64) * b + c).astype(f32)
+
+
+def _forward_positions(cm, norm, m, H, W, h, w, align):
+    """fp32 sampling positions of every output pixel, in the forward kernel's operation order (km_gen_coord)."""
+    mesh_u = ((np.arange(w, dtype=f32) / f32(w - 1)) - f32(0.5)) * f32(2.0)
+    mesh_v = ((np.arange(h, dtype=f32) / f32(h - 1)) - f32(0.5)) * f32(2.0)
+    if cm == 1:
+        u = _linspace(-1.0, 1.0, w) if align else _linspace(-1.0 + 1.0 / w, 1.0 - 1.0 / w, w)
+        v = _linspace(-1.0, 1.0, h) if align else _linspace(-1.0 + 1.0 / h, 1.0 - 1.0 / h, h)
+    elif cm == 2 and not norm:
+        u, v = np.arange(w, dtype=f32), np.arange(h, dtype=f32)
+    else:
+        u, v = mesh_u, mesh_v
+    U, V = np.meshgrid(u, v)
+    with np.errstate(all="ignore"):
+        if cm == 0:
+            den = (m[6] * U + m[7] * V) + m[8]
+            gx = ((m[0] * U + m[1] * V) + m[2]) / den
+            gy = ((m[3] * U + m[4] * V) + m[5]) / den
+        elif cm == 1:
+            gx = (m[0] * U + m[1] * V) + m[2]
+            gy = (m[3] * U + m[4] * V) + m[5]
+        else:
+            X = _fma(V, m[1], U * m[0]) + m[2]
+            Y = _fma(V, m[4], U * m[3]) + m[5]
+            Z = _fma(V, m[7], U * m[6]) + m[8]
+            sc = np.where(np.abs(Z) > f32(1e-8), f32(1) / (Z + f32(1e-8)), f32(1))
+            gx, gy = sc * X, sc * Y
+        if align:
+            x = ((gx + f32(1)) / f32(2)) * f32(W - 1)
+            y = ((gy + f32(1)) / f32(2)) * f32(H - 1)
+        else:  # one fused multiply-add: exact in float64, rounded once
+            x = ((gx + f32(1)).astype(np.float64) * (W / 2) - 0.5).astype(f32)
+            y = ((gy + f32(1)).astype(np.float64) * (H / 2) - 0.5).astype(f32)
+    return x, y
+
+
+def _normalized_inverse(M, H, W, h, w, pixel_base=False, affine=False):
+    def N(hh, ww):
+        return np.array([[2.0 / (ww - 1), 0, -1], [0, 2.0 / (hh - 1), -1], [0, 0, 1]])
+
+    A = np.linalg.inv(N(h, w) @ M @ np.linalg.inv(N(H, W)))
+    if pixel_base:  # base coordinates are output pixel indices: fold the output normalisation into the matrix
+        A = A @ N(h, w)
+    A = A / A[2, 2] if affine else A
+    return A.astype(f32).reshape(9)
+
+
+def _random_M(rng, H, W, h, w, perspective):
+    ang = rng.uniform(-math.pi, math.pi)
+    sc = math.exp(rng.uniform(-math.log(3), math.log(3))) * min(h, w) / min(H, W)
+    c, s = math.cos(ang) * sc, math.sin(ang) * sc
+    cs, cd = np.array([(W - 1) / 2, (H - 1) / 2]), np.array([(w - 1) / 2, (h - 1) / 2])
+    M = np.eye(3)
+    M[:2, :2] = [[c, -s], [s, c]]
+    M[:2, 2] = cd + rng.uniform(-0.3, 0.3, 2) * [w, h] - M[:2, :2] @ cs
+    M[2, :2] = rng.uniform(-1, 1, 2) * perspective / max(W, H)
+    return M
+
+
+def _sweep(boxlib, perspective, cases=60, cm=0, norm=1):
+    rng = np.random.default_rng(7 + int(perspective * 10))
+    out = (ctypes.c_int * 6)()
+    whole = checked = 0
+    visited = touching = 0
+    for case in range(cases):
+        H, W, h, w = (int(rng.integers(40, 200)) for _ in range(4))
+        align = int(rng.integers(0, 2))
+        m = _normalized_inverse(_random_M(rng, H, W, h, w, perspective), H, W, h, w, pixel_base=(cm == 2 and not norm), affine=(cm == 1))
+        x, y = _forward_positions(cm, norm, m, H, W, h, w, align)
+        xf, yf = np.floor(x), np.floor(y)
+        for _ in range(6):
+            X0 = int(rng.integers(0, max(1, (W + 63) // 64))) * 64
+            Y0 = int(rng.integers(0, max(1, (H + 63) // 64))) * 64
+            X1, Y1 = min(X0 + 64, W), min(Y0 + 64, H)
+            boxlib.tile_box(cm, m.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), H, W, h, w, align, norm, X0, X1, Y0, Y1, out)
+            j0, j1, i0, i1 = out[0], out[1], out[2], out[3]
+            with np.errstate(invalid="ignore"):
+                touch = (xf >= X0 - 1) & (xf <= X1 - 1) & (yf >= Y0 - 1) & (yf <= Y1 - 1)
+            ii, jj = np.nonzero(touch)
+            checked += 1
+            if ii.size:
+                assert jj.min() >= j0 and jj.max() <= j1 and ii.min() >= i0 and ii.max() <= i1, \
+                    f"box ({j0}..{j1}, {i0}..{i1}) misses touching pixels j {jj.min()}..{jj.max()}, i {ii.min()}..{ii.max()} " \
+                    f"(tile {X0},{Y0}, {H}x{W}->{h}x{w}, align {align})"
+            if (j0, j1, i0, i1) == (0, w - 1, 0, h - 1):
+                whole += 1
+            else:
+                visited += max(0, j1 - j0 + 1) * max(0, i1 - i0 + 1)
+                touching += int(ii.size)
+    return whole, checked, visited, touching
+
+
+@pytest.mark.parametrize("cm,norm,perspective", [(0, 1, 0.0), (0, 1, 0.5), (0, 1, 3.0), (1, 1, 0.0), (2, 1, 0.5), (2, 0, 0.5), (2, 0, 0.0)])
+def test_box_contains_every_touching_pixel(boxlib, cm, norm, perspective):
+    """cm 0: warp_perspective, 1: warp_affine (linspace base grid), 2: homography_warp (normalised / pixel base grid)."""
+    whole, checked, visited, touching = _sweep(boxlib, perspective, cm=cm, norm=norm)
+    assert touching > 20000  # the sweep is not vacuous
+    # the box must stay tight: few tiles may fall back to the whole output, and the rest over-scan the bounding box of
+    # the touching pixels only moderately (a rotated tile's axis-aligned box is up to 2x its area by geometry alone)
+    assert whole <= 0.25 * checked, f"{whole} of {checked} tiles scan the whole output"
+    assert visited <= 3.2 * max(touching, 1) + 200 * checked, (visited, touching)
+
+
+def test_spec_has_teeth():
+    """A box whose final margin is shaved by a few pixels must be caught by the same sweep."""
+    def shave(src):
+        old = "o.j0 = max(0, (int)floorf(jmin - mj));"
+        assert old in src
+        return src.replace(old, "o.j0 = max(0, (int)floorf(jmin - mj) + 3);")
+
+    with pytest.raises(AssertionError, match="misses touching pixels"):
+        _sweep(_build("tile_box_host_mutant", shave), 0.5)
+
+
+@pytest.mark.parametrize("cm,norm", [(0, 1), (1, 1), (2, 1), (2, 0)])
+def test_brute_force_positions_are_the_forward(oracle, cm, norm):
+    """The numpy positions above are the ones the (golden-pinned) oracle forward samples at: nearest-neighbour warps of
+    an index image return exactly nearbyint(x), nearbyint(y) wherever that lands inside the source."""
+    import torch
+
+    O = oracle
+    rng = np.random.default_rng(100 + cm * 2 + norm)
+    for align in (0, 1):
+        H, W, h, w = 61, 83, 57, 90
+        m = _normalized_inverse(_random_M(rng, H, W, h, w, 0.0 if cm == 1 else 0.5), H, W, h, w, pixel_base=(cm == 2 and not norm), affine=(cm == 1))
+        x, y = _forward_positions(cm, norm, m, H, W, h, w, align)
+        yy, xx = np.meshgrid(np.arange(H, dtype=f32), np.arange(W, dtype=f32), indexing="ij")
+        src = torch.from_numpy(np.stack([xx, yy])[None] + f32(1))  # +1: zeros padding stays distinguishable
+        out = O._warp_fwd(src, torch.from_numpy(m)[None], (h, w), cm, norm, "nearest", "zeros", bool(align), None).numpy()[0]
+        rx, ry = np.rint(x), np.rint(y)
+        inside = (rx >= 0) & (rx <= W - 1) & (ry >= 0) & (ry <= H - 1)
+        assert inside.sum() > 500
+        assert np.array_equal(out[0][inside], rx[inside] + 1) and np.array_equal(out[1][inside], ry[inside] + 1)
+        assert not out[0][~inside & np.isfinite(x) & np.isfinite(y)].any()
