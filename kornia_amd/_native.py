@@ -124,6 +124,11 @@ def require_device(t: torch.Tensor, name: str) -> None:
         )
 
 
+def on_device(t: torch.Tensor) -> bool:
+    """True when ``t`` lives in HIP device memory (the only place the native kernels can read)."""
+    return t.is_cuda
+
+
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 

@@ -207,7 +207,7 @@ def filter2d_separable(
         and input.dim() == 4 and kernel_x.dim() == 2 and kernel_y.dim() == 2
         and kernel_x.shape[0] == kernel_y.shape[0]
         and not (kernel_x.requires_grad or kernel_y.requires_grad)
-        and input.is_cuda
+        and N.on_device(input)
     )
     if fused:
         _validate(input, kernel_x[..., None, :], ["B", "H", "W"], border_type, padding)

@@ -7,6 +7,7 @@ from typing import Union
 import torch
 from torch import nn
 
+from .. import _native as N
 from ..core.check import KORNIA_CHECK, KORNIA_CHECK_IS_TENSOR, KORNIA_CHECK_SHAPE
 from .filter import filter2d, filter2d_separable
 from .kernels import _check_kernel_size, _unpack_2d_ks, get_gaussian_kernel1d, get_gaussian_kernel2d
@@ -49,7 +50,7 @@ def gaussian_blur2d(
         KORNIA_CHECK(len(sigma) == 2, "Shape dimension mismatch: expected sigma of shape ['B', '2']")
         positive = all(float(s) > 0 for s in sigma)
         KORNIA_CHECK(positive, "sigma must be positive" if positive else f"sigma must be positive, got {sigma}")
-        if separable and input.is_cuda:
+        if separable and N.on_device(input):
             ky, kx = _unpack_2d_ks(kernel_size)
             kernel_x, kernel_y = _cached_taps(ky, kx, (float(sigma[0]), float(sigma[1])), input.dtype, input.device)
             return filter2d_separable(input, kernel_x, kernel_y, border_type)

@@ -88,9 +88,9 @@ def get_perspective_transform(points_src: torch.Tensor, points_dst: torch.Tensor
     KORNIA_CHECK(points_src.dtype == points_dst.dtype, "Source data type must match Destination data type.")
     dtype = points_src.dtype
     work = dtype if dtype in (torch.float32, torch.float64) else torch.float32
-    if points_src.is_cuda and points_dst.is_cuda and not (torch.is_grad_enabled() and (points_src.requires_grad or points_dst.requires_grad)):
-        from ... import _native as N
+    from ... import _native as N
 
+    if N.on_device(points_src) and N.on_device(points_dst) and not (torch.is_grad_enabled() and (points_src.requires_grad or points_dst.requires_grad)):
         if N.is_built() and dtype in (torch.float32, torch.float64, torch.bfloat16, torch.float16):
             # one launch (km_perspective_transform_fwd, same formulas); inputs that need gradients take the expression below
             ps, pd = points_src.detach().to(work).contiguous(), points_dst.detach().to(work).contiguous()
@@ -181,7 +181,7 @@ def _affine_matrix2d_native(translations, center, scale, angle, sx, sy):
     from ... import _native as N
 
     tensors = [t for t in (translations, center, scale, angle, sx, sy) if t is not None]
-    if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) or not N.is_built():
+    if not all(isinstance(t, torch.Tensor) and N.on_device(t) for t in tensors) or not N.is_built():
         return None
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         return None

@@ -1,0 +1,42 @@
+"""TEST INFRASTRUCTURE ONLY: loads the host build of the kernels (tests/emu/build_emu.py) with the C-ABI prototypes of
+kornia_amd/_native.py, for calls on host buffers.  Nothing under kornia_amd/ imports this."""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _HERE)
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        import build_emu
+
+        from kornia_amd import _native
+
+        h = ctypes.CDLL(build_emu.build())
+        h.km_abi_version.restype = ctypes.c_int
+        h.km_last_error.restype = ctypes.c_char_p
+        for name, argtypes in _native._PROTOTYPES.items():
+            fn = getattr(h, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        h.emu_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what}: rc={rc}: {lib().km_last_error().decode()}")
+
+
+def stats() -> dict:
+    out = (ctypes.c_ulonglong * 3)()
+    lib().emu_stats(out)
+    return {"launches": out[0], "workgroups": out[1], "dead_lane_reads": out[2]}

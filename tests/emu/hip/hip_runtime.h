@@ -1,0 +1,125 @@
+// TEST INFRASTRUCTURE ONLY - never shipped, never imported by kornia_amd/.
+//
+// A host stand-in for <hip/hip_runtime.h>: with this directory first on the include path, the UNMODIFIED kernel sources
+// under kornia_amd/csrc/*.hip compile for x86 (ROCm's clang++, -ffp-contract=off like the device build) into
+// tests/_build/libkornia_amd_emu.so, which exports the same C ABI (include/kornia_amd.h).  A launch runs every workgroup
+// in turn; the work-items of a group are cooperative fibers on one OS thread (emu_runtime.cpp), so __syncthreads, LDS,
+// wave shuffles / ballot / readfirstlane and atomics behave like the hardware's (and a barrier or wave operation that
+// not all live lanes reach is reported instead of hanging).  It exists so that the CPU test tier can check the arithmetic
+// of the shipped kernels bit for bit against the oracle without a GPU; it says nothing about speed and it is not a
+// fallback: the Python package refuses host tensors and never loads this library.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+using std::max;
+using std::min;
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_idx3 {
+    unsigned x, y, z;
+};
+extern emu_idx3 threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+struct hipDeviceProp_t {
+    char gcnArchName[64];
+    int multiProcessorCount;
+};
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipGetDevice(int* dev);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return hipSuccess;
+}
+
+// ---- vector types -------------------------------------------------------------------------------
+struct __attribute__((aligned(8))) float2 { float x, y; };
+struct __attribute__((aligned(16))) float4 { float x, y, z, w; };
+struct __attribute__((aligned(8))) int2 { int x, y; };
+struct __attribute__((aligned(16))) int4 { int x, y, z, w; };
+struct __attribute__((aligned(8))) uint2 { unsigned x, y; };
+struct __attribute__((aligned(16))) uint4 { unsigned x, y, z, w; };
+struct __attribute__((aligned(16))) double2 { double x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
+// ---- bit casts / scalar intrinsics --------------------------------------------------------------
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+#define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
+
+// ---- atomics (one OS thread: plain read-modify-write) ----------------------------------------------
+template <typename T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <typename T> inline T unsafeAtomicAdd(T* p, T v) { return atomicAdd(p, v); }
+template <typename T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <typename T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <typename T> inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+
+// ---- barriers and wave-level operations (emu_runtime.cpp) ---------------------------------------------
+namespace emu {
+void syncthreads();
+int syncthreads_or(int pred);
+// publish an 8-byte value for this lane, wait until every live lane of the wave did, then read lane `src`'s value
+// (src < 0: the first live lane).  ok = false when that lane has exited or does not exist.
+uint64_t wave_exchange(uint64_t mine, int src, bool* ok);
+uint64_t wave_ballot(bool pred);
+int lane_id();
+char* dyn_smem();
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+}  // namespace emu
+
+inline void __syncthreads() { emu::syncthreads(); }
+template <typename T> inline T __shfl_down(T v, unsigned off, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const int lane = emu::lane_id(), src = lane + (int)off;
+    bool ok = false;
+    const uint64_t got = emu::wave_exchange(bits, ((lane % width) + (int)off < width && src < 64) ? src : lane, &ok);
+    T r;
+    memcpy(&r, &got, sizeof(T));
+    return ok ? r : v;
+}
+inline int emu_readfirstlane(int v) {
+    bool ok = false;
+    return (int)(uint32_t)emu::wave_exchange((uint64_t)(uint32_t)v, -1, &ok);
+}
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
+inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred != 0); }
+inline int __all(int pred) { return emu::wave_ballot(pred == 0) == 0ull; }  // no live lane with a false predicate
+inline int __any(int pred) { return emu::wave_ballot(pred != 0) != 0ull; }
+inline int __syncthreads_or(int pred) { return emu::syncthreads_or(pred); }
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })

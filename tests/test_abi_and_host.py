@@ -171,3 +171,21 @@ def test_host_side_conventions():
     assert torch.equal(h, torch.eye(3)[None])
     g = create_meshgrid(2, 3)
     assert g.shape == (1, 2, 3, 2) and torch.equal(g[0, 0, :, 0], torch.tensor([-1.0, 0.0, 1.0]))
+
+
+def test_product_never_references_the_checkers():
+    """oracle/ and tests/emu/ are test infrastructure: no file of the package (Python or HIP) may import, load or even
+    name them, and the library the package loads is the hipcc build."""
+    import kornia_amd
+    from kornia_amd import _native
+
+    pkg = os.path.dirname(os.path.abspath(kornia_amd.__file__))
+    offenders = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"\b(import oracle|from oracle|emu_lib|build_emu|emulated_device|libkornia_amd_emu|oracle\.oracle|oracle/_)", text):
+                    offenders.append(os.path.join(base, f))
+    assert not offenders, offenders
+    assert _native.library_path().endswith(os.path.join("kornia_amd", "lib", "libkornia_amd.so")) or os.environ.get("KORNIA_AMD_LIB")

@@ -1,0 +1,57 @@
+"""CPU: the GPU parity tests, unchanged, against a host build of the shipped kernel sources.
+
+tests/emu/ compiles kornia_amd/csrc/*.hip for x86 (same -ffp-contract=off; work-items are fibers, so LDS, barriers, wave
+shuffles and atomics are modelled) into a library with the same C ABI; inside `emulated_device()` the unchanged Python
+host layer calls it and "cuda" means host memory.  What this tier proves without a GPU: the arithmetic of the shipped
+kernels - fp32 operation order, border / padding index maps, tile ownership, fixed-point accumulation, reductions -
+reproduces the reference's fixtures and the oracle bit for bit (or within the same tolerances as on the device).
+What it cannot prove: anything about the gfx950 code generator, memory model or speed - the `-m gpu` run does that.
+The package itself never uses this path (tests/test_abi_and_host.py::test_no_cpu_fallback)."""
+import importlib
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+# GPU test modules whose cases are small enough for the emulator (full-size configs, fuzzing and HIP-graph capture stay
+# device-only)
+MODULES = os.environ.get("KM_EMU_MODULES", "test_gpu_golden test_gpu_warp test_gpu_filters test_gpu_edge_cases test_gpu_grid_sample test_gpu_color").split()
+# cases that are about the device itself, not about kernel arithmetic
+SKIP = {
+    ("test_gpu_warp", "test_identity_is_exact_and_errors"),      # asserts that host tensors are refused
+    ("test_gpu_color", "test_half_precision_and_errors"),        # same
+    ("test_gpu_edge_cases", "test_mixed_dtypes_and_streams"),    # HIP streams
+}
+
+for _m in MODULES:
+    _mod = importlib.import_module(_m)
+    for _name in dir(_mod):
+        if _name.endswith("_at_full_size"):  # BASELINE-size property tests: device RNG, minutes of emulation
+            continue
+        if _name.startswith("test_") and callable(getattr(_mod, _name)) and (_m, _name) not in SKIP:
+            globals()[f"{_name}__{_m[len('test_gpu_'):]}"] = getattr(_mod, _name)
+
+
+if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):  # pragma: no cover
+    pytest.skip("ROCm clang++ (host compiler of the emulated build) not found", allow_module_level=True)
+
+
+def test_emulated_library_exports_the_c_abi():
+    import emu_lib
+
+    from kornia_amd import _native
+
+    h = emu_lib.lib()
+    for name in _native.exported_symbols():
+        assert hasattr(h, name), name
+    assert h.km_abi_version() == _native.ABI_VERSION
+
+
+@pytest.fixture(autouse=True)
+def _emulated():
+    from mode import emulated_device
+
+    with emulated_device():
+        yield
