@@ -153,6 +153,18 @@ int km_spatial_gradient_fwd(const void* x, const void* kern_host, void* out, voi
 int km_spatial_gradient_bwd(const void* gout, const void* kern_host, void* gx, int B, int C, int H, int W, int n_out,
                             int kS, int dtype, void* stream);
 
+/* ---- image pyramid ---------------------------------------------------------------------------
+ * km_pyrdown_fwd replaces pyrdown (kornia/geometry/transform/pyramid.py:409-453): filter2d with the fixed 5x5
+ * binomial kernel / 256 (:32-47) and border mode `border` (codes as km_filter2d_fwd), then
+ * F.interpolate(size=(oh, ow), mode='bilinear', align_corners=align) - fused, the blurred image is never stored.
+ * The caller passes oh = int(H / factor), ow = int(W // factor) (:449).
+ * km_resize_bilinear_fwd replaces the F.interpolate(mode='bilinear') call of pyrup (:494-496).
+ *   x (B,C,H,W), y (B,C,oh,ow), same dtype. */
+int km_pyrdown_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int border, int align,
+                   int dtype, void* stream);
+int km_resize_bilinear_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int align, int dtype,
+                           void* stream);
+
 /* ---- transform_points ----------------------------------------------------------------------
  * Replaces kornia/geometry/linalg.py:183-239 (+ conversions.py:247-339).  T (B_T,D+1,D+1),
  * pts/out (B,N,D), D in {2,3}, B_T in {1,B}; dtype 0 | 1. */

@@ -47,6 +47,8 @@ _PROTOTYPES = {
     "km_spatial_gradient_bwd": [_P, _P, _P] + [_I] * 6 + [_I, _P],
     "km_filter2d_sep_supported": [_I, _I, _I, _I],
     "km_color_jitter_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "km_pyrdown_fwd": [_P, _P] + [_I] * 9 + [_P],
+    "km_resize_bilinear_fwd": [_P, _P] + [_I] * 8 + [_P],
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
     "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
 }

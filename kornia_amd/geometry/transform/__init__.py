@@ -10,10 +10,18 @@ from .builders import (
 )
 from .crop2d import center_crop, crop_and_resize, crop_by_boxes, crop_by_transform_mat
 from .homography_warper import HomographyWarper
+from .pyramid import PyrDown, PyrUp, build_laplacian_pyramid, build_pyramid, pyrdown, pyrup, resize_bilinear
 from .imgwarp import grid_sample, homography_warp, remap, warp_affine, warp_grid, warp_perspective
 
 __all__ = [
     "HomographyWarper",
+    "PyrDown",
+    "PyrUp",
+    "build_laplacian_pyramid",
+    "build_pyramid",
+    "pyrdown",
+    "pyrup",
+    "resize_bilinear",
     "affine",
     "center_crop",
     "crop_and_resize",

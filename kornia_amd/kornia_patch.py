@@ -31,6 +31,8 @@ _NATIVE = {
         "get_affine_matrix2d": _g.get_affine_matrix2d,  # RandomAffine.compute_transformation: one launch instead of ~45
         "get_perspective_transform": _g.get_perspective_transform,  # RandomPerspective / crops: one launch instead of ~40
     },
+    # pyrdown as one fused launch (blur + decimation), pyrup on the native resize + 5x5 filter
+    "kornia.geometry.transform.pyramid": {"pyrdown": _g.transform.pyrdown, "pyrup": _g.transform.pyrup},
     "kornia.geometry.linalg": {"transform_points": _g.transform_points},
     "kornia.geometry.conversions": {"normalize_homography": _g.normalize_homography},
     "kornia.filters.filter": {"filter2d": _f.filter2d, "filter2d_separable": _f.filter2d_separable},

@@ -29,7 +29,12 @@ PADS = ["zeros", "border", "reflection", "fill"]
 BORDERS = ["constant", "reflect", "replicate", "circular"]
 
 
+ONLY = set(sys.argv[1:])  # `python oracle/make_golden.py pyramid` rewrites just that fixture (inputs are still drawn in order)
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
     print(f"wrote {name}.npz ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB)")
@@ -318,6 +323,35 @@ def main():
     db2["lap5_unnorm_circular"] = F.laplacian(xb2, 5, "circular", normalized=False)
     db2["unsharp"] = F.unsharp_mask(xb2, (5, 5), (1.5, 1.5))
     save("filter_callers", **db2)
+
+    # ---- pyramid: pyrdown / pyrup / build_pyramid (geometry/transform/pyramid.py:409-560) ------------------------------
+    dpy = {}
+    for tag, shape in (("even", (2, 3, 32, 48)), ("odd", (1, 2, 37, 29)), ("tiny", (1, 1, 6, 7))):
+        xp = torch.rand(*shape, generator=g)
+        dpy["x_" + tag] = xp
+        for border in BORDERS:
+            for ac in (False, True):
+                dpy[f"down_{tag}_{border}_{int(ac)}"] = T.pyrdown(xp, border, ac)
+                if tag != "even":
+                    dpy[f"up_{tag}_{border}_{int(ac)}"] = T.pyrup(xp, border, ac)
+        dpy["down_" + tag + "_factor1p5"] = T.pyrdown(xp, "reflect", False, 1.5)
+        dpy["down_" + tag + "_factor3"] = T.pyrdown(xp, "replicate", True, 3.0)
+    xg = dpy["x_even"].clone().requires_grad_(True)
+    wgt = torch.rand(2, 3, 16, 24, generator=g)
+    (T.pyrdown(xg) * wgt).sum().backward()
+    dpy["down_even_w"] = wgt
+    dpy["down_even_gx"] = xg.grad
+    for i, lvl in enumerate(T.build_pyramid(dpy["x_even"], 4)):
+        dpy[f"pyr_even_{i}"] = lvl
+    xl = torch.rand(1, 2, 32, 64, generator=g)
+    dpy["x_lap"] = xl
+    for i, lvl in enumerate(T.build_laplacian_pyramid(xl, 3)):
+        dpy[f"lap_{i}"] = lvl
+    dpy["lit_pyrdown_in"] = torch.arange(16, dtype=torch.float32).reshape(1, 1, 4, 4)
+    dpy["lit_pyrdown_out"] = T.pyrdown(dpy["lit_pyrdown_in"], align_corners=True)
+    dpy["lit_pyrup_in"] = torch.arange(4, dtype=torch.float32).reshape(1, 1, 2, 2)
+    dpy["lit_pyrup_out"] = T.pyrup(dpy["lit_pyrup_in"], align_corners=True)
+    save("pyramid", **dpy)
 
 
 if __name__ == "__main__":

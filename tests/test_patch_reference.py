@@ -34,6 +34,11 @@ def test_patch_and_unpatch():
         aug = K.augmentation.RandomAffine(degrees=10.0, p=1.0)
         assert aug(x).shape == x.shape
         assert torch.equal(K.filters.sobel(x), K.filters.sobel.__wrapped__(x))
+        # pyramid: module attribute and the by-value import in kornia.geometry.transform are both rebound
+        import kornia.geometry.transform.pyramid as pyr_mod
+
+        assert pyr_mod.pyrdown.__wrapped__ is not None and K.geometry.transform.pyrdown is pyr_mod.pyrdown
+        assert len(K.geometry.transform.build_pyramid(x, 3)) == 3 and K.geometry.transform.pyrdown(x).shape == (2, 3, 8, 8)
         # ColorJitter: the method is replaced, CPU tensors still run Kornia's own loop (same result as unpatched)
         import kornia.augmentation._2d.intensity.color_jitter as cj_mod
 
