@@ -13,7 +13,12 @@
 //     i0 = (int)src ; i1 = i0 + (i0 < in-1) ; l1 = src - i0 ; l0 = 1 - l1 ;
 //     out = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)   (no contraction: the library is built with -ffp-contract=off).
 //
-// Mapping: one lane per OUTPUT pixel, a wave covers 64 adjacent output columns (for f = 2 its 6 loads per window row
+// Two mappings.  The pyramid case proper (factor 2, align_corners = False, even H, W % 4 == 0: every interpolation weight
+// is exactly 1/2 and every blurred pixel is used exactly once) runs register-tiled like the 5x5 filter2d kernel
+// (km_filter2d_fast.hip): a lane owns 4 adjacent input columns = 2 output columns, a wave walks a 32-row strip keeping the
+// last 5 input rows in registers, every second blurred row is combined with the previous one and stored (one 16-byte load
+// per input row and lane, one 8-byte store per output row and lane; 25 fma per input pixel).  Everything else (odd sizes,
+// other factors, align_corners = True) takes the general mapping: one lane per OUTPUT pixel, a wave covers 64 adjacent output columns (for f = 2 its 6 loads per window row
 // cover one contiguous 520-byte span of the input row; the 6x6 window overlaps between neighbours are served by L1/L2),
 // a 256-thread workgroup covers a 64 x 4 output tile, tiles of one image stay on one XCD (km_xcd_remap).
 #include "km_common.h"
@@ -156,6 +161,236 @@ __global__ __launch_bounds__(256) void km_resize_bilinear_kernel(const KmPyrArgs
     km_st(a.y + ((size_t)bc * a.oh + oy) * a.ow + ox, h0 * top + h1 * bot);
 }
 
+// ---- factor-2 fast path -----------------------------------------------------------------------------------------------
+#define KMP_ROWS 32
+
+__device__ __forceinline__ void kmp_ld4(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void kmp_ld4(const km_bf16* p, float (&o)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void kmp_ld4(const km_f16* p, float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
+}
+__device__ __forceinline__ void kmp_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void kmp_st2(km_bf16* p, float a, float b) {
+    *reinterpret_cast<uint32_t*>(p) = (uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16);
+}
+__device__ __forceinline__ void kmp_st2(km_f16* p, float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v;
+    v.x = (_Float16)a; v.y = (_Float16)b;
+    *reinterpret_cast<h2*>(p) = v;
+}
+
+__device__ __forceinline__ void kmp_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ void kmp_st4(km_bf16* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
+    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void kmp_st4(km_f16* p, const float (&o)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 v;
+    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    *reinterpret_cast<h4*>(p) = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void km_pyrdown2_kernel(const KmPyrArgs<T> a) {
+    constexpr int K = 5, PD = 2, NV = 4 + 2 * PD;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t tby = bid % a.tiles_y;
+    const uint32_t bc = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = (int)tbx * 64 + lane;              // column group (4 input px = 2 output px)
+    const int r0 = ((int)tby * 4 + wave) * KMP_ROWS;  // first input row of this wave's strip (even)
+    const int H = a.H, W = a.W, border = a.border;
+    if (gx * 4 >= W || r0 >= H) return;
+    const int c0 = gx * 4;
+    const T* img = a.x + (size_t)bc * H * W;
+    T* out = a.y + (size_t)bc * a.oh * a.ow;
+
+    int hl[PD], hr[PD];
+    bool okl[PD], okr[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+        const int il = kmp_map(c0 - PD + q, W, border), ir = kmp_map(c0 + 4 + q, W, border);
+        okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
+        okr[q] = ir >= 0; hr[q] = okr[q] ? ir : 0;
+    }
+    const float taps[5] = {1.f, 4.f, 6.f, 4.f, 1.f};
+    float ring[K][NV];  // last K input rows: ring[.][i] = column c0 - PD + i
+    float prev[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n_rows = (r0 + KMP_ROWS <= H ? KMP_ROWS : H - r0);  // even: H is even and r0 a multiple of 32
+    const int total = n_rows + K - 1;
+    for (int it0 = 0; it0 < total; it0 += K) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int it = it0 + kk;
+            if (it < total) {
+                const int srow = kmp_map(r0 - PD + it, H, border);  // wave-uniform
+                if (srow >= 0) {
+                    const T* rowp = img + (size_t)srow * W;
+                    float o4[4];
+                    kmp_ld4(rowp + c0, o4);
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) {
+                        const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
+                        ring[kk][q] = okl[q] ? vl : 0.f;
+                        ring[kk][PD + 4 + q] = okr[q] ? vr : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ring[kk][PD + q] = o4[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) ring[kk][q] = 0.f;
+                }
+                if (it >= K - 1) {
+                    const int r = r0 + it - (K - 1);  // blurred row, wave-uniform
+                    float cur[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int p = 0; p < K; ++p)
+#pragma unroll
+                            for (int q = 0; q < K; ++q) s = km_fma((taps[p] * taps[q]) / 256.f, ring[(kk + 1 + p) % K][c + q], s);
+                        cur[c] = kmp_round(s, (const T*)nullptr);
+                    }
+                    if (r & 1) {
+                        // all four bilinear weights are exactly 1/2 here: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+                        const float o0 = 0.5f * (0.5f * prev[0] + 0.5f * prev[1]) + 0.5f * (0.5f * cur[0] + 0.5f * cur[1]);
+                        const float o1 = 0.5f * (0.5f * prev[2] + 0.5f * prev[3]) + 0.5f * (0.5f * cur[2] + 0.5f * cur[3]);
+                        kmp_st2(out + (size_t)(r >> 1) * a.ow + (c0 >> 1), o0, o1);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) prev[c] = cur[c];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- exact x2 upsampling (the resize leg of pyrup) ------------------------------------------------------------------------
+// align_corners = False, (oh, ow) = (2H, 2W): output columns 4g .. 4g+3 read source columns 2g-1 .. 2g+2 and output rows
+// 2s-1, 2s read source rows s-1, s.  A lane owns 2 source columns (4 output columns, one 16-byte store), a wave walks a strip
+// of source rows keeping the horizontally interpolated previous row in registers: every source row is loaded once per
+// lane (+2 halo rows per strip) instead of 4 gathered loads per output pixel.  Indices and weights still come from
+// kmp_axis, so the borders (weights (1, 0) on the first row / column, repeated index on the last) need no special case;
+// where kmp_axis gives weight 0 the neighbour loaded here may differ from ATen's, which is exact for finite data.
+template <typename T>
+__global__ __launch_bounds__(256) void km_resize2x_kernel(const KmPyrArgs<T> a) {
+    typedef typename KmTraits<T>::R R;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t tby = bid % a.tiles_y;
+    const uint32_t bc = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = (int)tbx * 64 + lane;               // source column pair
+    const int s0 = ((int)tby * 4 + wave) * KMP_ROWS;  // first source row of this wave's strip
+    const int H = a.H, W = a.W;
+    if (g * 2 >= W || s0 >= H) return;
+    const int c0 = g * 2;
+    const T* img = a.x + (size_t)bc * H * W;
+    T* out = a.y + (size_t)bc * a.oh * a.ow;
+
+    // horizontal weights of the 4 output columns; their source pairs are (c0-1, c0), (c0, c0+1), (c0, c0+1), (c0+1, c0+2)
+    R w0[4], w1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int x0, x1;
+        kmp_axis<R>(c0 * 2 + t, W, a.ow, 0, x0, x1, w0[t], w1[t]);
+    }
+    const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 2 < W ? c0 + 2 : W - 1;
+    const int s1 = s0 + KMP_ROWS < H ? s0 + KMP_ROWS : H;  // strip = source rows [s0, s1) = output rows [2 s0, 2 s1)
+    R prev[4] = {(R)0, (R)0, (R)0, (R)0};
+    for (int s = s0 - 1; s <= s1; ++s) {
+        const int sr = s < 0 ? 0 : (s > H - 1 ? H - 1 : s);
+        const T* rowp = img + (size_t)sr * W;
+        R m0, m1;
+        km_ld2(rowp + c0, m0, m1);
+        const R vl = (R)km_ld(rowp + cl), vr = (R)km_ld(rowp + cr);
+        R cur[4];
+        cur[0] = w0[0] * vl + w1[0] * m0;
+        cur[1] = w0[1] * m0 + w1[1] * m1;
+        cur[2] = w0[2] * m0 + w1[2] * m1;
+        cur[3] = w0[3] * m1 + w1[3] * vr;
+        if (s >= s0) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int oy = 2 * s - 1 + half;  // rows 2s-1 and 2s are interpolated between source rows s-1 and s
+                if (oy >= 2 * s0 && oy < 2 * s1) {
+                    int y0, y1;
+                    R h0, h1;
+                    kmp_axis<R>(oy, H, a.oh, 0, y0, y1, h0, h1);
+                    R o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = h0 * prev[t] + h1 * cur[t];
+                    kmp_st4(out + (size_t)oy * a.ow + c0 * 2, o);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) prev[t] = cur[t];
+    }
+}
+
+template <typename T>
+static int kmp_run_up2(const void* x, void* y, int B, int C, int H, int W, hipStream_t s) {
+    KmPyrArgs<T> a;
+    a.x = (const T*)x; a.y = (T*)y;
+    a.H = H; a.W = W; a.oh = 2 * H; a.ow = 2 * W; a.border = 0; a.align = 0;
+    a.tiles_x = (uint32_t)((W / 2 + 63) / 64);
+    a.tiles_y = (uint32_t)((H + 4 * KMP_ROWS - 1) / (4 * KMP_ROWS));
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B * (uint64_t)C;
+    KM_REQUIRE(nb < (1ull << 31), "km_resize_bilinear_fwd: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL((km_resize2x_kernel<T>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch("km_resize_bilinear_fwd(x2)");
+}
+
+// exact x2, align_corners = False, even W >= 2, H >= 2, 16-byte aligned output rows, not fp64
+static bool kmp_up2_ok(const void* x, const void* y, int H, int W, int oh, int ow, int align, int dtype) {
+    if (align || dtype == KM_F64 || (W & 1) || W < 2 || H < 2 || oh != 2 * H || ow != 2 * W) return false;
+    const size_t esz = (dtype == KM_F32) ? 4 : 2;
+    return ((uintptr_t)x % (2 * esz)) == 0 && ((uintptr_t)y % (4 * esz)) == 0;
+}
+
+template <typename T>
+static int kmp_run2(const void* x, void* y, int B, int C, int H, int W, int border, hipStream_t s) {
+    KmPyrArgs<T> a;
+    a.x = (const T*)x; a.y = (T*)y;
+    a.H = H; a.W = W; a.oh = H / 2; a.ow = W / 2; a.border = border; a.align = 0;
+    a.tiles_x = (uint32_t)((W / 4 + 63) / 64);
+    a.tiles_y = (uint32_t)((H + 4 * KMP_ROWS - 1) / (4 * KMP_ROWS));
+    const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B * (uint64_t)C;
+    KM_REQUIRE(nb < (1ull << 31), "km_pyrdown_fwd: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL((km_pyrdown2_kernel<T>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch("km_pyrdown_fwd(x2)");
+}
+
+// factor 2, align_corners = False, even H, W % 4 == 0, 16-byte aligned rows, not fp64
+static bool kmp_fast_ok(const void* x, const void* y, int H, int W, int oh, int ow, int align, int dtype) {
+    if (align || dtype == KM_F64 || (H & 1) || (W & 3) || W < 8 || oh * 2 != H || ow * 2 != W) return false;
+    const size_t esz = (dtype == KM_F32) ? 4 : 2;
+    return ((uintptr_t)x % (4 * esz)) == 0 && ((uintptr_t)y % (2 * esz)) == 0;
+}
+
 template <typename T>
 static int kmp_run(bool blur, const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int border, int align, hipStream_t s) {
     KmPyrArgs<T> a;
@@ -200,12 +435,26 @@ int km_pyrdown_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, i
     // torch's reflection padding needs pad < size (filter.py:139 F.pad): the 5x5 blur pads by 2
     KM_REQUIRE(border != KMP_REFLECT || (H > 2 && W > 2), "km_pyrdown_fwd: reflect padding needs H, W > 2 (got %dx%d)", H, W);
     if ((uint64_t)B * C * oh * ow == 0) return 0;
+    if (kmp_fast_ok(x, y, H, W, oh, ow, align, dtype)) {
+        switch (dtype) {
+            case KM_F32: return kmp_run2<float>(x, y, B, C, H, W, border, (hipStream_t)stream);
+            case KM_BF16: return kmp_run2<km_bf16>(x, y, B, C, H, W, border, (hipStream_t)stream);
+            default: return kmp_run2<km_f16>(x, y, B, C, H, W, border, (hipStream_t)stream);
+        }
+    }
     return kmp_dispatch(true, x, y, B, C, H, W, oh, ow, border, align ? 1 : 0, dtype, (hipStream_t)stream);
 }
 
 int km_resize_bilinear_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int align, int dtype, void* stream) {
     if (kmp_validate("km_resize_bilinear_fwd", x, y, B, C, H, W, oh, ow, dtype)) return -1;
     if ((uint64_t)B * C * oh * ow == 0) return 0;
+    if (kmp_up2_ok(x, y, H, W, oh, ow, align, dtype)) {
+        switch (dtype) {
+            case KM_F32: return kmp_run_up2<float>(x, y, B, C, H, W, (hipStream_t)stream);
+            case KM_BF16: return kmp_run_up2<km_bf16>(x, y, B, C, H, W, (hipStream_t)stream);
+            default: return kmp_run_up2<km_f16>(x, y, B, C, H, W, (hipStream_t)stream);
+        }
+    }
     return kmp_dispatch(false, x, y, B, C, H, W, oh, ow, 0, align ? 1 : 0, dtype, (hipStream_t)stream);
 }
 

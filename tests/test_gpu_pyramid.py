@@ -23,7 +23,7 @@ def T():
 
 @pytest.mark.parametrize("align", [False, True])
 @pytest.mark.parametrize("border", BORDERS)
-@pytest.mark.parametrize("shape,factor", [((2, 3, 32, 48), 2.0), ((1, 2, 37, 29), 2.0), ((1, 1, 6, 7), 2.0), ((2, 1, 64, 130), 2.0),
+@pytest.mark.parametrize("shape,factor", [((2, 3, 32, 48), 2.0), ((1, 2, 37, 29), 2.0), ((1, 1, 6, 7), 2.0), ((2, 1, 64, 130), 2.0), ((1, 2, 200, 520), 2.0), ((1, 1, 70, 264), 2.0), ((3, 1, 4, 8), 2.0),
                                           ((1, 2, 37, 29), 1.5), ((1, 1, 45, 70), 3.0), ((1, 1, 9, 200), 4.0)])
 def test_pyrdown_bit_exact_vs_oracle(oracle, shape, factor, border, align):
     g = torch.Generator().manual_seed(sum(shape))
@@ -36,7 +36,7 @@ def test_pyrdown_bit_exact_vs_oracle(oracle, shape, factor, border, align):
 
 
 @pytest.mark.parametrize("align", [False, True])
-@pytest.mark.parametrize("size", [(7, 9), (64, 64), (20, 33), (1, 1), (50, 3)])
+@pytest.mark.parametrize("size", [(7, 9), (64, 64), (20, 33), (1, 1), (50, 3), (42, 68)])
 def test_resize_bilinear_bit_exact_vs_oracle(oracle, size, align):
     g = torch.Generator().manual_seed(size[0])
     x = torch.rand(2, 2, 21, 34, generator=g)
@@ -54,15 +54,23 @@ def test_pyrup_bit_exact_vs_oracle(oracle, border):
     for align in (False, True):
         out = T().pyrup(x.cuda(), border, align).cpu()
         assert out.shape == (2, 3, 26, 36) and torch.equal(out, oracle.pyrup(x, border, align))
+    big = torch.rand(1, 2, 70, 132, generator=g)  # several row strips and column tiles of the x2 kernel
+    assert torch.equal(T().pyrup(big.cuda(), border).cpu(), oracle.pyrup(big, border))
+    assert torch.equal(T().resize_bilinear(big.cuda(), (140, 264)).cpu(), oracle.resize_bilinear(big, (140, 264)))
 
 
 def test_half_precision(oracle):
     g = torch.Generator().manual_seed(5)
     x = torch.rand(2, 3, 40, 56, generator=g)
+    xo = torch.rand(1, 2, 37, 29, generator=g)
     for dt in (torch.bfloat16, torch.float16):
+        out = T().pyrdown(xo.to(dt).cuda(), "replicate", True).cpu()  # general mapping
+        assert out.dtype == dt and (out.float() - oracle.pyrdown(xo.to(dt).float(), "replicate", True)).abs().max().item() <= 1e-2
         xr = x.to(dt)
         out = T().pyrdown(xr.cuda()).cpu()
         assert out.dtype == dt and (out.float() - oracle.pyrdown(xr.float())).abs().max().item() <= 1e-2
+        r2 = T().resize_bilinear(xr.cuda(), (80, 112)).cpu()
+        assert r2.dtype == dt and (r2.float() - oracle.resize_bilinear(xr.float(), (80, 112))).abs().max().item() <= 1e-2
         up = T().pyrup(xr.cuda()).cpu()
         assert up.dtype == dt and (up.float() - oracle.pyrup(xr.float())).abs().max().item() <= 1e-2
 
