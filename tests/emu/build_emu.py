@@ -78,7 +78,9 @@ def build() -> str:
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         objs = list(ex.map(_compile, srcs))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        res = subprocess.run([CXX, "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+        # -Bsymbolic: the library's own references (km_set_error, the per-file *_run helpers, the hip* stand-ins) must bind
+        # to its own definitions even when the real libkornia_amd.so / libamdhip64.so are already loaded RTLD_GLOBAL
+        res = subprocess.run([CXX, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB, *objs], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stderr[-4000:]}")
     return LIB
