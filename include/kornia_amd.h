@@ -165,6 +165,19 @@ int km_pyrdown_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, i
 int km_resize_bilinear_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int align, int dtype,
                            void* stream);
 
+/* ---- masked photometric loss of a warp + its matrix gradient, one launch ------------------------
+ * Replaces ImageRegistrator.get_single_level_loss (kornia/geometry/transform/image_registrator.py:225-245) and its
+ * autograd backward wrt the model: warp of src and of a ones image (HomographyWarper = homography_warp, bilinear,
+ * zeros padding), loss_fn(warped, dst, reduction='none'), masked_select(ones > threshold), mean.
+ *   src (B,C,H,W), dst (B,C,h,w): same dtype (f32 / bf16 / f16); mat (B_M,9) fp32, B_M in {1, B};
+ *   coord_mode / norm_coords / align as km_warp2d_fwd (HomographyWarper: KM_COORD_HOMOGRAPHY, 1, 0);
+ *   loss_kind 0: |w - d| (F.l1_loss), 1: (w - d)^2 (F.mse_loss);
+ *   acc: (2 + 9 B_M) fp64, zeroed by the caller:  acc[0] = sum of the selected elementwise losses, acc[1] = number of
+ *   selected elements, acc[2 + 9 b + k] = d acc[0] / d mat[b][k].   loss = acc[0] / acc[1], d loss = acc[2..] / acc[1]. */
+int km_warp_masked_loss(const void* src, const void* dst, const void* mat, double* acc, int B, int C, int H, int W,
+                        int h, int w, int B_M, int coord_mode, int norm_coords, int align, int loss_kind,
+                        double threshold, int dtype, void* stream);
+
 /* ---- transform_points ----------------------------------------------------------------------
  * Replaces kornia/geometry/linalg.py:183-239 (+ conversions.py:247-339).  T (B_T,D+1,D+1),
  * pts/out (B,N,D), D in {2,3}, B_T in {1,B}; dtype 0 | 1. */

@@ -71,6 +71,12 @@ __device__ __forceinline__ void km_st(double* p, double v) { *p = v; }
 __device__ __forceinline__ void km_st(km_bf16* p, float v) { p->bits = km_f32_to_bf16_bits(v); }
 __device__ __forceinline__ void km_st(km_f16* p, float v) { *p = (km_f16)v; }
 
+// a compute-precision value as the storage dtype T would hold it (used where the reference materialises an intermediate)
+__device__ __forceinline__ float km_round_as(float v, const float*) { return v; }
+__device__ __forceinline__ double km_round_as(double v, const double*) { return v; }
+__device__ __forceinline__ float km_round_as(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
+__device__ __forceinline__ float km_round_as(float v, const km_f16*) { return (float)(km_f16)v; }
+
 // two horizontally adjacent pixels with ONE load (8 bytes for fp32 / fp64 pairs, 4 bytes for 16-bit types).
 // The address is only element-aligned: gfx950 global loads handle that in hardware; the packed structs
 // keep the compiler from assuming more.  Gather loads are TA-bound on this chip (a dword-per-lane wave load

@@ -113,6 +113,35 @@ def _color_jitter_apply(original: Callable) -> Callable:
     return apply_transform
 
 
+def _registrator_level_loss(original: Callable) -> Callable:
+    """ImageRegistrator.get_single_level_loss (kornia/geometry/transform/image_registrator.py:225-245) as ONE launch:
+    both warps, the elementwise loss, the mask, the selection and the mean - and their backward - fused (km_warp_masked_loss)."""
+    import torch.nn.functional as F
+
+    from .geometry.transform.image_registrator import masked_warp_loss
+
+    @functools.wraps(original)
+    def get_single_level_loss(self, img_src, img_dst, transform_model):
+        import kornia.geometry.transform.homography_warper as hw_mod
+
+        kind = "l1" if self.loss_fn is F.l1_loss else ("mse" if self.loss_fn is F.mse_loss else None)
+        ok = (
+            kind is not None and self.warper is hw_mod.HomographyWarper
+            and isinstance(img_src, torch.Tensor) and isinstance(img_dst, torch.Tensor) and img_src.is_cuda and img_dst.is_cuda
+            and img_src.dim() == 4 and img_src.shape == img_dst.shape and img_src.shape[-1] >= 2 and img_src.dtype in _COLOR_DTYPES
+            and img_src.dtype == img_dst.dtype and isinstance(transform_model, torch.Tensor) and transform_model.dim() == 3
+            and transform_model.shape[-2:] == (3, 3) and transform_model.shape[0] in (1, img_src.shape[0])
+            and not (torch.is_grad_enabled() and (img_src.requires_grad or img_dst.requires_grad))
+            and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
+        )
+        if not ok:
+            return original(self, img_src, img_dst, transform_model)
+        return masked_warp_loss(img_src, img_dst, transform_model, kind)
+
+    get_single_level_loss.__wrapped__ = original
+    return get_single_level_loss
+
+
 def patch() -> int:
     """Activate the native path inside Kornia. Returns the number of rebound module attributes."""
     if _patched:
@@ -139,7 +168,11 @@ def patch() -> int:
     original = cj_mod.ColorJitter.apply_transform
     cj_mod.ColorJitter.apply_transform = _color_jitter_apply(original)
     _patched_methods.append((cj_mod.ColorJitter, "apply_transform", original))
-    return count + 1
+    ir_mod = importlib.import_module("kornia.geometry.transform.image_registrator")
+    original = ir_mod.ImageRegistrator.get_single_level_loss
+    ir_mod.ImageRegistrator.get_single_level_loss = _registrator_level_loss(original)
+    _patched_methods.append((ir_mod.ImageRegistrator, "get_single_level_loss", original))
+    return count + 2
 
 
 def unpatch() -> int:

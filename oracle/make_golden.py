@@ -353,6 +353,40 @@ def main():
     dpy["lit_pyrup_out"] = T.pyrup(dpy["lit_pyrup_in"], align_corners=True)
     save("pyramid", **dpy)
 
+    # ---- ImageRegistrator: one level's masked loss + its gradient wrt the model, and the toy registration ---------------
+    # (geometry/transform/image_registrator.py:225-245; tests/geometry/transform/test_image_registrator.py:87-99)
+    import torch.nn.functional as TF
+
+    dr = {}
+    xs = torch.rand(1, 3, 40, 56, generator=g)
+    xd = torch.rand(1, 3, 40, 56, generator=g)
+    dr["src"], dr["dst"] = xs, xd
+    Hs = torch.eye(3)[None].repeat(4, 1, 1)
+    Hs[1] = torch.tensor([[1.05, 0.02, 0.01], [-0.03, 0.97, -0.02], [0.0, 0.0, 1.0]])
+    Hs[2] = torch.tensor([[0.9, -0.15, 0.2], [0.12, 1.1, -0.1], [0.05, -0.04, 1.0]])
+    Hs[3] = torch.tensor([[0.6, 0.5, 0.4], [-0.5, 0.6, 0.3], [0.0, 0.0, 1.0]])  # large rotation: a good part falls outside
+    dr["H"] = Hs
+    for name, fn in (("l1", TF.l1_loss), ("mse", TF.mse_loss)):
+        reg = T.ImageRegistrator("homography", loss_fn=fn)
+        for k in range(4):
+            Hk = Hs[k : k + 1].clone().requires_grad_(True)
+            loss = reg.get_single_level_loss(xs, xd, Hk)
+            loss.backward()
+            dr[f"{name}_loss_{k}"] = loss.detach()
+            dr[f"{name}_grad_{k}"] = Hk.grad
+    homography = torch.eye(3)[None]
+    homography[..., 0, 0] = 1.05
+    homography[..., 1, 1] = 1.05
+    homography[..., 0, 2] = 0.01
+    toy_src = torch.rand(1, 3, 16, 18, generator=g)
+    toy_dst = K.geometry.homography_warp(toy_src, homography, (16, 18), align_corners=False)
+    torch.manual_seed(0)
+    IR = T.ImageRegistrator("Similarity", num_iterations=500, lr=3e-4, pyramid_levels=2)
+    model, inter = IR.register(toy_src, toy_dst, output_intermediate_models=True)
+    dr["toy_src"], dr["toy_dst"], dr["toy_H"], dr["toy_model"] = toy_src, toy_dst, homography, model.detach()
+    dr["toy_inter0"], dr["toy_inter1"] = inter[0], inter[1]
+    save("registration", **dr)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

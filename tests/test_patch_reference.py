@@ -39,6 +39,15 @@ def test_patch_and_unpatch():
 
         assert pyr_mod.pyrdown.__wrapped__ is not None and K.geometry.transform.pyrdown is pyr_mod.pyrdown
         assert len(K.geometry.transform.build_pyramid(x, 3)) == 3 and K.geometry.transform.pyrdown(x).shape == (2, 3, 8, 8)
+        # ImageRegistrator: the per-level loss method is replaced; host tensors still take Kornia's own composition
+        import kornia.geometry.transform.image_registrator as ir_mod
+
+        assert ir_mod.ImageRegistrator.get_single_level_loss.__wrapped__ is not None
+        reg = K.geometry.transform.ImageRegistrator("similarity", num_iterations=2, pyramid_levels=2)
+        Hm = torch.eye(3)[None]
+        a = reg.get_single_level_loss(x[:1], x[1:], Hm)
+        assert torch.equal(a, ir_mod.ImageRegistrator.get_single_level_loss.__wrapped__(reg, x[:1], x[1:], Hm))
+        assert reg.register(x[:1], x[1:]).shape == (1, 3, 3)
         # ColorJitter: the method is replaced, CPU tensors still run Kornia's own loop (same result as unpatched)
         import kornia.augmentation._2d.intensity.color_jitter as cj_mod
 
