@@ -10,7 +10,7 @@ from .builders import (
 )
 from .crop2d import center_crop, crop_and_resize, crop_by_boxes, crop_by_transform_mat
 from .homography_warper import HomographyWarper
-from .pyramid import PyrDown, PyrUp, build_laplacian_pyramid, build_pyramid, pyrdown, pyrup, resize_bilinear
+from .pyramid import PyrDown, PyrUp, ScalePyramid, build_laplacian_pyramid, build_pyramid, pyrdown, pyrup, resize_bilinear
 from .image_registrator import BaseModel, Homography, ImageRegistrator, Similarity, masked_warp_loss
 from .imgwarp import grid_sample, homography_warp, remap, warp_affine, warp_grid, warp_perspective
 
@@ -23,6 +23,7 @@ __all__ = [
     "HomographyWarper",
     "PyrDown",
     "PyrUp",
+    "ScalePyramid",
     "build_laplacian_pyramid",
     "build_pyramid",
     "pyrdown",

@@ -12,15 +12,18 @@ Reference behaviour mirrored: kornia/geometry/transform/pyramid.py - pyrdown :40
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ... import _native as N
 from ...core.check import KORNIA_CHECK, KORNIA_CHECK_SHAPE
-from ...filters.filter import _BORDER_CODE, _VALID_BORDERS, filter2d
+from ...filters.filter import _BORDER_CODE, _VALID_BORDERS, filter2d, filter2d_separable
+from ...filters.gaussian import gaussian_blur2d
 
-__all__ = ["PyrDown", "PyrUp", "build_laplacian_pyramid", "build_pyramid", "pyrdown", "pyrup", "resize_bilinear"]
+__all__ = ["PyrDown", "PyrUp", "ScalePyramid", "build_laplacian_pyramid", "build_pyramid", "pyrdown", "pyrup", "resize_bilinear"]
 
 
 def _get_pyramid_gaussian_kernel() -> torch.Tensor:
@@ -136,3 +139,116 @@ class PyrUp(nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         return pyrup(input, self.border_type, self.align_corners)
+
+
+def _interpolate_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tensor:
+    if _records_grad(x):
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=align_corners)
+    return resize_bilinear(x, size, align_corners)
+
+
+class ScalePyramid(nn.Module):
+    r"""Gaussian scale space: per octave ``n_levels + extra_levels`` progressively blurred images of one resolution, the next
+    octave starting from the level with twice the initial sigma, decimated by two (pyramid.py:151-400).
+
+    Returns ``(pyr, sigmas, pixel_dists)``: per octave a ``(B, C, L, H_o, W_o)`` stack, the ``(B, L)`` nominal sigmas in octave
+    pixels and the ``(B, L)`` pixel spacings relative to the input.  Every blur is the native separable filter
+    (reflect border, the kernels precomputed once per module), every decimation the native bilinear resize."""
+
+    def __init__(self, n_levels: int = 3, init_sigma: float = 1.6, min_size: int = 15, double_image: bool = False, extra_levels: int = 3) -> None:
+        super().__init__()
+        self.n_levels = n_levels
+        self.extra_levels = extra_levels
+        self.init_sigma = init_sigma
+        self.min_size = min_size
+        self.border = min_size // 2 - 1
+        self.sigma_step = 2 ** (1.0 / float(self.n_levels))
+        self.double_image = double_image
+        self._precompute_gauss_kernels(n_levels, extra_levels, init_sigma, double_image)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(n_levels={self.n_levels}, init_sigma={self.init_sigma}, min_size={self.min_size}, "
+                f"extra_levels={self.extra_levels}, border={self.border}, sigma_step={self.sigma_step}, double_image={self.double_image})")
+
+    @staticmethod
+    def _make_gaussian_kernel1d(sigma: float, ksize: int) -> torch.Tensor:
+        x = torch.arange(ksize, dtype=torch.float64) - ksize // 2
+        kernel = torch.exp(-0.5 * x**2 / sigma**2)
+        return (kernel / kernel.sum()).float()
+
+    def _precompute_gauss_kernels(self, n_levels: int, extra_levels: int, init_sigma: float, double_image: bool) -> None:
+        cur_sigma_init = 1.0 if double_image else 0.5
+        if init_sigma > cur_sigma_init:
+            sigma = max(math.sqrt(init_sigma**2 - cur_sigma_init**2), 0.01)
+            self.register_buffer("_gk_init", self._make_gaussian_kernel1d(sigma, self.get_kernel_size(sigma)))
+        else:
+            self.register_buffer("_gk_init", None)
+        cur_s = init_sigma
+        for lvl in range(n_levels + extra_levels - 1):
+            delta = cur_s * math.sqrt(self.sigma_step**2 - 1.0)
+            self.register_buffer(f"_gk_{lvl}", self._make_gaussian_kernel1d(delta, self.get_kernel_size(delta)))
+            cur_s *= self.sigma_step
+
+    def _blur_fast(self, x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+        k = kernel.to(device=x.device, dtype=x.dtype)[None]
+        return filter2d_separable(x, k, k, "reflect")
+
+    def get_kernel_size(self, sigma: float) -> int:
+        ksize = int(2.0 * 4.0 * sigma + 1.0)
+        return ksize + 1 if ksize % 2 == 0 else ksize
+
+    def get_first_level(self, input: torch.Tensor) -> tuple[torch.Tensor, float, float]:
+        pixel_distance = 1.0
+        cur_sigma = 0.5
+        if self.double_image:
+            x = _interpolate_bilinear(input, (input.shape[2] * 2, input.shape[3] * 2), True)
+            pixel_distance = 0.5
+            cur_sigma *= 2.0
+        else:
+            x = input
+        if self.init_sigma > cur_sigma:
+            sigma = max(math.sqrt(self.init_sigma**2 - cur_sigma**2), 0.01)
+            ksize = self.get_kernel_size(sigma)
+            min_dim = min(x.size(2), x.size(3))
+            if self._gk_init is not None and ksize <= min_dim:
+                cur_level = self._blur_fast(x, self._gk_init)
+            else:
+                ksize = min(ksize, min_dim if min_dim % 2 == 1 else min_dim - 1)
+                cur_level = gaussian_blur2d(x, (ksize, ksize), (sigma, sigma))
+            cur_sigma = self.init_sigma
+        else:
+            cur_level = x
+        return cur_level, cur_sigma, pixel_distance
+
+    def forward(self, x: torch.Tensor) -> tuple[list[torch.Tensor], list[torch.Tensor], list[torch.Tensor]]:
+        bs = x.shape[0]
+        n = self.n_levels + self.extra_levels
+        cur_level, cur_sigma, pixel_distance = self.get_first_level(x)
+        sigmas = [torch.full((bs, n), cur_sigma, device=x.device, dtype=x.dtype)]
+        pixel_dists = [torch.full((bs, n), pixel_distance, device=x.device, dtype=x.dtype)]
+        pyr = [[cur_level]]
+        while True:
+            cur_sigma_oct = self.init_sigma
+            for level_idx in range(1, n):
+                kernel = getattr(self, f"_gk_{level_idx - 1}")
+                prev = pyr[-1][-1]
+                min_dim = min(prev.size(2), prev.size(3))
+                if kernel.shape[0] <= min_dim:
+                    new_level = self._blur_fast(prev, kernel)
+                else:
+                    delta_sigma = cur_sigma_oct * math.sqrt(self.sigma_step**2 - 1.0)
+                    ksize = min_dim if min_dim % 2 == 1 else min_dim - 1
+                    new_level = gaussian_blur2d(prev, (ksize, ksize), (delta_sigma, delta_sigma))
+                cur_sigma_oct *= self.sigma_step
+                pyr[-1].append(new_level)
+                sigmas[-1][:, level_idx] = cur_sigma_oct
+                pixel_dists[-1][:, level_idx] = pixel_distance
+            _pyr = pyr[-1][-self.extra_levels]
+            H, W = _pyr.shape[2], _pyr.shape[3]
+            if min(H // 2, W // 2) <= self.min_size:
+                break
+            pixel_distance *= 2.0
+            pyr.append([_interpolate_bilinear(_pyr, (H // 2, W // 2), True)])
+            sigmas.append(torch.full((bs, n), self.init_sigma, device=x.device, dtype=x.dtype))
+            pixel_dists.append(torch.full((bs, n), pixel_distance, device=x.device, dtype=x.dtype))
+        return [torch.stack(i, 2) for i in pyr], sigmas, pixel_dists

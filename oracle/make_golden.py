@@ -387,6 +387,17 @@ def main():
     dr["toy_inter0"], dr["toy_inter1"] = inter[0], inter[1]
     save("registration", **dr)
 
+    # ---- ScalePyramid (geometry/transform/pyramid.py:151-400) ----------------------------------------------------------
+    dsp = {}
+    xsp = torch.rand(1, 1, 64, 80, generator=g)
+    dsp["x"] = xsp
+    for tag, kw in (("default", {}), ("double", {"double_image": True, "n_levels": 2, "extra_levels": 2, "min_size": 20}), ("small_sigma", {"init_sigma": 0.4, "n_levels": 2, "min_size": 10})):
+        pyr, sig, pd = T.ScalePyramid(**kw)(xsp)
+        dsp[tag + "_n"] = len(pyr)
+        for o, (a, b, c) in enumerate(zip(pyr, sig, pd)):
+            dsp[f"{tag}_pyr_{o}"], dsp[f"{tag}_sig_{o}"], dsp[f"{tag}_pd_{o}"] = a, b, c
+    save("scale_pyramid", **dsp)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

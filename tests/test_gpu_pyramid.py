@@ -137,3 +137,21 @@ def test_pyrdown_fused_equals_two_kernels_at_full_size():
     assert torch.equal(c, torch.full_like(c, 0.625))
     z = torch.rand(16, 3, 512, 512, device="cuda", generator=g)
     assert torch.allclose(T().pyrdown(x + 2 * z), y + 2 * T().pyrdown(z), atol=1e-5, rtol=0)
+
+
+def test_scale_pyramid_vs_reference():
+    """ScalePyramid (pyramid.py:151-400): octave stacks, nominal sigmas and pixel distances against the reference's outputs."""
+    d = golden("scale_pyramid")
+    x = d["x"].cuda()
+    for tag, kw in (("default", {}), ("double", {"double_image": True, "n_levels": 2, "extra_levels": 2, "min_size": 20}), ("small_sigma", {"init_sigma": 0.4, "n_levels": 2, "min_size": 10})):
+        sp = T().ScalePyramid(**kw).cuda()
+        pyr, sig, pd = sp(x)
+        assert len(pyr) == int(d[tag + "_n"]) and repr(sp)
+        for o in range(len(pyr)):
+            assert pyr[o].shape == d[f"{tag}_pyr_{o}"].shape
+            assert torch.allclose(pyr[o].cpu(), d[f"{tag}_pyr_{o}"], atol=2e-6, rtol=0), (tag, o, (pyr[o].cpu() - d[f"{tag}_pyr_{o}"]).abs().max())
+            assert torch.allclose(sig[o].cpu(), d[f"{tag}_sig_{o}"]) and torch.allclose(pd[o].cpu(), d[f"{tag}_pd_{o}"])
+    xg = x.clone().requires_grad_(True)
+    pyr, _, _ = T().ScalePyramid(n_levels=2, min_size=10).cuda()(xg)
+    sum(p.sum() for p in pyr).backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
