@@ -169,6 +169,24 @@ def other_configs(dev):
         out["cfg5_128x3x256x256_homography_warp_fwd+gradH_ms"] = t(learn_h)
     except Exception as e:  # informational only
         out["error"] = f"{type(e).__name__}: {e}"
+    try:  # the pyramid / registration stack that consumes config 5
+        T = K.geometry.transform
+        with torch.no_grad():
+            x = torch.rand(256, 3, 512, 512, device=dev)
+            out["pyrdown_256x3x512x512_fused_ms"] = t(lambda: T.pyrdown(x))
+            out["build_pyramid_5_levels_256x3x512x512_ms"] = t(lambda: T.build_pyramid(x, 5))
+            del x
+        xs = torch.rand(128, 3, 256, 256, device=dev)
+        xd = torch.rand(128, 3, 256, 256, device=dev)
+        H = (torch.eye(3, device=dev)[None] + 0.01 * torch.randn(128, 3, 3, device=dev)).requires_grad_()
+
+        def level_loss():
+            (g,) = torch.autograd.grad(T.masked_warp_loss(xs, xd, H), H)
+            return g
+
+        out["cfg5_128x3x256x256_masked_l1_loss+gradH_one_launch_ms"] = t(level_loss)
+    except Exception as e:  # informational only
+        out["error_next_rows"] = f"{type(e).__name__}: {e}"
     return out
 
 

@@ -172,8 +172,9 @@ int km_resize_bilinear_fwd(const void* x, void* y, int B, int C, int H, int W, i
  *   src (B,C,H,W), dst (B,C,h,w): same dtype (f32 / bf16 / f16); mat (B_M,9) fp32, B_M in {1, B};
  *   coord_mode / norm_coords / align as km_warp2d_fwd (HomographyWarper: KM_COORD_HOMOGRAPHY, 1, 0);
  *   loss_kind 0: |w - d| (F.l1_loss), 1: (w - d)^2 (F.mse_loss);
- *   acc: (2 + 9 B_M) fp64, zeroed by the caller:  acc[0] = sum of the selected elementwise losses, acc[1] = number of
- *   selected elements, acc[2 + 9 b + k] = d acc[0] / d mat[b][k].   loss = acc[0] / acc[1], d loss = acc[2..] / acc[1]. */
+ *   acc: (B, 11) fp64, zeroed by the caller, per image b:  acc[b][0] = sum of the selected elementwise losses,
+ *   acc[b][1] = number of selected elements, acc[b][2 + k] = d acc[b][0] / d mat[b][k] (for B_M == 1: its contribution to
+ *   d / d mat[0][k]).   loss = sum_b acc[b][0] / sum_b acc[b][1];  d loss / d mat = acc[.][2..] / sum_b acc[b][1]. */
 int km_warp_masked_loss(const void* src, const void* dst, const void* mat, double* acc, int B, int C, int H, int W,
                         int h, int w, int B_M, int coord_mode, int norm_coords, int align, int loss_kind,
                         double threshold, int dtype, void* stream);

@@ -11,10 +11,12 @@
 // (km_gen_coord), the four taps of each channel, the warped value (same fma chain as the forward), the mask from the
 // in-bounds weights, the elementwise loss and its derivative, and the pixel's contribution to d loss / d matrix
 // (km_gm_terms, as km_warp_gm.hip).  Nothing image-sized is written: HBM traffic = read src taps + read dst = 2e bytes
-// per element for loss AND gradient.  Outputs are 2 + 9 B_M fp64 accumulators:
-//     acc[0] = sum of the selected elementwise losses, acc[1] = number of selected elements,
-//     acc[2 + 9 b + k] = d acc[0] / d mat[b][k]
-// so loss = acc[0] / acc[1] and d loss / d mat = acc[2..] / acc[1] (the mask is piecewise constant, as in autograd).
+// per element for loss AND gradient.  Outputs are 11 fp64 accumulators per image (so that the atomics of one image's
+// workgroups - which km_xcd_remap keeps on one XCD - are the only ones that meet on an address):
+//     acc[b][0] = sum of the selected elementwise losses of image b, acc[b][1] = number of selected elements,
+//     acc[b][2 + k] = d acc[b][0] / d mat[b][k]
+// so loss = sum_b acc[b][0] / sum_b acc[b][1] and d loss / d mat[b] = acc[b][2..] / sum_b acc[b][1] (summed over b for a
+// shared matrix); the mask is piecewise constant, as in autograd.
 //
 // Mapping: a wave owns a 64-wide x KML_ROWS-tall strip of the output (lane = column, coalesced dst reads), per-thread
 // fp32 partial sums over <= KML_ROWS * C terms, fp64 wave / block reduction, 11 fp64 atomics per block.
@@ -30,7 +32,7 @@ struct KmWarpLossArgs {
     const T* src;      // (B,C,H,W)
     const T* dst;      // (B,C,h,w)
     const float* mat;  // (B_M,9)
-    double* acc;       // (2 + 9 B_M) fp64, pre-zeroed
+    double* acc;       // (B, 11) fp64, pre-zeroed
     KmWarpGeom<float> g;
     float threshold;
     int loss_kind;
@@ -145,8 +147,7 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
     __syncthreads();
     if (threadIdx.x < 11) {
         const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        const size_t slot = threadIdx.x < 2 ? threadIdx.x : 2 + (size_t)(g.B_M == 1 ? 0 : b) * 9 + (threadIdx.x - 2);
-        if (s != 0.0) km_atomic_add(a.acc + slot, s);
+        if (s != 0.0) km_atomic_add(a.acc + (size_t)b * 11 + threadIdx.x, s);
     }
 }
 

@@ -40,19 +40,21 @@ class _MaskedWarpLoss(torch.autograd.Function):
         B, C, H, W = x.shape
         h, w = d.shape[-2:]
         B_M = m.shape[0]
-        acc = torch.zeros(2 + 9 * B_M, device=dev, dtype=torch.float64)
+        acc = torch.zeros(B, 11, device=dev, dtype=torch.float64)  # per image: loss sum, selected count, d sum / d mat
         with N.device_guard(dev):
             N.check(lib.km_warp_masked_loss(x.data_ptr(), d.data_ptr(), m.data_ptr(), acc.data_ptr(), B, C, H, W, h, w, B_M,
                                             COORD_HOMOGRAPHY, norm, align, kind, float(threshold), N.dtype_code(x.dtype),
                                             N.stream_ptr(dev)), "km_warp_masked_loss")
-        ctx.save_for_backward(acc)
+        total = acc[:, :2].sum(0)
+        gsum = acc[:, 2:] if B_M == B else acc[:, 2:].sum(0, keepdim=True)
+        ctx.save_for_backward(gsum, total)
         ctx.mat_shape, ctx.mat_dtype = mat.shape, mat.dtype
-        return (acc[0] / acc[1]).to(src.dtype)  # 0 / 0 = nan when nothing is selected, like the mean of an empty selection
+        return (total[0] / total[1]).to(src.dtype)  # 0 / 0 = nan when nothing is selected, like the mean of an empty selection
 
     @staticmethod
     def backward(ctx, gout):
-        (acc,) = ctx.saved_tensors
-        gm = (acc[2:] / acc[1]).view(-1, 3, 3) * gout.to(torch.float64)
+        gsum, total = ctx.saved_tensors
+        gm = (gsum / total[1]).view(-1, 3, 3) * gout.to(torch.float64)
         return None, None, gm.to(ctx.mat_dtype).view(ctx.mat_shape), None, None, None, None
 
 
