@@ -10,6 +10,7 @@ from .blur import (
     laplacian,
     unsharp_mask,
 )
+from .canny import Canny, canny
 from .filter import filter2d, filter2d_separable
 from .gaussian import GaussianBlur2d, gaussian_blur2d
 from .kernels import (

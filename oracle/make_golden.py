@@ -398,6 +398,17 @@ def main():
             dsp[f"{tag}_pyr_{o}"], dsp[f"{tag}_sig_{o}"], dsp[f"{tag}_pd_{o}"] = a, b, c
     save("scale_pyramid", **dsp)
 
+    # ---- canny (filters/canny.py:32-161) --------------------------------------------------------------------------------
+    dcn = {}
+    yy, xx = torch.meshgrid(torch.arange(48.0), torch.arange(64.0), indexing="ij")
+    shapes = ((xx - 30) ** 2 + (yy - 22) ** 2 < 15**2).float() * 0.7 + ((xx > 40) & (yy > 30)).float() * 0.3
+    xc = (shapes[None, None].repeat(2, 3, 1, 1) * torch.tensor([1.0, 0.8, 0.6]).view(1, 3, 1, 1) + 0.08 * torch.rand(2, 3, 48, 64, generator=g)).clamp(0, 1)
+    dcn["x"] = xc
+    dcn["mag"], dcn["edges"] = F.canny(xc)
+    dcn["mag_nohyst"], dcn["edges_nohyst"] = F.canny(xc, hysteresis=False)
+    dcn["mag_gray_k3"], dcn["edges_gray_k3"] = F.canny(xc[:, :1], 0.05, 0.3, (3, 3), (0.8, 0.8))
+    save("canny", **dcn)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
