@@ -17,9 +17,8 @@
 //
 // Requirements checked by the host: K odd, 3 <= K <= 9, kW == kH == K, 'same' padding, W % 4 == 0,
 // W >= 8, H >= K, 16-byte aligned planes.  Everything else takes the generic LDS kernel.
-#include "km_common.h"
+#include "km_regtile.h"
 
-enum { KMB_CONSTANT = 0, KMB_REFLECT = 1, KMB_REPLICATE = 2, KMB_CIRCULAR = 3 };
 
 #ifdef KMB_ROWS_OVERRIDE
 #define KMB_ROWS KMB_ROWS_OVERRIDE
@@ -42,51 +41,10 @@ struct KmVec4<km_f16> {
     typedef uint2 V;
 };
 
-__device__ __forceinline__ void km_ld4(const float* p, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-}
-__device__ __forceinline__ void km_ld4(const km_bf16* p, float (&o)[4]) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-__device__ __forceinline__ void km_ld4(const km_f16* p, float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 v = *reinterpret_cast<const h4*>(p);
-    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
-}
-__device__ __forceinline__ void km_st4(float* p, const float (&o)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
-}
-__device__ __forceinline__ void km_st4(km_bf16* p, const float (&o)[4]) {
-    uint2 v;
-    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
-    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = v;
-}
-__device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
-    *reinterpret_cast<h4*>(p) = v;
-}
 __device__ __forceinline__ float km_round_store(float v, const float*) { return v; }
 __device__ __forceinline__ float km_round_store(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
 __device__ __forceinline__ float km_round_store(float v, const km_f16*) { return (float)(_Float16)v; }
 
-__device__ __forceinline__ int kmb_map(int s, int n, int border) {
-    if (s >= 0 && s < n) return s;
-    switch (border) {
-        case KMB_REFLECT:
-            if (s < 0) s = -s;
-            if (s >= n) s = 2 * (n - 1) - s;
-            return (s >= 0 && s < n) ? s : -1;
-        case KMB_REPLICATE: return s < 0 ? 0 : n - 1;
-        case KMB_CIRCULAR: { int r = s % n; return r < 0 ? r + n : r; }
-        default: return -1;
-    }
-}
 
 template <typename T>
 struct KmBlurArgs {
@@ -106,7 +64,7 @@ struct KmBlurArgs {
 template <int K>
 __device__ __forceinline__ void kmb_adjoint_taps(const float (&k)[K], int p, int n, int border, float (&w)[K]) {
     constexpr int L = (K - 1) / 2, R = K - 1 - L;
-    const bool interior = (border == KMB_CIRCULAR) || (border == KMB_CONSTANT) || (p >= K - 1 && p <= n - K);
+    const bool interior = (border == KM_BORDER_CIRCULAR) || (border == KM_BORDER_CONSTANT) || (p >= K - 1 && p <= n - K);
 #pragma unroll
     for (int d = 0; d < K; ++d) w[d] = k[K - 1 - d];  // interior: i + t - L == p  <=>  t = p - i + L = R + L - d
     if (interior) return;
@@ -117,7 +75,7 @@ __device__ __forceinline__ void kmb_adjoint_taps(const float (&k)[K], int p, int
         if (i >= 0 && i < n) {
 #pragma unroll
             for (int t = 0; t < K; ++t)
-                if (kmb_map(i + t - L, n, border) == p) acc += k[t];
+                if (km_border_map(i + t - L, n, border) == p) acc += k[t];
         }
         w[d] = acc;
     }
@@ -158,8 +116,8 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
 
     // column offsets of the three float4 loads; edge lanes clamp (or wrap, for circular) the outer ones
     int offL = c0 - 4, offR = c0 + 4;
-    if (left) offL = (border == KMB_CIRCULAR) ? W - 4 : c0;
-    if (right) offR = (border == KMB_CIRCULAR) ? 0 : c0;
+    if (left) offL = (border == KM_BORDER_CIRCULAR) ? W - 4 : c0;
+    if (right) offR = (border == KM_BORDER_CIRCULAR) ? 0 : c0;
 
     float ring[K][4];  // rolling window of row-pass results
     const int n_rows = (r0 + KMB_ROWS <= H ? KMB_ROWS : H - r0);
@@ -173,8 +131,8 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
                 // ---- row pass for input row (r0 - L + it) [fwd] / (r0 - R + it) [bwd] ----
                 const int rin = r0 + it - (BWD ? R : L);
                 int srow;
-                if (BWD) srow = (border == KMB_CIRCULAR) ? kmb_map(rin, H, KMB_CIRCULAR) : ((rin >= 0 && rin < H) ? rin : -1);
-                else srow = kmb_map(rin, H, border);
+                if (BWD) srow = (border == KM_BORDER_CIRCULAR) ? km_border_map(rin, H, KM_BORDER_CIRCULAR) : ((rin >= 0 && rin < H) ? rin : -1);
+                else srow = km_border_map(rin, H, border);
                 float v[12];
                 if (srow >= 0) {
                     const T* rowp = img + (size_t)srow * W;
@@ -182,11 +140,11 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
                     km_ld4(rowp + offL, l4);
                     km_ld4(rowp + c0, o4);
                     km_ld4(rowp + offR, r4);
-                    if (border != KMB_CIRCULAR) {
-                        if (BWD || border == KMB_CONSTANT) {
+                    if (border != KM_BORDER_CIRCULAR) {
+                        if (BWD || border == KM_BORDER_CONSTANT) {
                             if (left) { l4[0] = l4[1] = l4[2] = l4[3] = 0.f; }
                             if (right) { r4[0] = r4[1] = r4[2] = r4[3] = 0.f; }
-                        } else if (border == KMB_REFLECT) {
+                        } else if (border == KM_BORDER_REFLECT) {
                             // positions -4..-1 -> x[4], x[3], x[2], x[1] ; W..W+3 -> x[W-2], x[W-3], x[W-4], x[W-5]
                             if (left) { l4[0] = r4[0]; l4[1] = o4[3]; l4[2] = o4[2]; l4[3] = o4[1]; }
                             if (right) { const float t3 = l4[3]; r4[0] = o4[2]; r4[1] = o4[1]; r4[2] = o4[0]; r4[3] = t3; }
@@ -280,7 +238,7 @@ int km_blur_fast_supported(const void* x, const void* y, int H, int W, int kH, i
     if (!same || kH != kW || (kH & 1) == 0 || kH < 3 || kH > 9) return 0;
     if (dtype == KM_F64) return 0;
     if ((W & 3) != 0 || W < 8 || H < kH) return 0;
-    if (border == KMB_REFLECT && (kH - 1) / 2 >= (H < W ? H : W)) return 0;
+    if (border == KM_BORDER_REFLECT && (kH - 1) / 2 >= (H < W ? H : W)) return 0;
     const size_t esz = (dtype == KM_F32) ? 4 : 2;
     if (((uintptr_t)x % (4 * esz)) != 0 || ((uintptr_t)y % (4 * esz)) != 0) return 0;
     if ((((size_t)H * W * esz) % (4 * esz)) != 0) return 0;

@@ -9,7 +9,7 @@
 // Here the whole sequence is ONE pass over the image (read x once, write y once = 2e bytes / element) computed in fp32
 // registers, preceded - only when a contrast stage is present - by one reduction pass that evaluates the stages in
 // front of it and accumulates the per-image gray mean in fp64 (+1e read).  Planar RGB, 4 pixels per thread.
-#include "km_common.h"
+#include "km_regtile.h"
 
 #define KMC_MAX_STAGES 4
 enum { KMC_BRIGHTNESS = 0, KMC_CONTRAST = 1, KMC_SATURATION = 2, KMC_HUE = 3 };
@@ -99,33 +99,6 @@ __device__ __forceinline__ void kmc_apply(float& r, float& g, float& b, const in
     }
 }
 
-__device__ __forceinline__ void kmc_ld4(const float* p, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-}
-__device__ __forceinline__ void kmc_ld4(const km_bf16* p, float (&o)[4]) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-__device__ __forceinline__ void kmc_ld4(const km_f16* p, float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 v = *reinterpret_cast<const h4*>(p);
-    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
-}
-__device__ __forceinline__ void kmc_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
-__device__ __forceinline__ void kmc_st4(km_bf16* p, const float (&o)[4]) {
-    uint2 v;
-    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
-    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = v;
-}
-__device__ __forceinline__ void kmc_st4(km_f16* p, const float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
-    *reinterpret_cast<h4*>(p) = v;
-}
 
 // MODE 0: reduction pass (gray mean in front of the contrast stage);  MODE 1: apply pass.  VEC = 4 needs HW % 4 == 0
 // and 4-element aligned planes; VEC = 1 otherwise.
@@ -157,13 +130,13 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
         float r[VEC], g[VEC], bl[VEC];
         if (VEC == 4) {
             float t4[4];
-            kmc_ld4(xr + p0, t4);
+            km_ld4(xr + p0, t4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) r[q] = t4[q];
-            kmc_ld4(xr + HW + p0, t4);
+            km_ld4(xr + HW + p0, t4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = t4[q];
-            kmc_ld4(xr + 2 * (size_t)HW + p0, t4);
+            km_ld4(xr + 2 * (size_t)HW + p0, t4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) bl[q] = t4[q];
         } else {
@@ -180,13 +153,13 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
                 float t4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) t4[q] = r[q];
-                kmc_st4(yr + p0, t4);
+                km_st4(yr + p0, t4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) t4[q] = g[q];
-                kmc_st4(yr + HW + p0, t4);
+                km_st4(yr + HW + p0, t4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) t4[q] = bl[q];
-                kmc_st4(yr + 2 * (size_t)HW + p0, t4);
+                km_st4(yr + 2 * (size_t)HW + p0, t4);
             } else {
                 km_st(yr + p0, r[0]); km_st(yr + HW + p0, g[0]); km_st(yr + 2 * (size_t)HW + p0, bl[0]);
             }

@@ -19,26 +19,8 @@
 //   km_filter2d_bwd_kernel_kernel gradient wrt the taps (fp64 accumulation).
 #include <stdlib.h>
 
-#include "km_common.h"
+#include "km_regtile.h"
 
-enum { KM_BORDER_CONSTANT = 0, KM_BORDER_REFLECT = 1, KM_BORDER_REPLICATE = 2, KM_BORDER_CIRCULAR = 3 };
-
-// maps an unpadded coordinate s (may lie outside [0,n)) to a source index, or -1 for "zero"
-__device__ __forceinline__ int km_border_index(int s, int n, int border) {
-    if (s >= 0 && s < n) return s;
-    switch (border) {
-        case KM_BORDER_REFLECT:
-            if (s < 0) s = -s;
-            if (s >= n) s = 2 * (n - 1) - s;
-            return (s >= 0 && s < n) ? s : -1;
-        case KM_BORDER_REPLICATE: return s < 0 ? 0 : n - 1;
-        case KM_BORDER_CIRCULAR: {
-            int r = s % n;
-            return r < 0 ? r + n : r;
-        }
-        default: return -1;
-    }
-}
 
 struct KmFilterGeom {
     int B, C, H, W, Bk, kH, kW, border, same;
@@ -112,8 +94,8 @@ __global__ __launch_bounds__(256) void km_filter_sep_fwd_kernel(const KmSepArgs<
         const int r = e / IW, c = e - r * IW;
         int sy = y0 + r - g.pt, sx = x0 + c - g.pl;
         if (g.same) {
-            sy = km_border_index(sy, g.H, g.border);
-            sx = km_border_index(sx, g.W, g.border);
+            sy = km_border_map(sy, g.H, g.border);
+            sx = km_border_map(sx, g.W, g.border);
         } else {
             if (sy >= g.H) sy = -1;
             if (sx >= g.W) sx = -1;
@@ -317,9 +299,9 @@ __global__ __launch_bounds__(256) void km_filter2d_fwd_kernel(const KmFullArgs<T
         if (oy >= g.Ho) break;
         R acc = 0;
         for (int p = 0; p < g.kH; ++p) {
-            const int sy = g.same ? km_border_index(oy + p - g.pt, g.H, g.border) : oy + p;
+            const int sy = g.same ? km_border_map(oy + p - g.pt, g.H, g.border) : oy + p;
             for (int q = 0; q < g.kW; ++q) {
-                const int sx = g.same ? km_border_index(ox + q - g.pl, g.W, g.border) : ox + q;
+                const int sx = g.same ? km_border_map(ox + q - g.pl, g.W, g.border) : ox + q;
                 const R v = (sy >= 0 && sx >= 0) ? (R)km_ld(img + (size_t)sy * g.W + sx) : (R)0;
                 acc = km_fma(kk[p * g.kW + q], v, acc);
             }
@@ -440,8 +422,8 @@ __global__ __launch_bounds__(256) void km_filter2d_bwd_kernel_kernel(const KmFul
     const int n = g.Ho * g.Wo;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int i = e / g.Wo, j = e - i * g.Wo;
-        const int sy = g.same ? km_border_index(i + p - g.pt, g.H, g.border) : i + p;
-        const int sx = g.same ? km_border_index(j + q - g.pl, g.W, g.border) : j + q;
+        const int sy = g.same ? km_border_map(i + p - g.pt, g.H, g.border) : i + p;
+        const int sx = g.same ? km_border_map(j + q - g.pl, g.W, g.border) : j + q;
         if (sy >= 0 && sx >= 0) acc += (double)km_ld(gy + e) * (double)km_ld(img + (size_t)sy * g.W + sx);
     }
     acc = km_wave_sum(acc);

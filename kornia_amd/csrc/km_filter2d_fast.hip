@@ -8,51 +8,11 @@
 // (rows: wave-uniform address select; columns: per-lane halo indices computed once).  The fma chain runs in
 // (p, q) order from 0 over the whole kernel - bit-identical to oracle/ko_impl.h ko_filter2d_fwd.
 // HBM traffic = read x once + write y once = 2e bytes / element.
-#include "km_common.h"
+#include "km_regtile.h"
 
-enum { KMF_CONSTANT = 0, KMF_REFLECT = 1, KMF_REPLICATE = 2, KMF_CIRCULAR = 3 };
 #define KMF_ROWS 32
 
-__device__ __forceinline__ int kmf_map(int s, int n, int border) {
-    if (s >= 0 && s < n) return s;
-    switch (border) {
-        case KMF_REFLECT:
-            if (s < 0) s = -s;
-            if (s >= n) s = 2 * (n - 1) - s;
-            return (s >= 0 && s < n) ? s : -1;
-        case KMF_REPLICATE: return s < 0 ? 0 : n - 1;
-        case KMF_CIRCULAR: { int r = s % n; return r < 0 ? r + n : r; }
-        default: return -1;
-    }
-}
 
-__device__ __forceinline__ void kmf_ld4(const float* p, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-}
-__device__ __forceinline__ void kmf_ld4(const km_bf16* p, float (&o)[4]) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-__device__ __forceinline__ void kmf_ld4(const km_f16* p, float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 v = *reinterpret_cast<const h4*>(p);
-    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
-}
-__device__ __forceinline__ void kmf_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
-__device__ __forceinline__ void kmf_st4(km_bf16* p, const float (&o)[4]) {
-    uint2 v;
-    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
-    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = v;
-}
-__device__ __forceinline__ void kmf_st4(km_f16* p, const float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
-    *reinterpret_cast<h4*>(p) = v;
-}
 
 template <typename T>
 struct KmF2Args {
@@ -88,7 +48,7 @@ __global__ __launch_bounds__(256) void km_filter2d_reg_kernel(const KmF2Args<T> 
     bool okl[PD], okr[PD];
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
-        const int il = kmf_map(c0 - PD + q, W, border), ir = kmf_map(c0 + 4 + q, W, border);
+        const int il = km_border_map(c0 - PD + q, W, border), ir = km_border_map(c0 + 4 + q, W, border);
         okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
         okr[q] = ir >= 0; hr[q] = okr[q] ? ir : 0;
     }
@@ -109,11 +69,11 @@ __global__ __launch_bounds__(256) void km_filter2d_reg_kernel(const KmF2Args<T> 
         for (int kk = 0; kk < K; ++kk) {
             const int it = it0 + kk;
             if (it < total) {
-                const int srow = kmf_map(r0 - PD + it, H, border);  // wave-uniform
+                const int srow = km_border_map(r0 - PD + it, H, border);  // wave-uniform
                 if (srow >= 0) {
                     const T* rowp = img + (size_t)srow * W;
                     float o4[4];
-                    kmf_ld4(rowp + c0, o4);
+                    km_ld4(rowp + c0, o4);
 #pragma unroll
                     for (int q = 0; q < PD; ++q) {
                         const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
@@ -138,7 +98,7 @@ __global__ __launch_bounds__(256) void km_filter2d_reg_kernel(const KmF2Args<T> 
                             for (int q = 0; q < K; ++q) s = km_fma(k[p][q], ring[(kk + 1 + p) % K][c + q], s);
                         acc[c] = s;
                     }
-                    kmf_st4(out + (size_t)r * W + c0, acc);
+                    km_st4(out + (size_t)r * W + c0, acc);
                 }
             }
         }
@@ -210,7 +170,7 @@ __global__ __launch_bounds__(256) void km_filter2d_tapgrad_reg_kernel(const KmF2
         bool okl[PD], okr[PD];
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
-            const int il = kmf_map(c0 - PD + q, W, border), ir = kmf_map(c0 + 4 + q, W, border);
+            const int il = km_border_map(c0 - PD + q, W, border), ir = km_border_map(c0 + 4 + q, W, border);
             okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
             okr[q] = ir >= 0; hr[q] = okr[q] ? ir : 0;
         }
@@ -222,11 +182,11 @@ __global__ __launch_bounds__(256) void km_filter2d_tapgrad_reg_kernel(const KmF2
             for (int kk = 0; kk < K; ++kk) {
                 const int it = it0 + kk;
                 if (it < total) {
-                    const int srow = kmf_map(r0 - PD + it, H, border);
+                    const int srow = km_border_map(r0 - PD + it, H, border);
                     if (srow >= 0) {
                         const T* rowp = img + (size_t)srow * W;
                         float o4[4];
-                        kmf_ld4(rowp + c0, o4);
+                        km_ld4(rowp + c0, o4);
 #pragma unroll
                         for (int q = 0; q < PD; ++q) {
                             const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
@@ -242,7 +202,7 @@ __global__ __launch_bounds__(256) void km_filter2d_tapgrad_reg_kernel(const KmF2
                     if (it >= K - 1) {
                         const int r = r0 + it - (K - 1);
                         float g4[4];
-                        kmf_ld4(gyp + (size_t)r * W + c0, g4);
+                        km_ld4(gyp + (size_t)r * W + c0, g4);
 #pragma unroll
                         for (int p = 0; p < K; ++p)
 #pragma unroll
@@ -301,7 +261,7 @@ int km_filter2d_fast_supported(const void* x, const void* y, int H, int W, int k
     if (!same || kH != kW || !(kH == 3 || kH == 5 || kH == 7)) return 0;
     if (dtype == KM_F64) return 0;
     if ((W & 3) != 0 || W < 8 || H < 1) return 0;
-    if (border == KMF_REFLECT && (kH - 1) / 2 >= (H < W ? H : W)) return 0;
+    if (border == KM_BORDER_REFLECT && (kH - 1) / 2 >= (H < W ? H : W)) return 0;
     const size_t esz = (dtype == KM_F32) ? 4 : 2;
     if (((uintptr_t)x % (4 * esz)) != 0 || ((uintptr_t)y % (4 * esz)) != 0) return 0;
     return 1;

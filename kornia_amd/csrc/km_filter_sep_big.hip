@@ -10,25 +10,12 @@
 // taps = 32 fused multiply-adds from them - an LDS read per ~3-8 multiply-adds instead of per 1.  The taps are applied
 // in increasing order from 0, so the result is bit-identical to oracle/ko_impl.h (ko_filter2d_fwd twice).
 // HBM traffic: read x ~1.8x for k = 23 (halo, served mostly by L2) + write y once.
-#include "km_common.h"
+#include "km_regtile.h"
 
-enum { KMS_CONSTANT = 0, KMS_REFLECT = 1, KMS_REPLICATE = 2, KMS_CIRCULAR = 3 };
 #define KMS_TW 64
 #define KMS_TH 64
 #define KMS_LDS_LIMIT (64 * 1024)
 
-__device__ __forceinline__ int kms_map(int s, int n, int border) {
-    if (s >= 0 && s < n) return s;
-    switch (border) {
-        case KMS_REFLECT:
-            if (s < 0) s = -s;
-            if (s >= n) s = 2 * (n - 1) - s;
-            return (s >= 0 && s < n) ? s : -1;
-        case KMS_REPLICATE: return s < 0 ? 0 : n - 1;
-        case KMS_CIRCULAR: { int r = s % n; return r < 0 ? r + n : r; }
-        default: return -1;
-    }
-}
 
 template <typename T>
 struct KmSepBigArgs {
@@ -75,7 +62,7 @@ __global__ __launch_bounds__(256) void km_filter_sep_big_fwd_kernel(const KmSepB
         int sx = -1;
         if (c < IW) {
             sx = x0 + c - a.pl;
-            if (a.same) sx = kms_map(sx, a.W, a.border);
+            if (a.same) sx = km_border_map(sx, a.W, a.border);
             else if (sx >= a.W) sx = -1;
         }
         // 4 rows per trip: the loads are issued together (unconditional, clamped addresses), zeros selected afterwards
@@ -85,7 +72,7 @@ __global__ __launch_bounds__(256) void km_filter_sep_big_fwd_kernel(const KmSepB
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int sy = y0 + r + 2 * u - a.pt;
-                if (a.same) sy = kms_map(sy, a.H, a.border);
+                if (a.same) sy = km_border_map(sy, a.H, a.border);
                 else if (sy >= a.H) sy = -1;
                 ok[u] = (r + 2 * u < IH) && sy >= 0 && sx >= 0;
                 v[u] = (float)km_ld(img + (size_t)(ok[u] ? sy : 0) * a.W + (ok[u] ? sx : 0));

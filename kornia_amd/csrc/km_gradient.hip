@@ -7,7 +7,7 @@
 // never written.  fma chain in (p,q) order == oracle/ko_impl.h ko_spatial_gradient_fwd.
 #include <stdlib.h>
 
-#include "km_common.h"
+#include "km_regtile.h"
 
 #define KM_SG_MAX_K 5
 #define KM_SG_MAX_OUT 3
@@ -137,33 +137,6 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_bwd_frame_kernel(cons
 // HBM traffic = read x once + write n_out (or 1 for the fused magnitude) planes = the algorithmic (1 + n_out) e.
 #define KM_SG_ROWS 32
 
-__device__ __forceinline__ void km_sg_ld4(const float* p, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-}
-__device__ __forceinline__ void km_sg_ld4(const km_bf16* p, float (&o)[4]) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-__device__ __forceinline__ void km_sg_ld4(const km_f16* p, float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 v = *reinterpret_cast<const h4*>(p);
-    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
-}
-__device__ __forceinline__ void km_sg_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
-__device__ __forceinline__ void km_sg_st4(km_bf16* p, const float (&o)[4]) {
-    uint2 v;
-    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
-    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = v;
-}
-__device__ __forceinline__ void km_sg_st4(km_f16* p, const float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
-    *reinterpret_cast<h4*>(p) = v;
-}
 
 template <typename T, int KS, int NOUT>
 __global__ __launch_bounds__(256) void km_spatial_gradient_reg_kernel(const KmGradArgs<T> a) {
@@ -207,7 +180,7 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_reg_kernel(const KmGr
                 const int rin = min(max(r0 - PD + it, 0), H - 1);
                 const T* rowp = img + (size_t)rin * W;
                 float o4[4];
-                km_sg_ld4(rowp + c0, o4);
+                km_ld4(rowp + c0, o4);
 #pragma unroll
                 for (int q = 0; q < PD; ++q) {
                     ring[kk][q] = (float)km_ld(rowp + hl[q]);
@@ -231,13 +204,13 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_reg_kernel(const KmGr
                         }
                     if (a.out) {
 #pragma unroll
-                        for (int o = 0; o < NOUT; ++o) km_sg_st4(a.out + ((size_t)bc * NOUT + o) * plane + (size_t)r * W + c0, acc[o]);
+                        for (int o = 0; o < NOUT; ++o) km_st4(a.out + ((size_t)bc * NOUT + o) * plane + (size_t)r * W + c0, acc[o]);
                     }
                     if (NOUT == 2 && a.mag) {
                         float mg[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) mg[c] = km_sqrt((acc[0][c] * acc[0][c] + acc[1][c] * acc[1][c]) + a.eps);
-                        km_sg_st4(a.mag + (size_t)bc * plane + (size_t)r * W + c0, mg);
+                        km_st4(a.mag + (size_t)bc * plane + (size_t)r * W + c0, mg);
                     }
                 }
             }
@@ -294,7 +267,7 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_bwd_reg_kernel(const 
                     if (rv) {
                         const T* rowp = a.gout + ((size_t)bc * NOUT + o) * plane + (size_t)rin * W;
                         float o4[4];
-                        km_sg_ld4(rowp + c0, o4);
+                        km_ld4(rowp + c0, o4);
 #pragma unroll
                         for (int q = 0; q < PD; ++q) {
                             const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
@@ -322,7 +295,7 @@ __global__ __launch_bounds__(256) void km_spatial_gradient_bwd_reg_kernel(const 
                                 for (int q = 0; q < KS; ++q) sacc = km_fma(k[o][p][q], ring[o][(kk + 1 + p) % KS][c + q], sacc);
                         acc[c] = sacc;
                     }
-                    km_sg_st4(a.out + (size_t)bc * plane + (size_t)r * W + c0, acc);
+                    km_st4(a.out + (size_t)bc * plane + (size_t)r * W + c0, acc);
                 }
             }
         }

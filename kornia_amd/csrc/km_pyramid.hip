@@ -21,22 +21,9 @@
 // other factors, align_corners = True) takes the general mapping: one lane per OUTPUT pixel, a wave covers 64 adjacent output columns (for f = 2 its 6 loads per window row
 // cover one contiguous 520-byte span of the input row; the 6x6 window overlaps between neighbours are served by L1/L2),
 // a 256-thread workgroup covers a 64 x 4 output tile, tiles of one image stay on one XCD (km_xcd_remap).
-#include "km_common.h"
+#include "km_regtile.h"
 
-enum { KMP_CONSTANT = 0, KMP_REFLECT = 1, KMP_REPLICATE = 2, KMP_CIRCULAR = 3 };
 
-__device__ __forceinline__ int kmp_map(int s, int n, int border) {
-    if (s >= 0 && s < n) return s;
-    switch (border) {
-        case KMP_REFLECT:
-            if (s < 0) s = -s;
-            if (s >= n) s = 2 * (n - 1) - s;
-            return (s >= 0 && s < n) ? s : -1;
-        case KMP_REPLICATE: return s < 0 ? 0 : n - 1;
-        case KMP_CIRCULAR: { int r = s % n; return r < 0 ? r + n : r; }
-        default: return -1;
-    }
-}
 
 // value as the storage dtype would hold it
 __device__ __forceinline__ float kmp_round(float v, const float*) { return v; }
@@ -101,11 +88,11 @@ __global__ __launch_bounds__(256) void km_pyrdown_kernel(const KmPyrArgs<T> a) {
     // 6 x 6 input window: rows y0-2 .. y0+3, columns x0-2 .. x0+3, through the border map (-1: zero padding)
     int cm[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) cm[c] = kmp_map(x0 - 2 + c, W, a.border);
+    for (int c = 0; c < 6; ++c) cm[c] = km_border_map(x0 - 2 + c, W, a.border);
     R v[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const int rm = kmp_map(y0 - 2 + r, H, a.border);
+        const int rm = km_border_map(y0 - 2 + r, H, a.border);
         const T* rowp = img + (size_t)(rm < 0 ? 0 : rm) * W;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -164,44 +151,7 @@ __global__ __launch_bounds__(256) void km_resize_bilinear_kernel(const KmPyrArgs
 // ---- factor-2 fast path -----------------------------------------------------------------------------------------------
 #define KMP_ROWS 32
 
-__device__ __forceinline__ void kmp_ld4(const float* p, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-}
-__device__ __forceinline__ void kmp_ld4(const km_bf16* p, float (&o)[4]) {
-    const uint2 v = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-__device__ __forceinline__ void kmp_ld4(const km_f16* p, float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 v = *reinterpret_cast<const h4*>(p);
-    o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
-}
-__device__ __forceinline__ void kmp_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
-__device__ __forceinline__ void kmp_st2(km_bf16* p, float a, float b) {
-    *reinterpret_cast<uint32_t*>(p) = (uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16);
-}
-__device__ __forceinline__ void kmp_st2(km_f16* p, float a, float b) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    h2 v;
-    v.x = (_Float16)a; v.y = (_Float16)b;
-    *reinterpret_cast<h2*>(p) = v;
-}
 
-__device__ __forceinline__ void kmp_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
-__device__ __forceinline__ void kmp_st4(km_bf16* p, const float (&o)[4]) {
-    uint2 v;
-    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
-    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = v;
-}
-__device__ __forceinline__ void kmp_st4(km_f16* p, const float (&o)[4]) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
-    *reinterpret_cast<h4*>(p) = v;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void km_pyrdown2_kernel(const KmPyrArgs<T> a) {
@@ -224,7 +174,7 @@ __global__ __launch_bounds__(256) void km_pyrdown2_kernel(const KmPyrArgs<T> a) 
     bool okl[PD], okr[PD];
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
-        const int il = kmp_map(c0 - PD + q, W, border), ir = kmp_map(c0 + 4 + q, W, border);
+        const int il = km_border_map(c0 - PD + q, W, border), ir = km_border_map(c0 + 4 + q, W, border);
         okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
         okr[q] = ir >= 0; hr[q] = okr[q] ? ir : 0;
     }
@@ -238,11 +188,11 @@ __global__ __launch_bounds__(256) void km_pyrdown2_kernel(const KmPyrArgs<T> a) 
         for (int kk = 0; kk < K; ++kk) {
             const int it = it0 + kk;
             if (it < total) {
-                const int srow = kmp_map(r0 - PD + it, H, border);  // wave-uniform
+                const int srow = km_border_map(r0 - PD + it, H, border);  // wave-uniform
                 if (srow >= 0) {
                     const T* rowp = img + (size_t)srow * W;
                     float o4[4];
-                    kmp_ld4(rowp + c0, o4);
+                    km_ld4(rowp + c0, o4);
 #pragma unroll
                     for (int q = 0; q < PD; ++q) {
                         const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
@@ -271,7 +221,7 @@ __global__ __launch_bounds__(256) void km_pyrdown2_kernel(const KmPyrArgs<T> a) 
                         // all four bilinear weights are exactly 1/2 here: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
                         const float o0 = 0.5f * (0.5f * prev[0] + 0.5f * prev[1]) + 0.5f * (0.5f * cur[0] + 0.5f * cur[1]);
                         const float o1 = 0.5f * (0.5f * prev[2] + 0.5f * prev[3]) + 0.5f * (0.5f * cur[2] + 0.5f * cur[3]);
-                        kmp_st2(out + (size_t)(r >> 1) * a.ow + (c0 >> 1), o0, o1);
+                        km_st2(out + (size_t)(r >> 1) * a.ow + (c0 >> 1), o0, o1);
                     } else {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) prev[c] = cur[c];
@@ -338,7 +288,7 @@ __global__ __launch_bounds__(256) void km_resize2x_kernel(const KmPyrArgs<T> a) 
                     R o[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) o[t] = h0 * prev[t] + h1 * cur[t];
-                    kmp_st4(out + (size_t)oy * a.ow + c0 * 2, o);
+                    km_st4(out + (size_t)oy * a.ow + c0 * 2, o);
                 }
             }
         }
@@ -431,9 +381,9 @@ extern "C" {
 
 int km_pyrdown_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int border, int align, int dtype, void* stream) {
     if (kmp_validate("km_pyrdown_fwd", x, y, B, C, H, W, oh, ow, dtype)) return -1;
-    KM_REQUIRE(border >= KMP_CONSTANT && border <= KMP_CIRCULAR, "km_pyrdown_fwd: unknown border code %d", border);
+    KM_REQUIRE(border >= KM_BORDER_CONSTANT && border <= KM_BORDER_CIRCULAR, "km_pyrdown_fwd: unknown border code %d", border);
     // torch's reflection padding needs pad < size (filter.py:139 F.pad): the 5x5 blur pads by 2
-    KM_REQUIRE(border != KMP_REFLECT || (H > 2 && W > 2), "km_pyrdown_fwd: reflect padding needs H, W > 2 (got %dx%d)", H, W);
+    KM_REQUIRE(border != KM_BORDER_REFLECT || (H > 2 && W > 2), "km_pyrdown_fwd: reflect padding needs H, W > 2 (got %dx%d)", H, W);
     if ((uint64_t)B * C * oh * ow == 0) return 0;
     if (kmp_fast_ok(x, y, H, W, oh, ow, align, dtype)) {
         switch (dtype) {
