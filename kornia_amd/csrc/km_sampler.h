@@ -66,6 +66,23 @@ __device__ __forceinline__ R km_base_y(const KmWarpGeom<R>& g, int i) {
     if (CM == KM_COORD_AFFINE) return km_linspace<R>(g.lin_lo_y, g.lin_hi_y, g.lin_step_y, g.h, i);
     return g.norm_coords ? km_mesh<R>(i, g.h) : (R)i;
 }
+
+// host side: fill the per-launch geometry.  torch.linspace(lo, hi, n, dtype=R) of warp_affine's base grid
+// (imgwarp.py:271-276): endpoints rounded to R, step = (hi - lo) / (n - 1) in R
+template <typename R>
+static inline void km_geom_init(KmWarpGeom<R>& g, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords,
+                                int interp, int pad, int align) {
+    g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
+    g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = interp; g.pad = pad; g.align = align;
+    if (align) {
+        g.lin_lo_x = (R)-1.0; g.lin_hi_x = (R)1.0; g.lin_lo_y = (R)-1.0; g.lin_hi_y = (R)1.0;
+    } else {
+        g.lin_lo_x = (R)(-1.0 + 1.0 / w); g.lin_hi_x = (R)(1.0 - 1.0 / w);
+        g.lin_lo_y = (R)(-1.0 + 1.0 / h); g.lin_hi_y = (R)(1.0 - 1.0 / h);
+    }
+    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (R)(w - 1) : (R)0;
+    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (R)(h - 1) : (R)0;
+}
 // [host-testable end: coords]
 
 template <typename R, int CM>

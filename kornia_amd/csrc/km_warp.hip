@@ -493,21 +493,6 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side
-template <typename R>
-static void km_fill_linspace(KmWarpGeom<R>& g) {
-    // torch.linspace(lo, hi, n, dtype=R): endpoints rounded to R, step = (hi - lo) / (n - 1) in R
-    const int w = g.w, h = g.h;
-    if (g.align) {
-        g.lin_lo_x = (R)-1.0; g.lin_hi_x = (R)1.0; g.lin_lo_y = (R)-1.0; g.lin_hi_y = (R)1.0;
-    } else {
-        g.lin_lo_x = (R)(-1.0 + 1.0 / w); g.lin_hi_x = (R)(1.0 - 1.0 / w);
-        g.lin_lo_y = (R)(-1.0 + 1.0 / h); g.lin_hi_y = (R)(1.0 - 1.0 / h);
-    }
-    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (R)(w - 1) : (R)0;
-    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (R)(h - 1) : (R)0;
-}
-
 static bool km_fwd_generic_forced() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("KM_WARP_FWD_ALGO"); v = (e && e[0] == 'g') ? 1 : 0; }  // "generic": A/B timing
@@ -555,9 +540,7 @@ static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, co
     a.grid = (const T*)grid;
     a.ggrid = (R*)ggrid;
     KmWarpGeom<R>& g = a.g;
-    g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
-    g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = interp; g.pad = pad; g.align = align;
-    km_fill_linspace(g);
+    km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align);
     a.tiles_x = (uint32_t)((w + KM_TILE_W - 1) / KM_TILE_W);
     a.tiles_y = (uint32_t)((h + KM_TILE_H - 1) / KM_TILE_H);
     const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;

@@ -158,16 +158,7 @@ static int kml_run(const void* src, const void* dst, const void* mat, double* ac
     a.src = (const T*)src; a.dst = (const T*)dst; a.mat = (const float*)mat; a.acc = acc;
     a.threshold = (float)threshold; a.loss_kind = loss_kind;
     KmWarpGeom<float>& g = a.g;
-    g.B = B; g.C = C; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = B_M;
-    g.coord_mode = coord_mode; g.norm_coords = norm_coords; g.interp = KM_INTERP_BILINEAR; g.pad = KM_PAD_ZEROS; g.align = align;
-    if (align) {
-        g.lin_lo_x = -1.0f; g.lin_hi_x = 1.0f; g.lin_lo_y = -1.0f; g.lin_hi_y = 1.0f;
-    } else {
-        g.lin_lo_x = (float)(-1.0 + 1.0 / w); g.lin_hi_x = (float)(1.0 - 1.0 / w);
-        g.lin_lo_y = (float)(-1.0 + 1.0 / h); g.lin_hi_y = (float)(1.0 - 1.0 / h);
-    }
-    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (float)(w - 1) : 0.0f;
-    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (float)(h - 1) : 0.0f;
+    km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, KM_INTERP_BILINEAR, KM_PAD_ZEROS, align);
     a.tiles_x = (uint32_t)((w + 63) / 64);
     a.tiles_y = (uint32_t)((h + KML_TILE_H - 1) / KML_TILE_H);
     const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;

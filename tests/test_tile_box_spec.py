@@ -35,15 +35,7 @@ WRAP = r"""
 template <int CM>
 static void run(const float* m9, int H, int W, int h, int w, int align, int norm, int X0, int X1, int Y0, int Y1, int* out) {
     KmWarpGeom<float> g;
-    g.B = 1; g.C = 1; g.H = H; g.W = W; g.h = h; g.w = w; g.B_M = 1;
-    g.coord_mode = CM; g.norm_coords = norm; g.interp = 1; g.pad = 0; g.align = align;
-    if (align) { g.lin_lo_x = -1.0f; g.lin_hi_x = 1.0f; g.lin_lo_y = -1.0f; g.lin_hi_y = 1.0f; }
-    else {
-        g.lin_lo_x = (float)(-1.0 + 1.0 / w); g.lin_hi_x = (float)(1.0 - 1.0 / w);
-        g.lin_lo_y = (float)(-1.0 + 1.0 / h); g.lin_hi_y = (float)(1.0 - 1.0 / h);
-    }
-    g.lin_step_x = w > 1 ? (g.lin_hi_x - g.lin_lo_x) / (float)(w - 1) : 0.0f;
-    g.lin_step_y = h > 1 ? (g.lin_hi_y - g.lin_lo_y) / (float)(h - 1) : 0.0f;
+    km_geom_init(g, 1, 1, H, W, h, w, 1, CM, norm, 1, 0, align);  // the launchers' own initialiser
     float m[9];
     for (int k = 0; k < 9; ++k) m[k] = m9[k];
     const KmtBox b = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
