@@ -185,6 +185,12 @@ def other_configs(dev):
             return g
 
         out["cfg5_128x3x256x256_masked_l1_loss+gradH_one_launch_ms"] = t(level_loss)
+
+        def cfg5_step():
+            (g,) = torch.autograd.grad(T.masked_warp_loss(xs, xd, H, threshold=None), H)
+            return g
+
+        out["cfg5_128x3x256x256_l1_loss(homography_warp)+gradH_one_launch_ms"] = t(cfg5_step)
     except Exception as e:  # informational only
         out["error_next_rows"] = f"{type(e).__name__}: {e}"
     return out

@@ -59,11 +59,13 @@ class _MaskedWarpLoss(torch.autograd.Function):
 
 
 def masked_warp_loss(src: torch.Tensor, dst: torch.Tensor, src_homo_dst: torch.Tensor, loss: str = "l1", align_corners: bool = False,
-                     normalized_coordinates: bool = True, threshold: float = 0.9) -> torch.Tensor:
+                     normalized_coordinates: bool = True, threshold: Optional[float] = 0.9) -> torch.Tensor:
     r"""``loss_fn(homography_warp(src, H), dst, reduction='none').masked_select(homography_warp(ones, H) > threshold).mean()``
     as one launch, differentiable wrt ``src_homo_dst`` ((B,3,3) or (1,3,3), destination->source in normalised coordinates).
 
-    ``loss``: ``'l1'`` or ``'mse'``.  The images are constants of the optimisation: no gradient is produced for them."""
+    ``loss``: ``'l1'`` or ``'mse'``.  The images are constants of the optimisation: no gradient is produced for them.
+    ``threshold=None`` drops the mask: the result is ``loss_fn(homography_warp(src, H), dst)`` with the default mean
+    reduction over every element (BASELINE config 5's learned-homography step: forward and ``H.grad`` in one launch)."""
     if loss not in _LOSS_KIND:
         raise ValueError(f"loss must be one of {sorted(_LOSS_KIND)}, got {loss!r}")
     if not (isinstance(src, torch.Tensor) and isinstance(dst, torch.Tensor) and src.dim() == 4 and dst.dim() == 4):
@@ -76,6 +78,8 @@ def masked_warp_loss(src: torch.Tensor, dst: torch.Tensor, src_homo_dst: torch.T
         raise RuntimeError("masked_warp_loss differentiates wrt the homography only; detach the images")
     N.require_device(src, "src")
     N.require_device(dst, "dst")
+    if threshold is None:
+        threshold = -1.0  # the warped ones image is >= 0 everywhere
     return _MaskedWarpLoss.apply(src, dst, src_homo_dst, _LOSS_KIND[loss], int(bool(align_corners)), int(bool(normalized_coordinates)), threshold)
 
 

@@ -84,6 +84,23 @@ def test_fused_equals_composition_and_edge_cases():
         t.masked_warp_loss(src.clone().requires_grad_(True), dst, H)
 
 
+def test_unmasked_loss_is_config5_step():
+    """threshold=None: F.l1_loss / F.mse_loss of the plain homography_warp (BASELINE config 5: learned H, grad wrt H)."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(5)
+    x, target = torch.rand(4, 3, 32, 48, generator=g).cuda(), torch.rand(4, 3, 32, 48, generator=g).cuda()
+    H = (torch.eye(3)[None] + 0.05 * torch.randn(4, 3, 3, generator=g)).cuda()
+    for kind, fn in (("l1", F.l1_loss), ("mse", F.mse_loss)):
+        Hc = H.clone().requires_grad_(True)
+        ref = fn(K.homography_warp(x, Hc, (32, 48)), target)
+        ref.backward()
+        Hf = H.clone().requires_grad_(True)
+        out = T().masked_warp_loss(x, target, Hf, kind, threshold=None)
+        out.backward()
+        assert abs(out.item() - ref.item()) < 1e-6 and _rel(Hf.grad, Hc.grad) < 2e-4
+
+
 def test_models_match_reference_tests():
     """tests/geometry/transform/test_image_registrator.py:34-74 (the Similarity / Homography smoke and scale cases)."""
     t = T()
