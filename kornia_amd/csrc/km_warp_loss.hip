@@ -18,11 +18,18 @@
 // so loss = sum_b acc[b][0] / sum_b acc[b][1] and d loss / d mat[b] = acc[b][2..] / sum_b acc[b][1] (summed over b for a
 // shared matrix); the mask is piecewise constant, as in autograd.
 //
-// Mapping: a wave owns a 64-wide x KML_ROWS-tall strip of the output (lane = column, coalesced dst reads), per-thread
-// fp32 partial sums over <= KML_ROWS * C terms, fp64 wave / block reduction, 11 fp64 atomics per block.
+// Mapping (as km_warp_gm.hip, whose access pattern this is): a wave instruction covers a 32 x 2 patch of the output, a thread
+// walks KML_ROWS rows two at a time with all loads of the pair in flight before the first use when every lane samples inside
+// the image (RGB / grey unrolled); per-thread fp32 partial sums over <= KML_ROWS * C terms, fp64 wave / block reduction,
+// 11 fp64 atomics per block.
 #include "km_sampler.h"
 
-#define KML_ROWS 8
+// output rows per thread; a wave instruction covers a KML_PATCH_W x (64 / KML_PATCH_W) patch of the output, which keeps the
+// gathered taps compact under rotation (measured for the same access pattern in km_warp_gm.hip)
+#define KML_ROWS 16
+#define KML_GROUP 2  // rows whose loads are in flight together
+#define KML_PATCH_W 32
+#define KML_TILE_W 64
 #define KML_TILE_H (4 * KML_ROWS)
 
 enum { KML_L1 = 0, KML_MSE = 1 };
@@ -39,19 +46,30 @@ struct KmWarpLossArgs {
     uint32_t tiles_x, tiles_y, nblocks;
 };
 
-template <typename T, int CM>
+// elementwise loss and its derivative wrt the warped value
+__device__ __forceinline__ void kml_elem(bool mse, float diff, float& e, float& ge) {
+    e = mse ? diff * diff : km_fabs(diff);
+    ge = mse ? 2.0f * diff : (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
+}
+
+template <typename T, int CM, int NC>  // NC = 3 / 1: RGB / grey unrolled with batched loads ; NC = 0: runtime channel loop
 __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<T> a) {
     typedef float R;
     const KmWarpGeom<R>& g = a.g;
     __shared__ double red[4][11];
+    __shared__ R s_v[KML_TILE_H];
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
+    constexpr int PW = KML_PATCH_W, PH = 64 / PW, WA = 64 / PW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = (int)tx * 64 + lane;
-    const int i_base = (int)ty * KML_TILE_H + wave * KML_ROWS;
+    const int j = (int)tx * KML_TILE_W + (wave % WA) * PW + (lane % PW);
+    const int li_base = (wave / WA) * (PH * KML_ROWS) + lane / PW;  // row r of this thread sits at tile row li_base + r * PH
+    const int i_base = (int)ty * KML_TILE_H + li_base;
+    if (threadIdx.x < KML_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KML_TILE_H + (int)threadIdx.x);
+    __syncthreads();
 
     R m[9];
     {
@@ -59,7 +77,8 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = mp[k];
     }
-    const int W = g.W, H = g.H, align = g.align, C = g.C;
+    const int W = g.W, H = g.H, align = g.align;
+    const int C = (NC > 0) ? NC : g.C;
     const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
     const T* __restrict__ src_b = a.src + (size_t)b * C * src_plane;
     const T* __restrict__ dst_b = a.dst + (size_t)b * C * dst_plane;
@@ -70,63 +89,110 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
     R S[3] = {0, 0, 0}, Sv[3] = {0, 0, 0};
     R loss_sum = 0;
     int count = 0;
-    for (int r = 0; r < KML_ROWS; ++r) {
-        const int i = i_base + r;
-        const bool ok = col_ok && i < g.h;  // wave-uniform in i, per-lane in j
-        const R v = km_base_y<R, CM>(g, i < g.h ? i : 0);
-        KmCoord<R> cd;
-        km_gen_coord<R, CM>(m, u, v, cd);
-        R mx, my;
-        const R x = km_unnormalize(cd.gx, W, align, mx);
-        const R y = km_unnormalize(cd.gy, H, align, my);
-        KmBilin<R> t;
-        km_bilinear_setup(x, y, W, H, t);
-        // the warped ones image: the in-bounds weights through the forward's fma chain (nw, ne, sw, se from 0)
-        R ones = 0;
-        if (t.b00) ones = km_fma((R)1, t.w00, ones);
-        if (t.b01) ones = km_fma((R)1, t.w01, ones);
-        if (t.b10) ones = km_fma((R)1, t.w10, ones);
-        if (t.b11) ones = km_fma((R)1, t.w11, ones);
-        ones = km_round_as(ones, (const T*)nullptr);
-        const bool sel = ok && (ones > a.threshold);
-        const uint32_t d_off = ok ? (uint32_t)i * (uint32_t)g.w + (uint32_t)j : 0u;
-        R gix = 0, giy = 0;
-        if (__any(sel)) {
-            const bool inside = __all(t.b00 && t.b01 && t.b10 && t.b11);
-            for (int c = 0; c < C; ++c) {
-                const T* img = src_b + (size_t)c * src_plane;
-                R s00, s01, s10, s11;
-                if (inside) {  // (x0, x0 + 1) of a row with one load
-                    km_ld2(km_at(img, (uint32_t)t.i00), s00, s01);
-                    km_ld2(km_at(img, (uint32_t)t.i10), s10, s11);
-                } else {       // clamped addresses, out-of-bounds taps are not part of the reference's sum
-                    const R v00 = (R)km_ld(img + t.i00), v01 = (R)km_ld(img + t.i01), v10 = (R)km_ld(img + t.i10), v11 = (R)km_ld(img + t.i11);
-                    s00 = t.b00 ? v00 : (R)0; s01 = t.b01 ? v01 : (R)0; s10 = t.b10 ? v10 : (R)0; s11 = t.b11 ? v11 : (R)0;
-                }
-                R wv = 0;
-                if (t.b00) wv = km_fma(s00, t.w00, wv);
-                if (t.b01) wv = km_fma(s01, t.w01, wv);
-                if (t.b10) wv = km_fma(s10, t.w10, wv);
-                if (t.b11) wv = km_fma(s11, t.w11, wv);
-                wv = km_round_as(wv, (const T*)nullptr);  // the warped image is stored in the image dtype by the reference
-                const R d = (R)km_ld(km_at(dst_b + (size_t)c * dst_plane, d_off));
-                const R diff = wv - d;
-                const R e = mse ? diff * diff : km_fabs(diff);
-                const R ge = mse ? (R)2 * diff : (diff > (R)0 ? (R)1 : (diff < (R)0 ? (R)-1 : (R)0));
-                if (sel) {
-                    loss_sum += e;
-                    count += 1;
-                    gix = km_fma(ge, km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-                    giy = km_fma(ge, km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
+    for (int r0 = 0; r0 < KML_ROWS; r0 += KML_GROUP) {
+        KmCoord<R> cd[KML_GROUP];
+        KmBilin<R> t[KML_GROUP];
+        R mx[KML_GROUP], my[KML_GROUP], gix[KML_GROUP], giy[KML_GROUP];
+        uint32_t d_off[KML_GROUP];
+        bool sel[KML_GROUP];
+        bool inside = true, any_sel = false;
+#pragma unroll
+        for (int q = 0; q < KML_GROUP; ++q) {
+            const int i = i_base + (r0 + q) * PH;
+            const bool ok = col_ok && (i < g.h);
+            km_gen_coord<R, CM>(m, u, s_v[li_base + (r0 + q) * PH], cd[q]);
+            const R x = km_unnormalize(cd[q].gx, W, align, mx[q]);
+            const R y = km_unnormalize(cd[q].gy, H, align, my[q]);
+            km_bilinear_setup(x, y, W, H, t[q]);
+            // the warped ones image: the in-bounds weights through the forward's fma chain (nw, ne, sw, se from 0)
+            R ones = 0;
+            if (t[q].b00) ones = km_fma((R)1, t[q].w00, ones);
+            if (t[q].b01) ones = km_fma((R)1, t[q].w01, ones);
+            if (t[q].b10) ones = km_fma((R)1, t[q].w10, ones);
+            if (t[q].b11) ones = km_fma((R)1, t[q].w11, ones);
+            ones = km_round_as(ones, (const T*)nullptr);
+            sel[q] = ok && (ones > a.threshold);
+            d_off[q] = ok ? (uint32_t)i * (uint32_t)g.w + (uint32_t)j : 0u;
+            inside = inside && t[q].b00 && t[q].b01 && t[q].b10 && t[q].b11;
+            any_sel = any_sel || sel[q];
+            gix[q] = 0;
+            giy[q] = 0;
+        }
+        if (__any(any_sel)) {
+            if (NC > 0 && __all(inside)) {
+                // every lane samples inside the image for all rows of the group: all loads back to back before the first use
+                constexpr int NCC = NC > 0 ? NC : 1;
+                R dv[KML_GROUP][NCC], v[KML_GROUP][NCC][4];
+#pragma unroll
+                for (int q = 0; q < KML_GROUP; ++q)
+#pragma unroll
+                    for (int c = 0; c < NCC; ++c) {
+                        dv[q][c] = (R)km_ld(km_at(dst_b + c * dst_plane, d_off[q]));
+                        km_ld2(km_at(src_b + c * src_plane, (uint32_t)t[q].i00), v[q][c][0], v[q][c][1]);
+                        km_ld2(km_at(src_b + c * src_plane, (uint32_t)t[q].i10), v[q][c][2], v[q][c][3]);
+                    }
+#pragma unroll
+                for (int q = 0; q < KML_GROUP; ++q)
+#pragma unroll
+                    for (int c = 0; c < NCC; ++c) {
+                        const R s00 = v[q][c][0], s01 = v[q][c][1], s10 = v[q][c][2], s11 = v[q][c][3];
+                        R wv = km_fma(s00, t[q].w00, (R)0);
+                        wv = km_fma(s01, t[q].w01, wv);
+                        wv = km_fma(s10, t[q].w10, wv);
+                        wv = km_fma(s11, t[q].w11, wv);
+                        wv = km_round_as(wv, (const T*)nullptr);  // the reference stores the warped image in the image dtype
+                        R e, ge;
+                        kml_elem(mse, wv - dv[q][c], e, ge);
+                        if (sel[q]) {
+                            loss_sum += e;
+                            count += 1;
+                            gix[q] = km_fma(ge, km_fma(s01 - s00, t[q].wy1, (s11 - s10) * t[q].wy0), gix[q]);
+                            giy[q] = km_fma(ge, km_fma(s10 - s00, t[q].wx1, (s11 - s01) * t[q].wx0), giy[q]);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < KML_GROUP; ++q) {
+                    const KmBilin<R>& tq = t[q];
+                    const bool row_inside = __all(tq.b00 && tq.b01 && tq.b10 && tq.b11);
+                    for (int c = 0; c < C; ++c) {
+                        const T* img = src_b + (size_t)c * src_plane;
+                        R s00, s01, s10, s11;
+                        if (row_inside) {  // (x0, x0 + 1) of a row with one load
+                            km_ld2(km_at(img, (uint32_t)tq.i00), s00, s01);
+                            km_ld2(km_at(img, (uint32_t)tq.i10), s10, s11);
+                        } else {           // clamped addresses; out-of-bounds taps are not part of the reference's sum
+                            const R v00 = (R)km_ld(img + tq.i00), v01 = (R)km_ld(img + tq.i01), v10 = (R)km_ld(img + tq.i10), v11 = (R)km_ld(img + tq.i11);
+                            s00 = tq.b00 ? v00 : (R)0; s01 = tq.b01 ? v01 : (R)0; s10 = tq.b10 ? v10 : (R)0; s11 = tq.b11 ? v11 : (R)0;
+                        }
+                        R wv = 0;
+                        if (tq.b00) wv = km_fma(s00, tq.w00, wv);
+                        if (tq.b01) wv = km_fma(s01, tq.w01, wv);
+                        if (tq.b10) wv = km_fma(s10, tq.w10, wv);
+                        if (tq.b11) wv = km_fma(s11, tq.w11, wv);
+                        wv = km_round_as(wv, (const T*)nullptr);
+                        const R d = (R)km_ld(km_at(dst_b + (size_t)c * dst_plane, d_off[q]));
+                        R e, ge;
+                        kml_elem(mse, wv - d, e, ge);
+                        if (sel[q]) {
+                            loss_sum += e;
+                            count += 1;
+                            gix[q] = km_fma(ge, km_fma(s01 - s00, tq.wy1, (s11 - s10) * tq.wy0), gix[q]);
+                            giy[q] = km_fma(ge, km_fma(s10 - s00, tq.wx1, (s11 - s01) * tq.wx0), giy[q]);
+                        }
+                    }
                 }
             }
         }
-        const R gx_ = sel ? gix * mx : (R)0, gy_ = sel ? giy * my : (R)0;
-        R ax, ay, az;
-        km_gm_terms<CM>(cd, gx_, gy_, ax, ay, az);
-        if (sel) {  // unselected pixels may have undefined coordinates (NaN * 0): keep them out of the sums
-            S[0] += ax; S[1] += ay; S[2] += az;
-            Sv[0] = km_fma(ax, cd.v, Sv[0]); Sv[1] = km_fma(ay, cd.v, Sv[1]); Sv[2] = km_fma(az, cd.v, Sv[2]);
+#pragma unroll
+        for (int q = 0; q < KML_GROUP; ++q) {
+            const R gx_ = sel[q] ? gix[q] * mx[q] : (R)0, gy_ = sel[q] ? giy[q] * my[q] : (R)0;
+            R ax, ay, az;
+            km_gm_terms<CM>(cd[q], gx_, gy_, ax, ay, az);
+            if (sel[q]) {  // unselected pixels may have undefined coordinates (NaN * 0): keep them out of the sums
+                S[0] += ax; S[1] += ay; S[2] += az;
+                Sv[0] = km_fma(ax, cd[q].v, Sv[0]); Sv[1] = km_fma(ay, cd[q].v, Sv[1]); Sv[2] = km_fma(az, cd[q].v, Sv[2]);
+            }
         }
     }
     R out[11];
@@ -151,6 +217,16 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
     }
 }
 
+template <typename T, int CM>
+static void kml_launch(const KmWarpLossArgs<T>& a, hipStream_t s) {
+    if (a.g.C == 3)
+        hipLaunchKernelGGL((km_warp_loss_kernel<T, CM, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else if (a.g.C == 1)
+        hipLaunchKernelGGL((km_warp_loss_kernel<T, CM, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_loss_kernel<T, CM, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
+}
+
 template <typename T>
 static int kml_run(const void* src, const void* dst, const void* mat, double* acc, int B, int C, int H, int W, int h, int w, int B_M,
                    int coord_mode, int norm_coords, int align, int loss_kind, double threshold, hipStream_t s) {
@@ -159,16 +235,16 @@ static int kml_run(const void* src, const void* dst, const void* mat, double* ac
     a.threshold = (float)threshold; a.loss_kind = loss_kind;
     KmWarpGeom<float>& g = a.g;
     km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, KM_INTERP_BILINEAR, KM_PAD_ZEROS, align);
-    a.tiles_x = (uint32_t)((w + 63) / 64);
+    a.tiles_x = (uint32_t)((w + KML_TILE_W - 1) / KML_TILE_W);
     a.tiles_y = (uint32_t)((h + KML_TILE_H - 1) / KML_TILE_H);
     const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
     KM_REQUIRE(nb < (1ull << 31), "km_warp_masked_loss: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
     switch (coord_mode) {
-        case KM_COORD_PERSPECTIVE: hipLaunchKernelGGL((km_warp_loss_kernel<T, KM_COORD_PERSPECTIVE>), dim3(a.nblocks), dim3(256), 0, s, a); break;
-        case KM_COORD_AFFINE: hipLaunchKernelGGL((km_warp_loss_kernel<T, KM_COORD_AFFINE>), dim3(a.nblocks), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((km_warp_loss_kernel<T, KM_COORD_HOMOGRAPHY>), dim3(a.nblocks), dim3(256), 0, s, a); break;
+        case KM_COORD_PERSPECTIVE: kml_launch<T, KM_COORD_PERSPECTIVE>(a, s); break;
+        case KM_COORD_AFFINE: kml_launch<T, KM_COORD_AFFINE>(a, s); break;
+        default: kml_launch<T, KM_COORD_HOMOGRAPHY>(a, s); break;
     }
     return km_check_launch("km_warp_masked_loss");
 }
