@@ -193,6 +193,18 @@ def other_configs(dev):
         out["cfg5_128x3x256x256_l1_loss(homography_warp)+gradH_one_launch_ms"] = t(cfg5_step)
     except Exception as e:  # informational only
         out["error_next_rows"] = f"{type(e).__name__}: {e}"
+    try:  # the remaining callers of the path, small so that the default run stays short
+        T = K.geometry.transform
+        with torch.no_grad():
+            x = torch.rand(64, 3, 256, 256, device=dev)
+            out["pyrup_64x3x256x256_to_512_ms"] = t(lambda: T.pyrup(x))
+            x = torch.rand(8, 1, 512, 512, device=dev)
+            sp = T.ScalePyramid().to(dev)
+            out["scale_pyramid_8x1x512x512_ms"] = t(lambda: sp(x))
+            x = torch.rand(16, 3, 512, 512, device=dev)
+            out["canny_16x3x512x512_ms"] = t(lambda: K.filters.canny(x))
+    except Exception as e:  # informational only
+        out["error_callers"] = f"{type(e).__name__}: {e}"
     return out
 
 
