@@ -22,6 +22,20 @@ def _from_kornia():
         return None
 
 
+def _detail_error(name: str, fields: tuple, doc: str, base: type) -> type:
+    """An error type that carries optional keyword-only details (``None`` when not given), e.g. ``ShapeError(msg, actual_shape=...)``."""
+
+    def __init__(self, message: str, **details: Any) -> None:
+        unknown = sorted(set(details) - set(fields))
+        if unknown:
+            raise TypeError(f"{name}() got unexpected keyword arguments {unknown}")
+        base.__init__(self, message)
+        for field in fields:
+            setattr(self, field, details.get(field))
+
+    return type(name, (base,), {"__init__": __init__, "__doc__": doc, "__module__": __name__, "_fields": fields})
+
+
 _k = _from_kornia()
 if _k is not None:
     BaseError, ShapeError, TypeCheckError, ValueCheckError, DeviceError = _k
@@ -30,26 +44,7 @@ else:
     class BaseError(Exception):
         """Root of all validation errors."""
 
-    class ShapeError(BaseError):
-        def __init__(self, message: str, *, actual_shape=None, expected_shape=None):
-            super().__init__(message)
-            self.actual_shape = actual_shape
-            self.expected_shape = expected_shape
-
-    class TypeCheckError(BaseError):
-        def __init__(self, message: str, *, actual_type: Optional[type] = None, expected_type: Any = None):
-            super().__init__(message)
-            self.actual_type = actual_type
-            self.expected_type = expected_type
-
-    class ValueCheckError(BaseError):
-        def __init__(self, message: str, *, actual_value: Any = None, expected_range: Any = None):
-            super().__init__(message)
-            self.actual_value = actual_value
-            self.expected_range = expected_range
-
-    class DeviceError(BaseError):
-        def __init__(self, message: str, *, actual_devices: Optional[list] = None, expected_device: Any = None):
-            super().__init__(message)
-            self.actual_devices = actual_devices
-            self.expected_device = expected_device
+    ShapeError = _detail_error("ShapeError", ("actual_shape", "expected_shape"), "A tensor does not have the required shape.", BaseError)
+    TypeCheckError = _detail_error("TypeCheckError", ("actual_type", "expected_type"), "An argument has the wrong type.", BaseError)
+    ValueCheckError = _detail_error("ValueCheckError", ("actual_value", "expected_range"), "A value lies outside its allowed range.", BaseError)
+    DeviceError = _detail_error("DeviceError", ("actual_devices", "expected_device"), "Tensors live on different devices.", BaseError)

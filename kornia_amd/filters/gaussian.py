@@ -26,77 +26,67 @@ def _cached_taps(ky: int, kx: int, sigma: tuple, dtype: torch.dtype, device: tor
     return kernel_x.to(device), kernel_y.to(device)
 
 
-def gaussian_blur2d(
-    input: torch.Tensor,
-    kernel_size: Union[tuple[int, int], int],
-    sigma: Union[tuple[float, float], torch.Tensor],
-    border_type: str = "reflect",
-    separable: bool = True,
-) -> torch.Tensor:
+def _check_host_sigma(sigma: tuple) -> tuple[float, float]:
+    """A tuple sigma is validated on the host: no tensor is built and nothing synchronises."""
+    KORNIA_CHECK(len(sigma) == 2, "Shape dimension mismatch: expected sigma of shape ['B', '2']")
+    sy, sx = float(sigma[0]), float(sigma[1])
+    KORNIA_CHECK(sy > 0 and sx > 0, f"sigma must be positive, got {sigma}")
+    return sy, sx
+
+
+def _check_tensor_sigma(sigma: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """A tensor sigma goes through the reference's own test, ``(sigma > 0).all()``, which synchronises on a device tensor."""
+    KORNIA_CHECK_IS_TENSOR(sigma)
+    sigma = sigma.to(device=like.device, dtype=like.dtype)
+    KORNIA_CHECK_SHAPE(sigma, ["B", "2"])
+    if not torch.compiler.is_compiling():
+        KORNIA_CHECK(bool((sigma > 0).all()), f"sigma must be positive, got {sigma}")
+    return sigma
+
+
+def gaussian_blur2d(input: torch.Tensor, kernel_size: Union[tuple[int, int], int], sigma: Union[tuple[float, float], torch.Tensor],
+                    border_type: str = "reflect", separable: bool = True) -> torch.Tensor:
     r"""Blur ``input`` (B,C,H,W) with a Gaussian of size ``kernel_size`` (int or (ky, kx), odd) and
     standard deviation ``sigma`` = (sigma_y, sigma_x) floats or a (B,2) tensor (per-sample blur).
 
     ``border_type``: ``'constant' | 'reflect' | 'replicate' | 'circular'``; ``separable=False`` applies
     the full 2-D kernel instead of two 1-D passes.
-
-    A tuple ``sigma`` is validated on the host (no device sync); a tensor ``sigma`` is checked with the
-    reference's ``(sigma > 0).all()`` test, which synchronises when it lives on the device.
     """
     KORNIA_CHECK_IS_TENSOR(input)
     KORNIA_CHECK_SHAPE(input, ["B", "C", "H", "W"])
     _check_kernel_size(kernel_size, min_value=0)
+    ky, kx = _unpack_2d_ks(kernel_size)
 
     if isinstance(sigma, tuple):
-        KORNIA_CHECK(len(sigma) == 2, "Shape dimension mismatch: expected sigma of shape ['B', '2']")
-        positive = all(float(s) > 0 for s in sigma)
-        KORNIA_CHECK(positive, "sigma must be positive" if positive else f"sigma must be positive, got {sigma}")
-        if separable and N.on_device(input):
-            ky, kx = _unpack_2d_ks(kernel_size)
-            kernel_x, kernel_y = _cached_taps(ky, kx, (float(sigma[0]), float(sigma[1])), input.dtype, input.device)
-            return filter2d_separable(input, kernel_x, kernel_y, border_type)
+        host_sigma = _check_host_sigma(sigma)
+        if separable and N.on_device(input):  # steady state: one launch, taps resident on the device
+            taps_x, taps_y = _cached_taps(ky, kx, host_sigma, input.dtype, input.device)
+            return filter2d_separable(input, taps_x, taps_y, border_type)
         sigma = torch.tensor([sigma], device=input.device, dtype=input.dtype)
     else:
-        KORNIA_CHECK_IS_TENSOR(sigma)
-        sigma = sigma.to(device=input.device, dtype=input.dtype)
-        KORNIA_CHECK_SHAPE(sigma, ["B", "2"])
-        if not torch.compiler.is_compiling():
-            positive = bool((sigma > 0).all())
-            KORNIA_CHECK(positive, "sigma must be positive" if positive else f"sigma must be positive, got {sigma}")
+        sigma = _check_tensor_sigma(sigma, input)
 
-    if separable:
-        ky, kx = _unpack_2d_ks(kernel_size)
-        bs = sigma.shape[0]
-        kernel_x = get_gaussian_kernel1d(kx, sigma[:, 1].view(bs, 1))
-        kernel_y = get_gaussian_kernel1d(ky, sigma[:, 0].view(bs, 1))
-        return filter2d_separable(input, kernel_x, kernel_y, border_type)
-    kernel = get_gaussian_kernel2d(kernel_size, sigma)
-    return filter2d(input, kernel, border_type)
+    if not separable:
+        return filter2d(input, get_gaussian_kernel2d(kernel_size, sigma), border_type)
+    per_sample = sigma.shape[0]
+    # sigma[:, 0] is the vertical deviation, sigma[:, 1] the horizontal one (gaussian.py:111-114)
+    taps_x = get_gaussian_kernel1d(kx, sigma[:, 1].view(per_sample, 1))
+    taps_y = get_gaussian_kernel1d(ky, sigma[:, 0].view(per_sample, 1))
+    return filter2d_separable(input, taps_x, taps_y, border_type)
 
 
 class GaussianBlur2d(nn.Module):
     r"""Module form of :func:`gaussian_blur2d` (same arguments)."""
 
-    def __init__(
-        self,
-        kernel_size: Union[tuple[int, int], int],
-        sigma: Union[tuple[float, float], torch.Tensor],
-        border_type: str = "reflect",
-        separable: bool = True,
-    ) -> None:
+    _FIELDS = ("kernel_size", "sigma", "border_type", "separable")
+
+    def __init__(self, kernel_size: Union[tuple[int, int], int], sigma: Union[tuple[float, float], torch.Tensor], border_type: str = "reflect",
+                 separable: bool = True) -> None:
         super().__init__()
-        self.kernel_size = kernel_size
-        self.sigma = sigma
-        self.border_type = border_type
-        self.separable = separable
+        self.kernel_size, self.sigma, self.border_type, self.separable = kernel_size, sigma, border_type, separable
 
     def __repr__(self) -> str:
-        return (
-            f"{self.__class__.__name__}"
-            f"(kernel_size={self.kernel_size}, "
-            f"sigma={self.sigma}, "
-            f"border_type={self.border_type}, "
-            f"separable={self.separable})"
-        )
+        return f"{type(self).__name__}(" + ", ".join(f"{name}={getattr(self, name)}" for name in self._FIELDS) + ")"
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return gaussian_blur2d(input, self.kernel_size, self.sigma, self.border_type, self.separable)
+        return gaussian_blur2d(input, *(getattr(self, name) for name in self._FIELDS))

@@ -84,6 +84,8 @@ def masked_warp_loss(src: torch.Tensor, dst: torch.Tensor, src_homo_dst: torch.T
 
 
 class BaseModel(nn.Module):
+    """A learnable geometric model: ``forward()`` gives the matrix, ``forward_inverse()`` the matrix of the opposite direction."""
+
     def reset_model(self) -> None:
         raise NotImplementedError
 
@@ -100,60 +102,58 @@ class Homography(BaseModel):
     def __init__(self) -> None:
         super().__init__()
         self.model = nn.Parameter(torch.eye(3))
-        self.reset_model()
 
     def __repr__(self) -> str:
-        return f"{self.__class__.__name__}({self.model})"
+        return f"{type(self).__name__}({self.model})"
 
     def reset_model(self) -> None:
-        torch.nn.init.eye_(self.model)
+        nn.init.eye_(self.model)
 
     def forward(self) -> torch.Tensor:
-        return torch.unsqueeze(self.model / self.model[2, 2], dim=0)
+        return (self.model / self.model[2, 2])[None]
 
     def forward_inverse(self) -> torch.Tensor:
-        return torch.unsqueeze(torch.inverse(self.model), dim=0)
+        return torch.inverse(self.model)[None]
 
 
 class Similarity(BaseModel):
     """Rotation / scale / shift, each either optimised or held at its neutral value."""
 
+    _NEUTRAL = {"rot": lambda: torch.zeros(1), "shift": lambda: torch.zeros(1, 2, 1), "scale": lambda: torch.ones(1)}
+
     def __init__(self, rotation: bool = True, scale: bool = True, shift: bool = True) -> None:
         super().__init__()
-        if rotation:
-            self.rot = nn.Parameter(torch.zeros(1))
-        else:
-            self.register_buffer("rot", torch.zeros(1))
-        if shift:
-            self.shift = nn.Parameter(torch.zeros(1, 2, 1))
-        else:
-            self.register_buffer("shift", torch.zeros(1, 2, 1))
-        if scale:
-            self.scale = nn.Parameter(torch.ones(1))
-        else:
-            self.register_buffer("scale", torch.ones(1))
-        self.reset_model()
+        for name, learn in (("rot", rotation), ("shift", shift), ("scale", scale)):
+            value = self._NEUTRAL[name]()
+            if learn:
+                setattr(self, name, nn.Parameter(value))
+            else:
+                self.register_buffer(name, value)
 
     def __repr__(self) -> str:
-        return f"{self.__class__.__name__}(angle = {self.rot},               \n shift={self.shift}, \n scale={self.scale})"
+        return f"{type(self).__name__}(angle = {self.rot},               \n shift={self.shift}, \n scale={self.scale})"
 
     def reset_model(self) -> None:
-        torch.nn.init.zeros_(self.rot)
-        torch.nn.init.zeros_(self.shift)
-        torch.nn.init.ones_(self.scale)
+        with torch.no_grad():
+            for name, make in self._NEUTRAL.items():
+                getattr(self, name).copy_(make())
 
     def forward(self) -> torch.Tensor:
-        rot = self.scale * angle_to_rotation_matrix(self.rot)
-        return convert_affinematrix_to_homography(torch.cat([rot, self.shift], dim=2))
+        linear = self.scale * angle_to_rotation_matrix(self.rot)
+        return convert_affinematrix_to_homography(torch.cat([linear, self.shift], dim=2))
 
     def forward_inverse(self) -> torch.Tensor:
         return torch.inverse(self.forward())
 
 
+# model_type string -> which of (rotation, scale, shift) a Similarity optimises; "homography" is the full 3x3 matrix
+_NAMED_MODELS = {"similarity": (True, True, True), "translation": (False, False, True), "rotation": (True, False, False), "scale": (False, True, False)}
+
+
 class ImageRegistrator(nn.Module):
     r"""Coarse-to-fine gradient descent on a geometric model that warps ``src_img`` onto ``dst_img``.
 
-    Same arguments, defaults and return values as the reference's class.  ``register`` keeps the reference's control flow
+    Same arguments, defaults and return values as the reference's class; ``register`` keeps the reference's stopping rule
     (one ``loss.item()`` per iteration for the tolerance test)."""
 
     known_models = ["homography", "similarity", "translation", "scale", "rotation"]
@@ -162,31 +162,21 @@ class ImageRegistrator(nn.Module):
                  pyramid_levels: int = 5, lr: float = 1e-3, num_iterations: int = 100, tolerance: float = 1e-4, warper: Optional[type] = None,
                  allow_shape_mismatch: bool = False) -> None:
         super().__init__()
-        if not isinstance(model_type, str):
+        if isinstance(model_type, str):
+            key = model_type.lower()
+            if key not in self.known_models:
+                raise ValueError(f"{model_type} is not supported. Try {self.known_models}")
+            self.model = Homography() if key == "homography" else Similarity(*_NAMED_MODELS[key])
+            self.warper = HomographyWarper
+        else:
             if warper is None:
                 raise ValueError("You must supply warper together with custom model")
-            self.warper = warper
-            self.model = model_type
-        elif model_type.lower() == "homography":
-            self.warper, self.model = HomographyWarper, Homography()
-        elif model_type.lower() == "similarity":
-            self.warper, self.model = HomographyWarper, Similarity(True, True, True)
-        elif model_type.lower() == "translation":
-            self.warper, self.model = HomographyWarper, Similarity(False, False, True)
-        elif model_type.lower() == "rotation":
-            self.warper, self.model = HomographyWarper, Similarity(True, False, False)
-        elif model_type.lower() == "scale":
-            self.warper, self.model = HomographyWarper, Similarity(False, True, False)
-        else:
-            raise ValueError(f"{model_type} is not supported. Try {self.known_models}")
-        self.pyramid_levels = pyramid_levels
-        self.optimizer = optimizer
-        self.lr = lr
-        self.loss_fn = loss_fn
-        self.num_iterations = num_iterations
-        self.tolerance = tolerance
-        self.allow_shape_mismatch = allow_shape_mismatch
+            self.model, self.warper = model_type, warper
+        self.pyramid_levels, self.num_iterations = pyramid_levels, num_iterations
+        self.optimizer, self.lr, self.loss_fn = optimizer, lr, loss_fn
+        self.tolerance, self.allow_shape_mismatch = tolerance, allow_shape_mismatch
 
+    # ---- one level ---------------------------------------------------------------------------------------------------
     def _fused_loss_kind(self, img_src: torch.Tensor, img_dst: torch.Tensor, transform_model: torch.Tensor) -> Optional[str]:
         kind = "l1" if self.loss_fn is F.l1_loss else ("mse" if self.loss_fn is F.mse_loss else None)
         ok = (
@@ -204,16 +194,18 @@ class ImageRegistrator(nn.Module):
         kind = self._fused_loss_kind(img_src, img_dst, transform_model)
         if kind is not None:
             return masked_warp_loss(img_src, img_dst, transform_model, kind)
-        _height, _width = img_dst.shape[-2:]
-        warper = self.warper(_height, _width)
-        img_src_to_dst = warper(img_src, transform_model)
-        loss = self.loss_fn(img_src_to_dst, img_dst, reduction="none")
-        ones_tensor = warper(torch.ones_like(img_src), transform_model)
-        return loss.masked_select(ones_tensor > 0.9).mean()
+        # any other warper / loss: the reference's composition on the native warps
+        warp = self.warper(*img_dst.shape[-2:])
+        covered = warp(torch.ones_like(img_src), transform_model) > 0.9
+        return self.loss_fn(warp(img_src, transform_model), img_dst, reduction="none").masked_select(covered).mean()
+
+    def _symmetric_loss(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        return self.get_single_level_loss(a, b, self.model()) + self.get_single_level_loss(b, a, self.model.forward_inverse())
 
     def reset_model(self) -> None:
         self.model.reset_model()
 
+    # ---- the whole pyramid ---------------------------------------------------------------------------------------------
     def register(self, src_img: torch.Tensor, dst_img: torch.Tensor, verbose: bool = False, output_intermediate_models: bool = False):
         r"""Estimate the transformation that warps ``src_img`` into ``dst_img``; returns the model matrix ((1,3,3) for the named
         models), and the per-level models as well when ``output_intermediate_models``."""
@@ -222,37 +214,28 @@ class ImageRegistrator(nn.Module):
             if not self.allow_shape_mismatch:
                 raise ValueError(f"Cannot register images of different shapes {src_img.shape} {dst_img.shape}. Consider setting `allow_shape_mismatch = True`")
             src_img = F.interpolate(src_img, size=dst_img.shape[-2:], mode="bilinear", align_corners=False)
-        _opt_args: dict[str, Any] = {"lr": self.lr}
-        opt = self.optimizer(self.model.parameters(), **_opt_args)
-        img_src_pyr = build_pyramid(src_img, self.pyramid_levels)[::-1]
-        img_dst_pyr = build_pyramid(dst_img, self.pyramid_levels)[::-1]
-        prev_loss = 1e10
-        aux_models = []
-        if len(img_dst_pyr) != len(img_src_pyr):
-            raise ValueError("Cannot register images of different sizes")
-        for img_src_level, img_dst_level in zip(img_src_pyr, img_dst_pyr):
-            for i in range(self.num_iterations):
+        opt = self.optimizer(self.model.parameters(), lr=self.lr)
+        coarse_to_fine = list(zip(reversed(build_pyramid(src_img, self.pyramid_levels)), reversed(build_pyramid(dst_img, self.pyramid_levels))))
+        last = 1e10  # carried across levels, like the reference
+        per_level = []
+        for level_src, level_dst in coarse_to_fine:
+            for it in range(self.num_iterations):
                 opt.zero_grad()
-                loss = self.get_single_level_loss(img_src_level, img_dst_level, self.model())
-                loss = loss + self.get_single_level_loss(img_dst_level, img_src_level, self.model.forward_inverse())
-                current_loss = loss.item()
-                if abs(current_loss - prev_loss) < self.tolerance:
+                loss = self._symmetric_loss(level_src, level_dst)
+                value = loss.item()
+                if abs(value - last) < self.tolerance:
                     break
-                prev_loss = current_loss
+                last = value
                 loss.backward()
-                if verbose and (i % 10 == 0):
-                    print(f"Loss = {current_loss:.4f}, iter={i}")
+                if verbose and it % 10 == 0:
+                    print(f"Loss = {value:.4f}, iter={it}")
                 opt.step()
             if output_intermediate_models:
-                aux_models.append(self.model().clone().detach())
-        if output_intermediate_models:
-            return self.model(), aux_models
-        return self.model()
+                per_level.append(self.model().detach().clone())
+        return (self.model(), per_level) if output_intermediate_models else self.model()
 
     def warp_src_into_dst(self, src_img: torch.Tensor) -> torch.Tensor:
-        _height, _width = src_img.shape[-2:]
-        return self.warper(_height, _width)(src_img, self.model())
+        return self.warper(*src_img.shape[-2:])(src_img, self.model())
 
     def warp_dst_inro_src(self, dst_img: torch.Tensor) -> torch.Tensor:  # the reference's spelling
-        _height, _width = dst_img.shape[-2:]
-        return self.warper(_height, _width)(dst_img, self.model.forward_inverse())
+        return self.warper(*dst_img.shape[-2:])(dst_img, self.model.forward_inverse())

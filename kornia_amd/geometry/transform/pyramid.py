@@ -13,6 +13,7 @@ Reference behaviour mirrored: kornia/geometry/transform/pyramid.py - pyrdown :40
 from __future__ import annotations
 
 import math
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
@@ -147,6 +148,10 @@ def _interpolate_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.T
     return resize_bilinear(x, size, align_corners)
 
 
+def _odd_at_most(n: int) -> int:
+    return n if n % 2 == 1 else n - 1
+
+
 class ScalePyramid(nn.Module):
     r"""Gaussian scale space: per octave ``n_levels + extra_levels`` progressively blurred images of one resolution, the next
     octave starting from the level with twice the initial sigma, decimated by two (pyramid.py:151-400).
@@ -157,98 +162,90 @@ class ScalePyramid(nn.Module):
 
     def __init__(self, n_levels: int = 3, init_sigma: float = 1.6, min_size: int = 15, double_image: bool = False, extra_levels: int = 3) -> None:
         super().__init__()
-        self.n_levels = n_levels
-        self.extra_levels = extra_levels
-        self.init_sigma = init_sigma
-        self.min_size = min_size
+        self.n_levels, self.extra_levels = n_levels, extra_levels
+        self.init_sigma, self.min_size, self.double_image = init_sigma, min_size, double_image
         self.border = min_size // 2 - 1
-        self.sigma_step = 2 ** (1.0 / float(self.n_levels))
-        self.double_image = double_image
-        self._precompute_gauss_kernels(n_levels, extra_levels, init_sigma, double_image)
+        self.sigma_step = 2 ** (1.0 / float(n_levels))
+        # taps of the first blur (input sigma 0.5, or 1.0 after doubling -> init_sigma) and of every level-to-level increment
+        start = 1.0 if double_image else 0.5
+        first = self._incremental_sigma(start, init_sigma) if init_sigma > start else None
+        self.register_buffer("_gk_init", None if first is None else self._make_gaussian_kernel1d(first, self.get_kernel_size(first)))
+        sigma = init_sigma
+        for lvl in range(n_levels + extra_levels - 1):
+            delta = sigma * math.sqrt(self.sigma_step**2 - 1.0)
+            self.register_buffer(f"_gk_{lvl}", self._make_gaussian_kernel1d(delta, self.get_kernel_size(delta)))
+            sigma *= self.sigma_step
 
     def __repr__(self) -> str:
-        return (f"{self.__class__.__name__}(n_levels={self.n_levels}, init_sigma={self.init_sigma}, min_size={self.min_size}, "
-                f"extra_levels={self.extra_levels}, border={self.border}, sigma_step={self.sigma_step}, double_image={self.double_image})")
+        names = ("n_levels", "init_sigma", "min_size", "extra_levels", "border", "sigma_step", "double_image")
+        return f"{type(self).__name__}(" + ", ".join(f"{n}={getattr(self, n)}" for n in names) + ")"
+
+    @staticmethod
+    def _incremental_sigma(have: float, want: float) -> float:
+        """Gaussians compose in quadrature: the blur that takes an image of sigma ``have`` to sigma ``want``."""
+        return max(math.sqrt(want**2 - have**2), 0.01)
 
     @staticmethod
     def _make_gaussian_kernel1d(sigma: float, ksize: int) -> torch.Tensor:
-        x = torch.arange(ksize, dtype=torch.float64) - ksize // 2
-        kernel = torch.exp(-0.5 * x**2 / sigma**2)
-        return (kernel / kernel.sum()).float()
-
-    def _precompute_gauss_kernels(self, n_levels: int, extra_levels: int, init_sigma: float, double_image: bool) -> None:
-        cur_sigma_init = 1.0 if double_image else 0.5
-        if init_sigma > cur_sigma_init:
-            sigma = max(math.sqrt(init_sigma**2 - cur_sigma_init**2), 0.01)
-            self.register_buffer("_gk_init", self._make_gaussian_kernel1d(sigma, self.get_kernel_size(sigma)))
-        else:
-            self.register_buffer("_gk_init", None)
-        cur_s = init_sigma
-        for lvl in range(n_levels + extra_levels - 1):
-            delta = cur_s * math.sqrt(self.sigma_step**2 - 1.0)
-            self.register_buffer(f"_gk_{lvl}", self._make_gaussian_kernel1d(delta, self.get_kernel_size(delta)))
-            cur_s *= self.sigma_step
-
-    def _blur_fast(self, x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
-        k = kernel.to(device=x.device, dtype=x.dtype)[None]
-        return filter2d_separable(x, k, k, "reflect")
+        offsets = torch.arange(ksize, dtype=torch.float64) - ksize // 2
+        taps = torch.exp(-0.5 * offsets**2 / sigma**2)
+        return (taps / taps.sum()).float()
 
     def get_kernel_size(self, sigma: float) -> int:
+        """Odd size covering +-4 sigma."""
         ksize = int(2.0 * 4.0 * sigma + 1.0)
-        return ksize + 1 if ksize % 2 == 0 else ksize
+        return ksize if ksize % 2 == 1 else ksize + 1
+
+    def _blur_fast(self, x: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+        taps = kernel.to(device=x.device, dtype=x.dtype)[None]
+        return filter2d_separable(x, taps, taps, "reflect")
+
+    def _blur(self, x: torch.Tensor, taps: Optional[torch.Tensor], sigma: float, wanted_size: int) -> torch.Tensor:
+        """The precomputed taps when they fit into the image, otherwise a Gaussian clipped to the largest odd size that does."""
+        smallest = min(x.shape[2], x.shape[3])
+        if taps is not None and wanted_size <= smallest:
+            return self._blur_fast(x, taps)
+        k = min(wanted_size, _odd_at_most(smallest))
+        return gaussian_blur2d(x, (k, k), (sigma, sigma))
 
     def get_first_level(self, input: torch.Tensor) -> tuple[torch.Tensor, float, float]:
-        pixel_distance = 1.0
-        cur_sigma = 0.5
+        """``(level, sigma, pixel_distance)`` of the image every octave descends from."""
+        level, sigma, pixel_distance = input, 0.5, 1.0
         if self.double_image:
-            x = _interpolate_bilinear(input, (input.shape[2] * 2, input.shape[3] * 2), True)
-            pixel_distance = 0.5
-            cur_sigma *= 2.0
-        else:
-            x = input
-        if self.init_sigma > cur_sigma:
-            sigma = max(math.sqrt(self.init_sigma**2 - cur_sigma**2), 0.01)
-            ksize = self.get_kernel_size(sigma)
-            min_dim = min(x.size(2), x.size(3))
-            if self._gk_init is not None and ksize <= min_dim:
-                cur_level = self._blur_fast(x, self._gk_init)
-            else:
-                ksize = min(ksize, min_dim if min_dim % 2 == 1 else min_dim - 1)
-                cur_level = gaussian_blur2d(x, (ksize, ksize), (sigma, sigma))
-            cur_sigma = self.init_sigma
-        else:
-            cur_level = x
-        return cur_level, cur_sigma, pixel_distance
+            level = _interpolate_bilinear(input, (input.shape[2] * 2, input.shape[3] * 2), True)
+            sigma, pixel_distance = 1.0, 0.5
+        if self.init_sigma > sigma:
+            delta = self._incremental_sigma(sigma, self.init_sigma)
+            level = self._blur(level, self._gk_init, delta, self.get_kernel_size(delta))
+            sigma = self.init_sigma
+        return level, sigma, pixel_distance
 
     def forward(self, x: torch.Tensor) -> tuple[list[torch.Tensor], list[torch.Tensor], list[torch.Tensor]]:
-        bs = x.shape[0]
-        n = self.n_levels + self.extra_levels
-        cur_level, cur_sigma, pixel_distance = self.get_first_level(x)
-        sigmas = [torch.full((bs, n), cur_sigma, device=x.device, dtype=x.dtype)]
-        pixel_dists = [torch.full((bs, n), pixel_distance, device=x.device, dtype=x.dtype)]
-        pyr = [[cur_level]]
+        batch, per_octave = x.shape[0], self.n_levels + self.extra_levels
+        ratio = math.sqrt(self.sigma_step**2 - 1.0)
+        level, first_sigma, pixel_distance = self.get_first_level(x)
+        stacks, sigmas, pixel_dists = [], [], []
         while True:
-            cur_sigma_oct = self.init_sigma
-            for level_idx in range(1, n):
-                kernel = getattr(self, f"_gk_{level_idx - 1}")
-                prev = pyr[-1][-1]
-                min_dim = min(prev.size(2), prev.size(3))
-                if kernel.shape[0] <= min_dim:
-                    new_level = self._blur_fast(prev, kernel)
+            levels = [level]
+            sig = torch.full((batch, per_octave), first_sigma if not stacks else self.init_sigma, device=x.device, dtype=x.dtype)
+            octave_sigma = self.init_sigma  # nominal sigma of levels[0] in this octave's pixels
+            for idx in range(1, per_octave):
+                taps = getattr(self, f"_gk_{idx - 1}")
+                prev = levels[-1]
+                smallest = min(prev.shape[2], prev.shape[3])
+                if taps.shape[0] <= smallest:
+                    levels.append(self._blur_fast(prev, taps))
                 else:
-                    delta_sigma = cur_sigma_oct * math.sqrt(self.sigma_step**2 - 1.0)
-                    ksize = min_dim if min_dim % 2 == 1 else min_dim - 1
-                    new_level = gaussian_blur2d(prev, (ksize, ksize), (delta_sigma, delta_sigma))
-                cur_sigma_oct *= self.sigma_step
-                pyr[-1].append(new_level)
-                sigmas[-1][:, level_idx] = cur_sigma_oct
-                pixel_dists[-1][:, level_idx] = pixel_distance
-            _pyr = pyr[-1][-self.extra_levels]
-            H, W = _pyr.shape[2], _pyr.shape[3]
-            if min(H // 2, W // 2) <= self.min_size:
-                break
+                    k = _odd_at_most(smallest)
+                    levels.append(gaussian_blur2d(prev, (k, k), (octave_sigma * ratio,) * 2))
+                octave_sigma *= self.sigma_step
+                sig[:, idx] = octave_sigma
+            stacks.append(torch.stack(levels, 2))
+            sigmas.append(sig)
+            pixel_dists.append(torch.full((batch, per_octave), pixel_distance, device=x.device, dtype=x.dtype))
+            seed = levels[-self.extra_levels]  # the level with twice the octave's initial sigma
+            half = (seed.shape[2] // 2, seed.shape[3] // 2)
+            if min(half) <= self.min_size:
+                return stacks, sigmas, pixel_dists
+            level = _interpolate_bilinear(seed, half, True)
             pixel_distance *= 2.0
-            pyr.append([_interpolate_bilinear(_pyr, (H // 2, W // 2), True)])
-            sigmas.append(torch.full((bs, n), self.init_sigma, device=x.device, dtype=x.dtype))
-            pixel_dists.append(torch.full((bs, n), pixel_distance, device=x.device, dtype=x.dtype))
-        return [torch.stack(i, 2) for i in pyr], sigmas, pixel_dists
