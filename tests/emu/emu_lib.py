@@ -27,6 +27,8 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         h.emu_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+        h.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
+        h.emu_set_schedule.restype = None
         _lib = h
     return _lib
 
@@ -40,3 +42,11 @@ def stats() -> dict:
     out = (ctypes.c_ulonglong * 3)()
     lib().emu_stats(out)
     return {"launches": out[0], "workgroups": out[1], "dead_lane_reads": out[2]}
+
+
+SCHEDULES = {"forward": 0, "reverse": 1, "random": 2, "lanes": 3}
+
+
+def set_schedule(mode: str, seed: int = 1) -> None:
+    """Order in which ready work-items resume: 'forward', 'reverse' (waves), 'random' (waves shuffled), 'lanes' (everything shuffled)."""
+    lib().emu_set_schedule(SCHEDULES[mode], seed)

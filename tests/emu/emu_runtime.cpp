@@ -112,7 +112,34 @@ static void fail(const char* what) {
     g_emu_error = 719;  // hipErrorLaunchFailure
 }
 
+// Order in which ready work-items are resumed within one scheduling pass.  Hardware gives no order between waves, so a
+// kernel that is correct must not depend on it: the test suite runs LDS-heavy kernels under "reverse" and seeded "random"
+// orders as well, which exposes a missing barrier (a consumer resumed before its producer) as a wrong result.
+//   KM_EMU_SCHEDULE = forward (default) | reverse | random:<seed> | lanes:<seed>
+static int g_sched_mode = -1;  // 0 forward, 1 waves reversed, 2 waves shuffled, 3 every work-item shuffled
+static unsigned long long g_sched_state = 0;
+static void sched_init() {
+    if (g_sched_mode >= 0) return;
+    const char* e = getenv("KM_EMU_SCHEDULE");
+    g_sched_mode = 0;
+    if (e && e[0] == 'r' && e[1] == 'e') g_sched_mode = 1;
+    if (e && ((e[0] == 'r' && e[1] == 'a') || e[0] == 'l')) {
+        g_sched_mode = e[0] == 'l' ? 3 : 2;
+        const char* c = strchr(e, ':');
+        g_sched_state = c ? strtoull(c + 1, nullptr, 10) : 1;
+        if (!g_sched_state) g_sched_state = 1;
+    }
+}
+extern "C" void emu_set_schedule(int mode, unsigned long long seed) { g_sched_mode = mode; g_sched_state = seed ? seed : 1; }
+static unsigned sched_rand(unsigned n) {  // xorshift64*
+    g_sched_state ^= g_sched_state >> 12; g_sched_state ^= g_sched_state << 25; g_sched_state ^= g_sched_state >> 27;
+    return (unsigned)((g_sched_state * 2685821657736338717ull) >> 33) % n;
+}
+
 static bool run_block(unsigned nthreads) {
+    sched_init();
+    static std::vector<unsigned> order;
+    order.resize(nthreads);
     for (unsigned t = 0; t < nthreads; ++t) {
         Fiber& f = g_fibers[t];
         f.state = READY;
@@ -131,7 +158,22 @@ static bool run_block(unsigned nthreads) {
     for (;;) {
         bool progressed = false;
         unsigned live = 0;
-        for (unsigned t = 0; t < nthreads; ++t) {
+        {   // waves are permuted as units (their lanes run in lane order, as lockstep execution would present them); "lanes"
+            // permutes every work-item, which additionally flags code that relies on lockstep within a wave
+            const unsigned nw = (nthreads + 63) / 64;
+            static std::vector<unsigned> worder;
+            worder.resize(nw);
+            for (unsigned w = 0; w < nw; ++w) worder[w] = g_sched_mode == 1 ? nw - 1 - w : w;
+            if (g_sched_mode >= 2)
+                for (unsigned w = nw - 1; w > 0; --w) std::swap(worder[w], worder[sched_rand(w + 1)]);
+            unsigned k = 0;
+            for (unsigned w = 0; w < nw; ++w)
+                for (unsigned l = 0; l < 64 && worder[w] * 64 + l < nthreads; ++l) order[k++] = worder[w] * 64 + l;
+            if (g_sched_mode == 3)
+                for (unsigned q = nthreads - 1; q > 0; --q) std::swap(order[q], order[sched_rand(q + 1)]);
+        }
+        for (unsigned k = 0; k < nthreads; ++k) {
+            const unsigned t = order[k];
             if (g_fibers[t].state == READY) {
                 g_cur = (int)t;
                 threadIdx = g_fibers[t].tid;

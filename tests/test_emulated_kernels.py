@@ -12,6 +12,7 @@ import os
 import sys
 
 import pytest
+import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 
@@ -47,6 +48,56 @@ def test_emulated_library_exports_the_c_abi():
     for name in _native.exported_symbols():
         assert hasattr(h, name), name
     assert h.km_abi_version() == _native.ABI_VERSION
+
+
+def test_emulator_schedules_expose_a_missing_barrier():
+    """The emulator's own teeth: a hand-off through LDS without a barrier is right by luck in launch order and wrong as soon
+    as the waves resume in another order; with the barrier every order gives the same answer; a wave operation that only part
+    of a wave reaches is reported as a launch failure instead of hanging."""
+    import ctypes
+    import subprocess
+
+    import build_emu
+
+    build_emu.build()
+    so = os.path.join(build_emu.OUT, "libselftest.so")
+    subprocess.run([build_emu.CXX, *build_emu._flags(), "-shared", "-Wl,-Bsymbolic", os.path.join(build_emu.EMU, "selftest_kernels.hip"),
+                    os.path.join(build_emu.EMU, "emu_runtime.cpp"), "-o", so], check=True)
+    h = ctypes.CDLL(so)
+    h.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
+    out = (ctypes.c_int * 512)()
+    expect = [((t + 192) % 256) + 1000 * b for b in range(2) for t in range(256)]
+    for mode in (0, 1, 2, 3):
+        h.emu_set_schedule(mode, 11)
+        assert h.selftest_handoff(out, 2, 1) == 0 and list(out) == expect
+    h.emu_set_schedule(0, 1)
+    assert h.selftest_handoff(out, 2, 0) == 0
+    in_launch_order = list(out)
+    h.emu_set_schedule(1, 1)
+    assert h.selftest_handoff(out, 2, 0) == 0
+    assert list(out) != in_launch_order, "reversing the wave order must change the result of the racy kernel"
+    assert h.selftest_divergent_wave_op(out) != 0
+
+
+@pytest.mark.parametrize("schedule", ["reverse", "random", "lanes"])
+def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
+    """The kernels that communicate through LDS (tile-owner scatter, matrix gradient, fused loss, colour statistics, large
+    separable filter) give the same results when their waves / work-items resume in another order."""
+    import emu_lib
+    import test_gpu_color
+    import test_gpu_filters
+    import test_gpu_warp
+    import test_zz_gpu_registration as reg
+
+    emu_lib.set_schedule(schedule, 5)  # (the autouse fixture below has already entered the emulated device)
+    try:
+        test_gpu_warp.test_tiled_backward_affine_and_homography(oracle, False)
+        test_gpu_warp.test_tiled_backward_vanishing_line_inside_image(oracle)
+        reg.test_single_level_loss_vs_reference("l1", torch.nn.functional.l1_loss)
+        test_gpu_color.test_all_orders_vs_restatement((3, 3, 37, 53))
+        test_gpu_filters.test_large_separable_kernels(oracle, "reflect", (23, 23), (2, 3, 70, 90))
+    finally:
+        emu_lib.set_schedule("forward")
 
 
 @pytest.fixture(autouse=True)
