@@ -26,6 +26,12 @@ int km_check_launch(const char* what);
         }                              \
     } while (0)
 
+// Vector accesses below assume natural alignment (the launchers check pointers and row pitches before choosing such a path).
+// Nothing on the device; the host build of the kernels used by the CPU test tier (tests/emu) turns it into a run-time check.
+#ifndef KM_CHECK_ALIGNED
+#define KM_CHECK_ALIGNED(p, bytes) ((void)0)
+#endif
+
 // ---- storage types ----------------------------------------------------------------------------
 struct km_bf16 {
     uint16_t bits;

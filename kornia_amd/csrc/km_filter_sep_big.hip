@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void km_filter_sep_big_fwd_kernel(const KmSepB
             float w[12];
 #pragma unroll
             for (int v4 = 0; v4 < 3; ++v4) {
+                KM_CHECK_ALIGNED(row + q0 + 4 * v4, 16);
                 const float4 t = *reinterpret_cast<const float4*>(row + q0 + 4 * v4);
                 w[4 * v4] = t.x; w[4 * v4 + 1] = t.y; w[4 * v4 + 2] = t.z; w[4 * v4 + 3] = t.w;
             }
             float kq[8];
             {
+                KM_CHECK_ALIGNED(s_kx + q0, 16);
                 const float4 ka = *reinterpret_cast<const float4*>(s_kx + q0), kb = *reinterpret_cast<const float4*>(s_kx + q0 + 4);
                 kq[0] = ka.x; kq[1] = ka.y; kq[2] = ka.z; kq[3] = ka.w; kq[4] = kb.x; kq[5] = kb.y; kq[6] = kb.z; kq[7] = kb.w;
             }
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void km_filter_sep_big_fwd_kernel(const KmSepB
             float w[12];
 #pragma unroll
             for (int v4 = 0; v4 < 3; ++v4) {
+                KM_CHECK_ALIGNED(row + q0 + 4 * v4, 16);
                 const float4 t = *reinterpret_cast<const float4*>(row + q0 + 4 * v4);
                 w[4 * v4] = t.x; w[4 * v4 + 1] = t.y; w[4 * v4 + 2] = t.z; w[4 * v4 + 3] = t.w;
             }
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256) void km_filter_sep_big_fwd_kernel(const KmSepB
                 for (int i = 0; i < 11; ++i) w[i] = s_tmp[(rbase + p0 + i) * KMS_TW + c];
                 float kp[8];
                 {
+                    KM_CHECK_ALIGNED(s_ky + p0, 16);
                     const float4 ka = *reinterpret_cast<const float4*>(s_ky + p0), kb = *reinterpret_cast<const float4*>(s_ky + p0 + 4);
                     kp[0] = ka.x; kp[1] = ka.y; kp[2] = ka.z; kp[3] = ka.w; kp[4] = kb.x; kp[5] = kb.y; kp[6] = kb.z; kp[7] = kb.w;
                 }

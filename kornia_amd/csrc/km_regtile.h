@@ -23,40 +23,53 @@ __device__ __forceinline__ int km_border_map(int s, int n, int border) {
 
 // four adjacent pixels with one 16-byte (fp32) / 8-byte (bf16, f16) access; p must be aligned to that size
 __device__ __forceinline__ void km_ld4(const float* p, float (&o)[4]) {
+    KM_CHECK_ALIGNED(p, 16);
     const float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 __device__ __forceinline__ void km_ld4(const km_bf16* p, float (&o)[4]) {
+    KM_CHECK_ALIGNED(p, 8);
     const uint2 v = *reinterpret_cast<const uint2*>(p);
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 __device__ __forceinline__ void km_ld4(const km_f16* p, float (&o)[4]) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    KM_CHECK_ALIGNED(p, 8);
     const h4 v = *reinterpret_cast<const h4*>(p);
     o[0] = (float)v.x; o[1] = (float)v.y; o[2] = (float)v.z; o[3] = (float)v.w;
 }
-__device__ __forceinline__ void km_st4(float* p, const float (&o)[4]) { *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]); }
+__device__ __forceinline__ void km_st4(float* p, const float (&o)[4]) {
+    KM_CHECK_ALIGNED(p, 16);
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
 __device__ __forceinline__ void km_st4(km_bf16* p, const float (&o)[4]) {
     uint2 v;
     v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
     v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
+    KM_CHECK_ALIGNED(p, 8);
     *reinterpret_cast<uint2*>(p) = v;
 }
 __device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 v;
     v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    KM_CHECK_ALIGNED(p, 8);
     *reinterpret_cast<h4*>(p) = v;
 }
 // two adjacent pixels with one 8-byte / 4-byte store
-__device__ __forceinline__ void km_st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void km_st2(float* p, float a, float b) {
+    KM_CHECK_ALIGNED(p, 8);
+    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+}
 __device__ __forceinline__ void km_st2(km_bf16* p, float a, float b) {
+    KM_CHECK_ALIGNED(p, 4);
     *reinterpret_cast<uint32_t*>(p) = (uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16);
 }
 __device__ __forceinline__ void km_st2(km_f16* p, float a, float b) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     h2 v;
     v.x = (_Float16)a; v.y = (_Float16)b;
+    KM_CHECK_ALIGNED(p, 4);
     *reinterpret_cast<h2*>(p) = v;
 }

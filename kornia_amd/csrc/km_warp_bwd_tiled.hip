@@ -561,6 +561,8 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
                     const size_t ostep = (size_t)(KMT_NT / 16) * g.W;
 #pragma unroll 2
                     for (int r = row0; r < THc; r += KMT_NT / 16) {
+                        KM_CHECK_ALIGNED(accp, 16);
+                        KM_CHECK_ALIGNED(outp, 16);
                         const int4 q = *reinterpret_cast<const int4*>(accp);
                         float4 v;
                         if (finite) {

@@ -39,9 +39,9 @@ def check(rc: int, what: str) -> None:
 
 
 def stats() -> dict:
-    out = (ctypes.c_ulonglong * 3)()
+    out = (ctypes.c_ulonglong * 4)()
     lib().emu_stats(out)
-    return {"launches": out[0], "workgroups": out[1], "dead_lane_reads": out[2]}
+    return {"launches": out[0], "workgroups": out[1], "dead_lane_reads": out[2], "misaligned_vector_accesses": out[3]}
 
 
 SCHEDULES = {"forward": 0, "reverse": 1, "random": 2, "lanes": 3}

@@ -107,6 +107,13 @@ uint64_t wave_ballot(bool pred) {
     return m;
 }
 
+static unsigned long long g_stat_misaligned = 0;
+void misaligned(const void* p, int bytes, const char* file, int line) {
+    g_stat_misaligned++;
+    if (!g_emu_error) snprintf(g_emu_msg, sizeof(g_emu_msg), "misaligned %d-byte vector access at %p (%s:%d)", bytes, p, file, line);
+    g_emu_error = 716;  // hipErrorMisalignedAddress, reported by the launch's km_check_launch
+}
+
 static void fail(const char* what) {
     snprintf(g_emu_msg, sizeof(g_emu_msg), "%s", what);
     g_emu_error = 719;  // hipErrorLaunchFailure
@@ -243,6 +250,6 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 }  // namespace emu
 
 extern "C" {
-// counters for the tests: launches, workgroups, shuffle reads from lanes that had already exited
-void emu_stats(unsigned long long* out) { out[0] = emu::g_stat_launches; out[1] = emu::g_stat_blocks; out[2] = emu::g_stat_dead_reads; }
+// counters for the tests: launches, workgroups, shuffle reads from lanes that had already exited, misaligned vector accesses
+void emu_stats(unsigned long long* out) { out[0] = emu::g_stat_launches; out[1] = emu::g_stat_blocks; out[2] = emu::g_stat_dead_reads; out[3] = emu::g_stat_misaligned; }
 }

@@ -55,6 +55,11 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
     return hipSuccess;
 }
 
+// ---- alignment of vector accesses (kornia_amd/csrc/km_common.h leaves this empty on the device) --------------------
+namespace emu { void misaligned(const void* p, int bytes, const char* file, int line); }
+#define KM_CHECK_ALIGNED(p, bytes) \
+    do { if (((uintptr_t)(p)) % (bytes)) emu::misaligned((p), (bytes), __FILE__, __LINE__); } while (0)
+
 // ---- vector types -------------------------------------------------------------------------------
 struct __attribute__((aligned(8))) float2 { float x, y; };
 struct __attribute__((aligned(16))) float4 { float x, y, z, w; };

@@ -100,6 +100,51 @@ def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
         emu_lib.set_schedule("forward")
 
 
+def test_odd_storage_offsets_never_reach_the_vector_paths(oracle):
+    """Contiguous tensors whose storage starts 4 (fp32) / 2 (bf16) bytes into an allocation: the launchers must route them to
+    kernels without 8 / 16-byte accesses.  The host build checks the alignment of every vector access (KM_CHECK_ALIGNED) and
+    fails the launch otherwise; results stay bit-identical to the oracle."""
+    import emu_lib
+
+    import kornia_amd as K
+
+    def shifted(shape, dtype=torch.float32, seed=0):
+        n = 1
+        for d in shape:
+            n *= d
+        base = torch.rand(n + 1, generator=torch.Generator().manual_seed(seed)).to(dtype)
+        t = base[1:].view(*shape)
+        assert t.is_contiguous() and t.data_ptr() % 8 != 0
+        return t
+
+    before = emu_lib.stats()["misaligned_vector_accesses"]
+    x = shifted((2, 3, 32, 48))
+    T = K.geometry.transform
+    assert torch.equal(K.gaussian_blur2d(x.cuda(), (5, 5), (1.5, 1.5)), oracle.gaussian_blur2d(x, (5, 5), (1.5, 1.5)))
+    k = torch.rand(1, 5, 5, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(K.filter2d(x.cuda(), k), oracle.filter2d(x, k))
+    assert torch.equal(K.spatial_gradient(x.cuda()), oracle.spatial_gradient(x))
+    assert torch.equal(T.pyrdown(x.cuda()), oracle.pyrdown(x))
+    assert torch.equal(T.pyrup(x.cuda()), oracle.pyrup(x))
+    xg = shifted((2, 3, 32, 48), seed=2).requires_grad_(True)
+    K.gaussian_blur2d(xg.cuda(), (5, 5), (1.5, 1.5)).sum().backward()
+    assert torch.isfinite(xg.grad).all()
+    xb = shifted((2, 3, 32, 48), torch.bfloat16)
+    assert (K.gaussian_blur2d(xb.cuda(), (5, 5), (1.5, 1.5)).float() - oracle.gaussian_blur2d(xb.float(), (5, 5), (1.5, 1.5))).abs().max() <= 1e-2
+    assert (T.pyrdown(xb.cuda()).float() - oracle.pyrdown(xb.float())).abs().max() <= 1e-2
+    big = shifted((1, 2, 40, 64), seed=4)
+    assert torch.equal(K.gaussian_blur2d(big.cuda(), (23, 23), (4.0, 4.0)), oracle.gaussian_blur2d(big, (23, 23), (4.0, 4.0)))  # LDS sliding-window kernel
+    M = torch.tensor([[[1.02, 0.03, 1.5], [-0.02, 0.98, -2.0], [1e-4, 0.0, 1.0]]]).repeat(2, 1, 1)
+    xw = shifted((2, 3, 64, 64), seed=5).requires_grad_(True)
+    go = shifted((2, 3, 64, 64), seed=6)
+    K.warp_perspective(xw.cuda(), M.cuda(), (64, 64)).backward(go.cuda())  # tile-owner scatter reading an odd-offset grad_out
+    gref, _ = oracle.warp_perspective_backward(go, xw.detach(), M, (64, 64))
+    assert torch.allclose(xw.grad, gref, atol=1e-5, rtol=1e-5)
+    f = [torch.full((2,), v) for v in (1.1, 0.9, 1.2, 0.05)]
+    assert torch.isfinite(K.enhance.color_jitter(x.cuda(), *f)).all()
+    assert emu_lib.stats()["misaligned_vector_accesses"] == before
+
+
 @pytest.fixture(autouse=True)
 def _emulated():
     from mode import emulated_device
