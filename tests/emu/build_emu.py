@@ -10,8 +10,11 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "kornia_amd", "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
-OUT = os.path.join(ROOT, "tests", "_build", "emu")
-LIB = os.path.join(ROOT, "tests", "_build", "libkornia_amd_emu.so")
+# KM_EMU_ASAN=1: a second build with AddressSanitizer (run the tests with the runtime preloaded, see tests/emu/asan.sh):
+# every out-of-bounds read or write of a kernel relative to the tensors it was handed is reported
+ASAN = os.environ.get("KM_EMU_ASAN", "") not in ("", "0")
+OUT = os.path.join(ROOT, "tests", "_build", "emu_asan" if ASAN else "emu")
+LIB = os.path.join(ROOT, "tests", "_build", "libkornia_amd_emu_asan.so" if ASAN else "libkornia_amd_emu.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 
 # (file, device-only text, host text): everything else is compiled exactly as shipped.  A substitution that no longer
@@ -31,6 +34,8 @@ def _flags() -> list[str]:
         cpu = open("/proc/cpuinfo").read()
     except OSError:
         cpu = ""
+    if ASAN:
+        flags += ["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"]
     if " fma " in cpu:
         flags.append("-mfma")
     if " f16c " in cpu:
@@ -80,7 +85,7 @@ def build() -> str:
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         # -Bsymbolic: the library's own references (km_set_error, the per-file *_run helpers, the hip* stand-ins) must bind
         # to its own definitions even when the real libkornia_amd.so / libamdhip64.so are already loaded RTLD_GLOBAL
-        res = subprocess.run([CXX, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB, *objs], capture_output=True, text=True)
+        res = subprocess.run([CXX, "-shared", "-fPIC", "-Wl,-Bsymbolic", *(["-fsanitize=address", "-shared-libasan"] if ASAN else []), "-o", LIB, *objs], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stderr[-4000:]}")
     return LIB
