@@ -18,7 +18,6 @@ bytes from SURVEY.md 8(d)) and `cpu_baseline` (the reference's op sequence on th
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
 import sys

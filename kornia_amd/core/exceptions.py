@@ -7,7 +7,7 @@ importable its classes are re-used, so a patched Kornia raises Kornia's own type
 from __future__ import annotations
 
 import sys
-from typing import Any, Optional
+from typing import Any
 
 __all__ = ["BaseError", "DeviceError", "ShapeError", "TypeCheckError", "ValueCheckError"]
 

@@ -12,7 +12,7 @@ What is native here
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Optional, Union
+from typing import Callable, Optional, Union
 
 import torch
 import torch.nn.functional as F

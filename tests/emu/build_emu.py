@@ -13,8 +13,11 @@ EMU = os.path.join(ROOT, "tests", "emu")
 # KM_EMU_ASAN=1: a second build with AddressSanitizer (run the tests with the runtime preloaded, see tests/emu/asan.sh):
 # every out-of-bounds read or write of a kernel relative to the tensors it was handed is reported
 ASAN = os.environ.get("KM_EMU_ASAN", "") not in ("", "0")
-OUT = os.path.join(ROOT, "tests", "_build", "emu_asan" if ASAN else "emu")
-LIB = os.path.join(ROOT, "tests", "_build", "libkornia_amd_emu_asan.so" if ASAN else "libkornia_amd_emu.so")
+# KM_EMU_UBSAN=1: UndefinedBehaviorSanitizer build (signed overflow in index arithmetic, misaligned typed accesses, bad shifts ...)
+UBSAN = os.environ.get("KM_EMU_UBSAN", "") not in ("", "0")
+_TAG = "_asan" if ASAN else ("_ubsan" if UBSAN else "")
+OUT = os.path.join(ROOT, "tests", "_build", "emu" + _TAG)
+LIB = os.path.join(ROOT, "tests", "_build", f"libkornia_amd_emu{_TAG}.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 
 # (file, device-only text, host text): everything else is compiled exactly as shipped.  A substitution that no longer
@@ -22,9 +25,13 @@ CXX = "/opt/rocm/lib/llvm/bin/clang++"
 SUBSTITUTIONS = [
     # dynamic LDS: `extern __shared__` has no host spelling
     ("*", "extern __shared__ __attribute__((aligned(16))) char smem_raw[];", "char* smem_raw = emu::dyn_smem();"),
-    # v_cvt_rpi_i32_f32 = floor(v + 0.5) (CDNA ISA: "round to plus infinity of v + 0.5" as implemented: floor(x + 0.5))
-    ("km_warp_bwd_tiled.hip", 'asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));', "r = (int)floorf(v + 0.5f);"),
+    # v_cvt_rpi_i32_f32 = floor(v + 0.5), saturating, NaN -> 0 (emu_cvt_rpi_i32_f32 in hip/hip_runtime.h)
+    ("km_warp_bwd_tiled.hip", 'asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));', "r = emu_cvt_rpi_i32_f32(v);"),
 ]
+
+
+def _rt(name: str) -> str:
+    return subprocess.run([CXX, f"-print-file-name=libclang_rt.{name}-x86_64.so"], capture_output=True, text=True).stdout.strip()
 
 
 def _flags() -> list[str]:
@@ -36,6 +43,8 @@ def _flags() -> list[str]:
         cpu = ""
     if ASAN:
         flags += ["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"]
+    if UBSAN:
+        flags += ["-fsanitize=undefined", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined", "-g1"]
     if " fma " in cpu:
         flags.append("-mfma")
     if " f16c " in cpu:
@@ -85,7 +94,9 @@ def build() -> str:
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         # -Bsymbolic: the library's own references (km_set_error, the per-file *_run helpers, the hip* stand-ins) must bind
         # to its own definitions even when the real libkornia_amd.so / libamdhip64.so are already loaded RTLD_GLOBAL
-        res = subprocess.run([CXX, "-shared", "-fPIC", "-Wl,-Bsymbolic", *(["-fsanitize=address", "-shared-libasan"] if ASAN else []), "-o", LIB, *objs], capture_output=True, text=True)
+        res = subprocess.run([CXX, "-shared", "-fPIC", "-Wl,-Bsymbolic", *(["-fsanitize=address", "-shared-libasan"] if ASAN else []),
+                              *(["-fsanitize=undefined", "-fno-sanitize=vptr,function", "-shared-libsan", "-Wl,-rpath," + os.path.dirname(_rt("ubsan_standalone"))] if UBSAN else []),
+                              "-o", LIB, *objs], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stderr[-4000:]}")
     return LIB

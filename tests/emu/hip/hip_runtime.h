@@ -81,6 +81,14 @@ inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 inline float __frcp_rn(float x) { return 1.0f / x; }
+// v_cvt_rpi_i32_f32: floor(v + 0.5) with the conversion's hardware semantics (saturation, NaN -> 0)
+inline int emu_cvt_rpi_i32_f32(float v) {
+    if (v != v) return 0;
+    const float f = floorf(v + 0.5f);
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return -2147483647 - 1;
+    return (int)f;
+}
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 

@@ -59,6 +59,8 @@ def test_emulator_schedules_expose_a_missing_barrier():
 
     import build_emu
 
+    if build_emu.UBSAN:
+        pytest.skip("the toy kernels are not linked against the sanitizer runtime")
     build_emu.build()
     so = os.path.join(build_emu.OUT, "libselftest.so")
     subprocess.run([build_emu.CXX, *build_emu._flags(), "-shared", "-Wl,-Bsymbolic", os.path.join(build_emu.EMU, "selftest_kernels.hip"),
