@@ -94,6 +94,8 @@ inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), f
 
 // ---- atomics (one OS thread: plain read-modify-write) ----------------------------------------------
 template <typename T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+// integer atomics wrap around (the hardware adds modulo 2^32; signed overflow would be undefined behaviour on the host)
+inline int atomicAdd(int* p, int v) { const int o = *p; *p = (int)((unsigned)o + (unsigned)v); return o; }
 template <typename T> inline T unsafeAtomicAdd(T* p, T v) { return atomicAdd(p, v); }
 template <typename T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }

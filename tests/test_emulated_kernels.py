@@ -102,6 +102,15 @@ def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
         emu_lib.set_schedule("forward")
 
 
+def test_smoke_entry_point_on_the_host_build(monkeypatch):
+    """__graft_entry__.smoke() (the driver's device check) end to end against the host build of the kernels."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as entry
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    entry.smoke()
+
+
 def test_odd_storage_offsets_never_reach_the_vector_paths(oracle):
     """Contiguous tensors whose storage starts 4 (fp32) / 2 (bf16) bytes into an allocation: the launchers must route them to
     kernels without 8 / 16-byte accesses.  The host build checks the alignment of every vector access (KM_CHECK_ALIGNED) and
