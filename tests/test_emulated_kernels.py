@@ -16,9 +16,9 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 
-# GPU test modules whose cases are small enough for the emulator (full-size configs, fuzzing and HIP-graph capture stay
+# GPU test modules whose cases are small enough for the emulator (full-size configs and HIP-graph capture stay
 # device-only)
-MODULES = os.environ.get("KM_EMU_MODULES", "test_gpu_golden test_gpu_warp test_gpu_filters test_gpu_edge_cases test_gpu_grid_sample test_gpu_color test_gpu_pyramid test_zz_gpu_registration test_zz_gpu_canny").split()
+MODULES = os.environ.get("KM_EMU_MODULES", "test_gpu_golden test_gpu_warp test_gpu_filters test_gpu_edge_cases test_gpu_grid_sample test_gpu_color test_gpu_fuzz test_gpu_pyramid test_zz_gpu_registration test_zz_gpu_canny test_zz_gpu_fuzz_pyramid").split()
 # cases that are about the device itself, not about kernel arithmetic
 SKIP = {
     ("test_gpu_warp", "test_identity_is_exact_and_errors"),      # asserts that host tensors are refused
@@ -32,7 +32,7 @@ for _m in MODULES:
         if _name.endswith("_at_full_size"):  # BASELINE-size property tests: device RNG, minutes of emulation
             continue
         if _name.startswith("test_") and callable(getattr(_mod, _name)) and (_m, _name) not in SKIP:
-            globals()[f"{_name}__{_m.replace('test_zz_gpu_', '').replace('test_gpu_', '')}"] = getattr(_mod, _name)
+            globals()[f"{_name}__{_m.replace('test_zz_gpu_', 'zz_').replace('test_gpu_', '')}"] = getattr(_mod, _name)
 
 
 if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):  # pragma: no cover

@@ -1,0 +1,70 @@
+"""GPU: randomized shapes for the pyramid kernels and the fused registration loss against the oracle (seeded; every case is
+reproducible from its seed).  Runs on the host build of the kernels in the CPU suite (tests/test_emulated_kernels.py, also
+under AddressSanitizer via tests/emu/asan.sh); sorts last because these shapes have not been on a device yet."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BORDERS = ["constant", "reflect", "replicate", "circular"]
+
+
+def T():
+    import kornia_amd as K
+
+    return K.geometry.transform
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_pyramid_shapes_against_oracle(oracle, seed):
+    g = torch.Generator().manual_seed(9000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    B, C = ri(1, 3), ri(1, 4)
+    H, W = ri(3, 140), ri(3, 300)
+    if seed % 3 == 0:  # the register-tiled factor-2 path: even height, width a multiple of 4
+        H, W = 2 * ri(2, 80), 4 * ri(2, 90)
+    border = BORDERS[ri(0, 3)]
+    align = bool(ri(0, 1))
+    factor = [2.0, 2.0, 1.5, 3.0, 2.5][ri(0, 4)]
+    dt = torch.float64 if seed % 5 == 4 else torch.float32
+    x = (torch.rand(B, C, H, W, generator=g) * 3 - 1).to(dt)
+    if int(float(H) / factor) > 0 and int(float(W) // factor) > 0:
+        out = T().pyrdown(x.cuda(), border, align, factor).cpu()
+        assert torch.equal(out, oracle.pyrdown(x, border, align, factor)), (seed, "pyrdown", x.shape, border, align, factor)
+    if H * W <= 20000:
+        up = T().pyrup(x.cuda(), border, align).cpu()
+        assert torch.equal(up, oracle.pyrup(x, border, align)), (seed, "pyrup", x.shape, border, align)
+    size = (ri(1, 150), ri(1, 150))
+    rs = T().resize_bilinear(x.cuda(), size, align).cpu()
+    assert torch.equal(rs, oracle.resize_bilinear(x, size, align)), (seed, "resize", x.shape, size, align)
+    if seed % 2 == 0 and W % 2 == 0:  # the exact x2 path
+        rs2 = T().resize_bilinear(x.cuda(), (2 * H, 2 * W), False).cpu()
+        assert torch.equal(rs2, oracle.resize_bilinear(x, (2 * H, 2 * W), False)), (seed, "resize x2", x.shape)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_masked_loss_against_oracle(oracle, seed):
+    g = torch.Generator().manual_seed(7000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    B, C = ri(1, 3), [1, 3, 2, 4][ri(0, 3)]
+    H, W = ri(4, 90), ri(4, 150)
+    src, dst = torch.rand(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g)
+    amp = [0.02, 0.1, 0.4][ri(0, 2)]
+    Hm = torch.eye(3)[None].repeat(B, 1, 1) + amp * (torch.rand(B, 3, 3, generator=g) - 0.5)
+    if seed % 4 == 3:
+        Hm = Hm[:1]
+    kind = ["l1", "mse"][ri(0, 1)]
+    align = bool(ri(0, 1))
+    thr = [0.9, 0.5, None][ri(0, 2)]
+    ref, gref = oracle.masked_warp_loss(src, dst, Hm, kind, align, True, -1.0 if thr is None else thr)
+    Hg = Hm.cuda().requires_grad_(True)
+    loss = T().masked_warp_loss(src.cuda(), dst.cuda(), Hg, kind, align, threshold=thr)
+    if torch.isnan(ref):
+        assert torch.isnan(loss)
+        return
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item())), (seed, loss.item(), ref.item())
+    assert _rel(Hg.grad.cpu(), gref) < 2e-4, (seed, Hg.grad.cpu(), gref)
