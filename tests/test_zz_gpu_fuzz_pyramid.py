@@ -40,6 +40,14 @@ def test_random_pyramid_shapes_against_oracle(oracle, seed):
     size = (ri(1, 150), ri(1, 150))
     rs = T().resize_bilinear(x.cuda(), size, align).cpu()
     assert torch.equal(rs, oracle.resize_bilinear(x, size, align)), (seed, "resize", x.shape, size, align)
+    if seed % 4 in (0, 1):  # half-precision storage through the same shapes (8-byte / 4-byte vector paths)
+        hd = torch.bfloat16 if seed % 8 < 4 else torch.float16
+        xh = x.float().clamp(0, 1).to(hd)
+        if int(float(H) / factor) > 0 and int(float(W) // factor) > 0:
+            oh = T().pyrdown(xh.cuda(), border, align, factor).cpu()
+            assert oh.dtype == hd and (oh.float() - oracle.pyrdown(xh.float(), border, align, factor)).abs().max().item() <= 2e-2
+        rh = T().resize_bilinear(xh.cuda(), (2 * H, 2 * W) if W % 2 == 0 else size, False).cpu()
+        assert (rh.float() - oracle.resize_bilinear(xh.float(), (2 * H, 2 * W) if W % 2 == 0 else size, False)).abs().max().item() <= 2e-2
     if seed % 2 == 0 and W % 2 == 0:  # the exact x2 path
         rs2 = T().resize_bilinear(x.cuda(), (2 * H, 2 * W), False).cpu()
         assert torch.equal(rs2, oracle.resize_bilinear(x, (2 * H, 2 * W), False)), (seed, "resize x2", x.shape)
