@@ -3,12 +3,11 @@
 Reference behaviour mirrored: kornia/geometry/transform/pyramid.py - pyrdown :409-453, pyrup :460-502, build_pyramid
 :505-560, build_laplacian_pyramid :572-654, PyrDown :50-99, PyrUp :102-148.
 
-  * pyrdown without a gradient to record is ONE launch, km_pyrdown_fwd (csrc/km_pyramid.hip): blur with the binomial
-    kernel and bilinear decimation fused, the blurred image is never written (1.25 e instead of 3.25 e bytes per input
-    element at factor 2);
-  * pyrup without a gradient is km_resize_bilinear_fwd + the register-tiled 5x5 km_filter2d_fwd;
-  * when autograd has to record the call, the differentiable composition of the reference is used: the native
-    filter2d (its backward is native) around F.interpolate, whose backward is ATen's.
+  * pyrdown is ONE launch, km_pyrdown_fwd (csrc/km_pyramid.hip): blur with the binomial kernel and bilinear decimation
+    fused, the blurred image is never written (1.25 e instead of 3.25 e bytes per input element at factor 2);
+  * pyrup is km_resize_bilinear_fwd + the register-tiled 5x5 km_filter2d_fwd;
+  * backward: both ops are linear, nothing of the forward is saved; the adjoint of the resize is ATen's
+    upsample_bilinear2d_backward, the adjoint of the blur is the native km_filter2d_bwd_input.
 """
 from __future__ import annotations
 
@@ -33,28 +32,65 @@ def _get_pyramid_gaussian_kernel() -> torch.Tensor:
     return (r[:, None] * r[None, :] / 256.0)[None]
 
 
-def _records_grad(t: torch.Tensor) -> bool:
-    return torch.is_grad_enabled() and t.requires_grad
-
-
 def _check_border(border_type: str) -> str:
     KORNIA_CHECK(str(border_type).lower() in _VALID_BORDERS, f"Invalid border, {border_type}. Expected one of {_VALID_BORDERS}")
     return str(border_type).lower()
 
 
+class _ResizeBilinearFunction(torch.autograd.Function):
+    """Native forward (km_resize_bilinear_fwd); the adjoint is ATen's upsample_bilinear2d_backward."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, oh: int, ow: int, align: int):
+        xc = x.detach().contiguous()
+        B, C, H, W = xc.shape
+        out = torch.empty(B, C, oh, ow, device=xc.device, dtype=xc.dtype)
+        with N.device_guard(xc.device):
+            N.check(N.lib().km_resize_bilinear_fwd(xc.data_ptr(), out.data_ptr(), B, C, H, W, oh, ow, align, N.dtype_code(xc.dtype),
+                                                   N.stream_ptr(xc.device)), "km_resize_bilinear_fwd")
+        ctx.cfg = ((B, C, H, W), oh, ow, align)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        shape, oh, ow, align = ctx.cfg
+        return torch.ops.aten.upsample_bilinear2d_backward(gy.contiguous(), [oh, ow], list(shape), bool(align), None, None), None, None, None
+
+
+class _PyrDownFunction(torch.autograd.Function):
+    """Fused native forward (km_pyrdown_fwd).  Backward: the resize's adjoint (ATen) followed by the native adjoint of the 5x5
+    blur (km_filter2d_bwd_input) - both linear, so nothing of the forward needs to be kept."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, oh: int, ow: int, border: int, align: int):
+        xc = x.detach().contiguous()
+        B, C, H, W = xc.shape
+        out = torch.empty(B, C, oh, ow, device=xc.device, dtype=xc.dtype)
+        with N.device_guard(xc.device):
+            N.check(N.lib().km_pyrdown_fwd(xc.data_ptr(), out.data_ptr(), B, C, H, W, oh, ow, border, align, N.dtype_code(xc.dtype),
+                                           N.stream_ptr(xc.device)), "km_pyrdown_fwd")
+        ctx.cfg = ((B, C, H, W), oh, ow, border, align, xc.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        (B, C, H, W), oh, ow, border, align, dtype = ctx.cfg
+        g_blur = torch.ops.aten.upsample_bilinear2d_backward(gy.detach().to(dtype).contiguous(), [oh, ow], [B, C, H, W], bool(align), None, None).contiguous()
+        taps = _get_pyramid_gaussian_kernel().to(device=gy.device, dtype=N.compute_dtype(dtype)).contiguous()
+        gx = torch.empty_like(g_blur)
+        with N.device_guard(gy.device):
+            N.check(N.lib().km_filter2d_bwd_input(g_blur.data_ptr(), taps.data_ptr(), gx.data_ptr(), B, C, H, W, 1, 5, 5, border, 1,
+                                                  N.dtype_code(dtype), N.stream_ptr(gy.device)), "km_filter2d_bwd_input")
+        return gx, None, None, None, None
+
+
 def resize_bilinear(input: torch.Tensor, size, align_corners: bool = False) -> torch.Tensor:
-    """``F.interpolate(input, size=size, mode='bilinear', align_corners=align_corners)`` (forward only) as one native launch."""
+    """``F.interpolate(input, size=size, mode='bilinear', align_corners=align_corners)`` with the forward as one native launch."""
     KORNIA_CHECK_SHAPE(input, ["B", "C", "H", "W"])
     N.require_device(input, "input")
     oh, ow = int(size[0]), int(size[1])
     KORNIA_CHECK(oh > 0 and ow > 0, f"Input and output sizes should be greater than 0, got output {oh}x{ow}")
-    x = input.contiguous()
-    B, C, H, W = x.shape
-    out = torch.empty(B, C, oh, ow, device=x.device, dtype=x.dtype)
-    with N.device_guard(x.device):
-        N.check(N.lib().km_resize_bilinear_fwd(x.data_ptr(), out.data_ptr(), B, C, H, W, oh, ow, int(bool(align_corners)),
-                                               N.dtype_code(x.dtype), N.stream_ptr(x.device)), "km_resize_bilinear_fwd")
-    return out
+    return _ResizeBilinearFunction.apply(input, oh, ow, int(bool(align_corners)))
 
 
 def pyrdown(input: torch.Tensor, border_type: str = "reflect", align_corners: bool = False, factor: float = 2.0) -> torch.Tensor:
@@ -63,18 +99,9 @@ def pyrdown(input: torch.Tensor, border_type: str = "reflect", align_corners: bo
     border = _check_border(border_type)
     _, _, height, width = input.shape
     oh, ow = int(float(height) / factor), int(float(width) // factor)
-    if _records_grad(input):
-        x_blur = filter2d(input, _get_pyramid_gaussian_kernel(), border)
-        return F.interpolate(x_blur, size=(oh, ow), mode="bilinear", align_corners=align_corners)
     N.require_device(input, "input")
     KORNIA_CHECK(oh > 0 and ow > 0, f"Input and output sizes should be greater than 0, got output {oh}x{ow}")
-    x = input.contiguous()
-    B, C, H, W = x.shape
-    out = torch.empty(B, C, oh, ow, device=x.device, dtype=x.dtype)
-    with N.device_guard(x.device):
-        N.check(N.lib().km_pyrdown_fwd(x.data_ptr(), out.data_ptr(), B, C, H, W, oh, ow, _BORDER_CODE[border], int(bool(align_corners)),
-                                       N.dtype_code(x.dtype), N.stream_ptr(x.device)), "km_pyrdown_fwd")
-    return out
+    return _PyrDownFunction.apply(input, oh, ow, _BORDER_CODE[border], int(bool(align_corners)))
 
 
 def pyrup(input: torch.Tensor, border_type: str = "reflect", align_corners: bool = False) -> torch.Tensor:
@@ -82,10 +109,7 @@ def pyrup(input: torch.Tensor, border_type: str = "reflect", align_corners: bool
     KORNIA_CHECK_SHAPE(input, ["B", "C", "H", "W"])
     border = _check_border(border_type)
     _, _, height, width = input.shape
-    if _records_grad(input):
-        x_up = F.interpolate(input, size=(height * 2, width * 2), mode="bilinear", align_corners=align_corners)
-    else:
-        x_up = resize_bilinear(input, (height * 2, width * 2), align_corners)
+    x_up = resize_bilinear(input, (height * 2, width * 2), align_corners)
     return filter2d(x_up, _get_pyramid_gaussian_kernel(), border)
 
 
@@ -143,8 +167,6 @@ class PyrUp(nn.Module):
 
 
 def _interpolate_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tensor:
-    if _records_grad(x):
-        return F.interpolate(x, size=size, mode="bilinear", align_corners=align_corners)
     return resize_bilinear(x, size, align_corners)
 
 

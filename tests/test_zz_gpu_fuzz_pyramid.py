@@ -76,3 +76,25 @@ def test_random_masked_loss_against_oracle(oracle, seed):
     loss.backward()
     assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item())), (seed, loss.item(), ref.item())
     assert _rel(Hg.grad.cpu(), gref) < 2e-4, (seed, Hg.grad.cpu(), gref)
+
+
+def test_pyramid_gradcheck_fp64():
+    """pyrdown / pyrup / resize are linear: native forward, adjoint = ATen's resize adjoint + the native blur adjoint."""
+    t = T()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 2, 9, 12, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    for border in ("reflect", "constant", "circular"):
+        assert torch.autograd.gradcheck(lambda v: t.pyrdown(v, border), (x,), eps=1e-6, atol=1e-6, nondet_tol=1e-9)
+        assert torch.autograd.gradcheck(lambda v: t.pyrdown(v, border, True, 1.5), (x,), eps=1e-6, atol=1e-6, nondet_tol=1e-9)
+    xs = torch.rand(1, 1, 5, 6, generator=g, dtype=torch.float64).cuda().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda v: t.pyrup(v, "replicate"), (xs,), eps=1e-6, atol=1e-6, nondet_tol=1e-9)
+    assert torch.autograd.gradcheck(lambda v: t.resize_bilinear(v, (7, 11), True), (xs,), eps=1e-6, atol=1e-6, nondet_tol=1e-9)
+    # fp32: the adjoint identity <A x, y> = <x, A^T y> of the fused forward / composed backward pair
+    a = torch.rand(2, 3, 32, 48, generator=g).cuda().requires_grad_(True)
+    y = torch.rand(2, 3, 16, 24, generator=g).cuda()
+    out = t.pyrdown(a)
+    (out * y).sum().backward()
+    b = torch.rand(2, 3, 32, 48, generator=g).cuda()
+    lhs = (t.pyrdown(b) * y).sum().item()
+    rhs = (b * a.grad).sum().item()
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
