@@ -4,7 +4,15 @@ under AddressSanitizer via tests/emu/asan.sh); sorts last because these shapes h
 import pytest
 import torch
 
+from _util import golden as _golden_np
+
 pytestmark = pytest.mark.gpu
+
+
+def golden(name):
+    return {k: torch.from_numpy(v) for k, v in _golden_np(name).items()}
+
+
 BORDERS = ["constant", "reflect", "replicate", "circular"]
 
 
@@ -98,3 +106,22 @@ def test_pyramid_gradcheck_fp64():
     lhs = (t.pyrdown(b) * y).sum().item()
     rhs = (b * a.grad).sum().item()
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_gradient_path_matches_reference():
+    """Gradient of pyrdown against the reference's autograd result (fused native forward, composed adjoint)."""
+    d = golden("pyramid")
+    x = d["x_even"].cuda().requires_grad_(True)
+    out = T().pyrdown(x)
+    assert torch.allclose(out.detach().cpu(), d["down_even_reflect_0"], atol=1e-6, rtol=0)
+    (out * d["down_even_w"].cuda()).sum().backward()
+    assert torch.allclose(x.grad.cpu(), d["down_even_gx"], atol=1e-5, rtol=1e-5)
+    with torch.no_grad():
+        assert torch.allclose(T().pyrdown(x).cpu(), out.detach().cpu(), atol=1e-6, rtol=0)
+
+
+def test_scale_pyramid_backward():
+    x = golden("scale_pyramid")["x"].cuda().requires_grad_(True)
+    pyr, _, _ = T().ScalePyramid(n_levels=2, min_size=10).cuda()(x)
+    sum(p.sum() for p in pyr).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
