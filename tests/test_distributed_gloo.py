@@ -1,5 +1,6 @@
 """CPU, world_size 2, gloo: the batch-shard / all_gather path used for N > 1 GPUs.  The per-rank op is
-the CPU oracle here (tests only) - the sharding logic is op-agnostic."""
+the CPU oracle (the sharding logic is op-agnostic) and, in the last test, the product's own Python layer running on the host
+build of the kernels (tests/emu) with the oracle as the checker."""
 import os
 import socket
 import sys
@@ -70,3 +71,54 @@ def test_shard_bounds():
     x, m = torch.zeros(8, 3), torch.zeros(1, 3, 3)
     xs, ms, n = shard_batch([x, m, None], 8, 4, 1)
     assert xs.shape[0] == 2 and ms is m and n is None
+
+
+def _worker_product(rank, world, port, batch, out_dir):
+    """Same sharding, but the per-rank op is the product's own Python layer on the host build of the kernels (tests/emu)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from _util import flagship_homographies
+        from mode import emulated_device
+
+        import kornia_amd as K
+        from kornia_amd.distributed import shard_bounds, sharded_apply
+
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand(batch, 3, 32, 40, generator=g)
+        M = flagship_homographies(batch, 32, 40, 32, 40, g, jitter=2.0)
+        with emulated_device():
+            step = lambda xs, Ms: K.gaussian_blur2d(K.warp_perspective(xs, Ms, (32, 40)), (5, 5), (1.5, 1.5))  # noqa: E731
+            got = sharded_apply(step, x, M)
+            assert torch.equal(got, oracle.gaussian_blur2d(oracle.warp_perspective(x, M, (32, 40)), (5, 5), (1.5, 1.5)))
+            pyr = sharded_apply(lambda xs: K.geometry.transform.pyrdown(xs), x)
+            assert torch.equal(pyr, oracle.pyrdown(x))
+            # gradients stay with their shard: each rank back-propagates its own slice, nothing is exchanged
+            lo, hi = shard_bounds(batch, world, rank)
+            xs, Ms = x[lo:hi].clone().requires_grad_(True), M[lo:hi].clone().requires_grad_(True)
+            go = torch.rand(batch, 3, 32, 40, generator=g)[lo:hi]
+            step(xs, Ms).backward(go)
+            gw = oracle.gaussian_blur2d_backward(go, oracle.warp_perspective(x[lo:hi], M[lo:hi], (32, 40)), (5, 5), (1.5, 1.5))
+            gx, _ = oracle.warp_perspective_backward(gw, x[lo:hi], M[lo:hi], (32, 40))
+            assert torch.allclose(xs.grad, gx, atol=1e-5) and Ms.grad.shape == (hi - lo, 3, 3)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_product_ops_world2_gloo(tmp_path):
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("host build of the kernels needs ROCm's clang++")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+
+    build_emu.build()  # once, before the ranks start
+    port = _free_port()
+    mp.spawn(_worker_product, args=(2, port, 5, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
