@@ -125,3 +125,47 @@ def test_scale_pyramid_backward():
     pyr, _, _ = T().ScalePyramid(n_levels=2, min_size=10).cuda()(x)
     sum(p.sum() for p in pyr).backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_reference_own_pyramid_cases():
+    """The cases of the reference's tests/geometry/transform/test_pyramid.py (shapes :27-35, 61-74, 114-139; symmetry :76-81,
+    151-162; blur order :141-149; conventions :41-56, 87-112; the octave-0 sigma example :174-189)."""
+    t = T()
+    z = lambda *s: torch.zeros(*s).cuda()  # noqa: E731
+    assert t.PyrUp()(z(1, 2, 4, 4)).shape == (1, 2, 8, 8) and t.PyrUp()(z(2, 2, 4, 4)).shape == (2, 2, 8, 8)
+    assert t.PyrDown()(z(1, 2, 4, 4)).shape == (1, 2, 2, 2) and t.PyrDown()(z(2, 2, 4, 4)).shape == (2, 2, 2, 2)
+    assert t.PyrDown(factor=3.0)(z(1, 2, 9, 9)).shape == (1, 2, 3, 3)
+    assert t.pyrdown(torch.rand(1, 1, 5, 5).cuda()).shape == (1, 1, 2, 2)  # floor, not OpenCV's ceil
+    blob = z(1, 1, 6, 6)
+    blob[:, :, 2:4, 2:4] = 1.0
+    out = t.PyrDown()(blob).squeeze()
+    assert torch.allclose(out, out.flip(0)) and torch.allclose(out, out.flip(1))
+    x = torch.arange(0.0, 25.0).view(1, 1, 5, 5).cuda()
+    for op in (t.pyrdown, t.pyrup):
+        assert torch.allclose(op(x), op(x, align_corners=False), atol=1e-2) and torch.allclose(op(x), op(x, border_type="reflect"), atol=1e-2)
+        assert not torch.allclose(op(x, align_corners=False), op(x, align_corners=True), atol=1e-2, rtol=1e-2)
+        assert not torch.allclose(op(x, border_type="reflect"), op(x, border_type="constant"), atol=1e-2, rtol=1e-2)
+    # ScalePyramid
+    sp, _, _ = t.ScalePyramid(n_levels=3)(z(1, 1, 32, 32))
+    assert sp[0].shape == (1, 1, 6, 32, 32)
+    sp, _, _ = t.ScalePyramid(n_levels=3)(torch.rand(1, 1, 31, 31, generator=torch.Generator().manual_seed(0)).cuda())
+    for level in sp:
+        for img in level:
+            per_blur = img.squeeze().reshape(3 + 3, -1).max(dim=1)[0]
+            assert torch.argmax(per_blur).item() == 0  # every further blur lowers the maximum
+    blob = z(1, 1, 16, 16)
+    blob[..., 6:10, 6:10] = 1.0
+    sp, _, _ = t.ScalePyramid(n_levels=3)(blob)
+    for level in sp:
+        for img in level:
+            img = img.squeeze()
+            assert torch.allclose(img, img.flip(1), atol=1e-6) and torch.allclose(img, img.flip(2), atol=1e-6)
+    _, sigmas, _ = t.ScalePyramid(n_levels=1, init_sigma=0.25)(torch.rand(1, 1, 32, 32).cuda())
+    assert torch.allclose(sigmas[0][0].cpu(), torch.tensor([0.5, 0.5, 1.0, 2.0]), atol=1e-3)
+    assert torch.allclose(sigmas[1][0].cpu(), torch.tensor([0.25, 0.5, 1.0, 2.0]), atol=1e-3)
+    # build_pyramid / build_laplacian_pyramid level shapes (:202-211, 230-239)
+    img = torch.rand(2, 3, 64, 64).cuda()
+    for levels in (2, 3, 4):
+        for pyr in (t.build_pyramid(img, levels), t.build_laplacian_pyramid(img, levels)):
+            assert len(pyr) == levels
+            assert all(p.shape == (2, 3, 64 // 2**i, 64 // 2**i) for i, p in enumerate(pyr))
