@@ -51,3 +51,25 @@ def test_canny_argument_checks():
     with pytest.raises(BaseError):
         K.filters.canny(x[0])
     assert repr(K.filters.Canny())
+
+
+def test_canny_known_answer_cross():
+    """The 5x5 cross of the reference's tests/filters/test_canny.py:85-137 (magnitude and edges, atol 1e-4), its cardinality and
+    non-contiguous-input cases (:43-50, 77-83)."""
+    import kornia_amd as K
+
+    cross = torch.zeros(1, 1, 5, 5)
+    cross[0, 0, 1:4, 2] = 1.0
+    cross[0, 0, 2, 1:4] = 1.0
+    ring = torch.tensor([[1.2458, 0.9672, 1.2458], [0.9672, 0.0, 0.9672], [1.2458, 0.9672, 1.2458]])
+    want_mag, want_edges = torch.zeros(1, 1, 5, 5), torch.zeros(1, 1, 5, 5)
+    want_mag[0, 0, 1:4, 1:4] = ring
+    want_edges[0, 0, 1:4, 1:4] = (ring > 0).float()
+    mag, edges = K.filters.canny(cross.cuda())
+    assert torch.allclose(mag.cpu(), want_mag, atol=1e-4, rtol=1e-4) and torch.allclose(edges.cpu(), want_edges, atol=1e-4, rtol=1e-4)
+    for batch in (1, 2):
+        m, e = K.filters.canny(torch.rand(batch, 3, 4, 4).cuda())
+        assert m.shape == (batch, 1, 4, 4) and e.shape == (batch, 1, 4, 4)
+    nc = torch.rand(2, 3, 5, 5).cuda().expand(2, -1, -1, -1)[..., ::1]
+    m, e = K.filters.canny(nc.transpose(2, 3))
+    assert m.is_contiguous() and e.shape == (2, 1, 5, 5)
