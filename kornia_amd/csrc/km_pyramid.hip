@@ -21,6 +21,8 @@
 // other factors, align_corners = True) takes the general mapping: one lane per OUTPUT pixel, a wave covers 64 adjacent output columns (for f = 2 its 6 loads per window row
 // cover one contiguous 520-byte span of the input row; the 6x6 window overlaps between neighbours are served by L1/L2),
 // a 256-thread workgroup covers a 64 x 4 output tile, tiles of one image stay on one XCD (km_xcd_remap).
+#include <stdlib.h>
+
 #include "km_regtile.h"
 
 
@@ -232,6 +234,95 @@ __global__ __launch_bounds__(256) void km_pyrdown2_kernel(const KmPyrArgs<T> a) 
     }
 }
 
+// ---- factor-2 fast path, separable evaluation (opt-in: KM_PYRDOWN_ALGO=separable) ---------------------------------------------
+// The binomial kernel is the outer product of [1 4 6 4 1] / 16 with itself: a horizontal 5-tap pass on every loaded row (kept in
+// the rolling window) and a vertical 5-tap pass per output row need 40 multiply-adds per lane and row instead of 100.  The sum
+// is the same real number in another rounding order (<= 2 ulp from the 25-tap chain of filter2d that the default path and the
+// oracle follow), so it stays opt-in until a device measurement says the 25-tap chain is what bounds the kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void km_pyrdown2_sep_kernel(const KmPyrArgs<T> a) {
+    constexpr int K = 5, PD = 2, NV = 4 + 2 * PD;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tbx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t tby = bid % a.tiles_y;
+    const uint32_t bc = bid / a.tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = (int)tbx * 64 + lane;
+    const int r0 = ((int)tby * 4 + wave) * KMP_ROWS;
+    const int H = a.H, W = a.W, border = a.border;
+    if (gx * 4 >= W || r0 >= H) return;
+    const int c0 = gx * 4;
+    const T* img = a.x + (size_t)bc * H * W;
+    T* out = a.y + (size_t)bc * a.oh * a.ow;
+
+    int hl[PD], hr[PD];
+    bool okl[PD], okr[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+        const int il = km_border_map(c0 - PD + q, W, border), ir = km_border_map(c0 + 4 + q, W, border);
+        okl[q] = il >= 0; hl[q] = okl[q] ? il : 0;
+        okr[q] = ir >= 0; hr[q] = okr[q] ? ir : 0;
+    }
+    const float taps[5] = {1.f / 16.f, 4.f / 16.f, 6.f / 16.f, 4.f / 16.f, 1.f / 16.f};
+    float ring[K][4];  // last K input rows after the horizontal pass
+    float prev[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n_rows = (r0 + KMP_ROWS <= H ? KMP_ROWS : H - r0);
+    const int total = n_rows + K - 1;
+    for (int it0 = 0; it0 < total; it0 += K) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int it = it0 + kk;
+            if (it < total) {
+                const int srow = km_border_map(r0 - PD + it, H, border);  // wave-uniform
+                if (srow >= 0) {
+                    const T* rowp = img + (size_t)srow * W;
+                    float v[NV];
+                    float o4[4];
+                    km_ld4(rowp + c0, o4);
+#pragma unroll
+                    for (int q = 0; q < PD; ++q) {
+                        const float vl = (float)km_ld(rowp + hl[q]), vr = (float)km_ld(rowp + hr[q]);
+                        v[q] = okl[q] ? vl : 0.f;
+                        v[PD + 4 + q] = okr[q] ? vr : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[PD + q] = o4[q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int q = 0; q < K; ++q) s = km_fma(taps[q], v[c + q], s);
+                        ring[kk][c] = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ring[kk][c] = 0.f;
+                }
+                if (it >= K - 1) {
+                    const int r = r0 + it - (K - 1);
+                    float cur[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int p = 0; p < K; ++p) s = km_fma(taps[p], ring[(kk + 1 + p) % K][c], s);
+                        cur[c] = kmp_round(s, (const T*)nullptr);
+                    }
+                    if (r & 1) {
+                        const float o0 = 0.5f * (0.5f * prev[0] + 0.5f * prev[1]) + 0.5f * (0.5f * cur[0] + 0.5f * cur[1]);
+                        const float o1 = 0.5f * (0.5f * prev[2] + 0.5f * prev[3]) + 0.5f * (0.5f * cur[2] + 0.5f * cur[3]);
+                        km_st2(out + (size_t)(r >> 1) * a.ow + (c0 >> 1), o0, o1);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) prev[c] = cur[c];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- exact x2 upsampling (the resize leg of pyrup) ------------------------------------------------------------------------
 // align_corners = False, (oh, ow) = (2H, 2W): output columns 4g .. 4g+3 read source columns 2g-1 .. 2g+2 and output rows
 // 2s-1, 2s read source rows s-1, s.  A lane owns 2 source columns (4 output columns, one 16-byte store), a wave walks a strip
@@ -330,6 +421,11 @@ static int kmp_run2(const void* x, void* y, int B, int C, int H, int W, int bord
     KM_REQUIRE(nb < (1ull << 31), "km_pyrdown_fwd: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
+    const char* algo = getenv("KM_PYRDOWN_ALGO");  // "separable": the 5 + 5 tap evaluation (A/B timing, see above)
+    if (algo && algo[0] == 's') {
+        hipLaunchKernelGGL((km_pyrdown2_sep_kernel<T>), dim3(a.nblocks), dim3(256), 0, s, a);
+        return km_check_launch("km_pyrdown_fwd(x2, separable)");
+    }
     hipLaunchKernelGGL((km_pyrdown2_kernel<T>), dim3(a.nblocks), dim3(256), 0, s, a);
     return km_check_launch("km_pyrdown_fwd(x2)");
 }

@@ -23,8 +23,11 @@ for B, C, S in ((64, 3, 512), (256, 3, 512), (16, 1, 1080)):
     fused = bench.event_time_ms(lambda: N.check(lib.km_pyrdown_fwd(x.data_ptr(), y.data_ptr(), B, C, H, W, H // 2, W // 2, 1, 0, 0, stream), "pd"), 10)
     with torch.no_grad():
         two = bench.event_time_ms(lambda: torch.nn.functional.interpolate(K.filter2d(x, kern, "reflect"), size=(H // 2, W // 2), mode="bilinear", align_corners=False), 10)
+    os.environ["KM_PYRDOWN_ALGO"] = "separable"
+    sep = bench.event_time_ms(lambda: N.check(lib.km_pyrdown_fwd(x.data_ptr(), y.data_ptr(), B, C, H, W, H // 2, W // 2, 1, 0, 0, stream), "pd"), 10)
+    del os.environ["KM_PYRDOWN_ALGO"]
     algo = (x.numel() + y.numel()) * e
-    print(f"pyrdown {B}x{C}x{H}x{W} fp32: fused {fused:.4f} ms = {algo / fused / 1e6:.0f} GB/s algorithmic (1.25 e B/px) | native blur + ATen resize {two:.4f} ms | x{two / fused:.2f}")
+    print(f"pyrdown {B}x{C}x{H}x{W} fp32: fused {fused:.4f} ms = {algo / fused / 1e6:.0f} GB/s algorithmic (1.25 e B/px) | separable variant {sep:.4f} ms | native blur + ATen resize {two:.4f} ms | x{two / fused:.2f}")
     up = torch.empty(B, C, H, W, device=dev)
     rs = bench.event_time_ms(lambda: N.check(lib.km_resize_bilinear_fwd(y.data_ptr(), up.data_ptr(), B, C, H // 2, W // 2, H, W, 0, 0, stream), "rs"), 10)
     with torch.no_grad():

@@ -169,3 +169,23 @@ def test_reference_own_pyramid_cases():
         for pyr in (t.build_pyramid(img, levels), t.build_laplacian_pyramid(img, levels)):
             assert len(pyr) == levels
             assert all(p.shape == (2, 3, 64 // 2**i, 64 // 2**i) for i, p in enumerate(pyr))
+
+
+def test_separable_pyrdown_variant(oracle, monkeypatch):
+    """KM_PYRDOWN_ALGO=separable (opt-in, csrc/km_pyramid.hip): the 5 + 5 tap evaluation of the factor-2 path agrees with the
+    25-tap chain to a few ulp, in every border mode and storage dtype; without the variable the default stays bit-identical."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 70, 264, generator=g) * 2 - 0.5
+    for border in BORDERS:
+        ref = oracle.pyrdown(x, border)
+        monkeypatch.setenv("KM_PYRDOWN_ALGO", "separable")
+        sep = T().pyrdown(x.cuda(), border).cpu()
+        monkeypatch.delenv("KM_PYRDOWN_ALGO")
+        assert torch.allclose(sep, ref, atol=1e-6, rtol=0) and not torch.equal(sep, ref)
+        assert torch.equal(T().pyrdown(x.cuda(), border).cpu(), ref)
+    for dt in (torch.bfloat16, torch.float16):
+        xh = x.clamp(0, 1).to(dt)
+        monkeypatch.setenv("KM_PYRDOWN_ALGO", "separable")
+        out = T().pyrdown(xh.cuda()).cpu()
+        monkeypatch.delenv("KM_PYRDOWN_ALGO")
+        assert out.dtype == dt and (out.float() - oracle.pyrdown(xh.float())).abs().max().item() <= 1e-2
