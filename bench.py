@@ -173,6 +173,11 @@ def other_configs(dev):
         with torch.no_grad():
             x = torch.rand(256, 3, 512, 512, device=dev)
             out["pyrdown_256x3x512x512_fused_ms"] = t(lambda: T.pyrdown(x))
+            os.environ["KM_PYRDOWN_ALGO"] = "separable"  # the opt-in 5 + 5 tap evaluation (csrc/km_pyramid.hip), timed for the A/B decision
+            try:
+                out["pyrdown_256x3x512x512_separable_variant_ms"] = t(lambda: T.pyrdown(x))
+            finally:
+                del os.environ["KM_PYRDOWN_ALGO"]
             out["build_pyramid_5_levels_256x3x512x512_ms"] = t(lambda: T.build_pyramid(x, 5))
             del x
         xs = torch.rand(128, 3, 256, 256, device=dev)
