@@ -33,7 +33,10 @@ for B, C, S in ((64, 3, 512), (256, 3, 512), (16, 1, 1080)):
     with torch.no_grad():
         at = bench.event_time_ms(lambda: torch.nn.functional.interpolate(y, size=(H, W), mode="bilinear", align_corners=False), 10)
         pu = bench.event_time_ms(lambda: T.pyrup(y), 10)
-    print(f"resize x2 to {H}x{W}: native {rs:.4f} ms = {(x.numel() + y.numel()) * e / rs / 1e6:.0f} GB/s | ATen {at:.4f} ms ; pyrup (resize + 5x5 blur) {pu:.4f} ms")
+        os.environ["KM_PYRDOWN_ALGO"] = "separable"
+        pus = bench.event_time_ms(lambda: T.pyrup(y), 10)
+        del os.environ["KM_PYRDOWN_ALGO"]
+    print(f"resize x2 to {H}x{W}: native {rs:.4f} ms = {(x.numel() + y.numel()) * e / rs / 1e6:.0f} GB/s | ATen {at:.4f} ms ; pyrup (resize + 5x5 blur) {pu:.4f} ms, with the separable blur {pus:.4f} ms")
     del x, y, up
 xb = torch.rand(64, 3, 512, 512, device=dev).bfloat16()
 yb = torch.empty(64, 3, 256, 256, device=dev, dtype=torch.bfloat16)

@@ -180,8 +180,10 @@ def test_separable_pyrdown_variant(oracle, monkeypatch):
         ref = oracle.pyrdown(x, border)
         monkeypatch.setenv("KM_PYRDOWN_ALGO", "separable")
         sep = T().pyrdown(x.cuda(), border).cpu()
+        up = T().pyrup(x[:, :, :20, :40].cuda(), border).cpu()
         monkeypatch.delenv("KM_PYRDOWN_ALGO")
         assert torch.allclose(sep, ref, atol=1e-6, rtol=0) and not torch.equal(sep, ref)
+        assert torch.allclose(up, oracle.pyrup(x[:, :, :20, :40], border), atol=1e-6, rtol=0)
         assert torch.equal(T().pyrdown(x.cuda(), border).cpu(), ref)
     for dt in (torch.bfloat16, torch.float16):
         xh = x.clamp(0, 1).to(dt)
