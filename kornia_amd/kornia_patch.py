@@ -17,6 +17,7 @@ from typing import Callable
 
 import torch
 
+from . import _native as _N
 from . import enhance as _e
 from . import filters as _f
 from . import geometry as _g
@@ -59,7 +60,7 @@ def _use_native(args, kwargs) -> bool:
     tensors = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor)]
     if not tensors:
         return False
-    return all(t.is_cuda and t.dtype in _SUPPORTED for t in tensors if t.is_floating_point()) and any(t.is_cuda for t in tensors)
+    return all(_N.on_device(t) and t.dtype in _SUPPORTED for t in tensors if t.is_floating_point()) and any(_N.on_device(t) for t in tensors)
 
 
 def _use_native_color(args, kwargs) -> bool:
@@ -97,7 +98,7 @@ def _color_jitter_apply(original: Callable) -> Callable:
     def apply_transform(self, input, params, flags, transform=None):
         keys = ("brightness_factor", "contrast_factor", "saturation_factor", "hue_factor")
         ok = (
-            isinstance(input, torch.Tensor) and input.is_cuda and input.dim() == 4 and input.shape[1] == 3
+            isinstance(input, torch.Tensor) and _N.on_device(input) and input.dim() == 4 and input.shape[1] == 3
             and input.dtype in _COLOR_DTYPES and not (torch.is_grad_enabled() and input.requires_grad)
             and all(isinstance(params.get(k), torch.Tensor) for k in keys)
             and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
@@ -127,7 +128,7 @@ def _registrator_level_loss(original: Callable) -> Callable:
         kind = "l1" if self.loss_fn is F.l1_loss else ("mse" if self.loss_fn is F.mse_loss else None)
         ok = (
             kind is not None and self.warper is hw_mod.HomographyWarper
-            and isinstance(img_src, torch.Tensor) and isinstance(img_dst, torch.Tensor) and img_src.is_cuda and img_dst.is_cuda
+            and isinstance(img_src, torch.Tensor) and isinstance(img_dst, torch.Tensor) and _N.on_device(img_src) and _N.on_device(img_dst)
             and img_src.dim() == 4 and img_src.shape == img_dst.shape and img_src.shape[-1] >= 2 and img_src.dtype in _COLOR_DTYPES
             and img_src.dtype == img_dst.dtype and isinstance(transform_model, torch.Tensor) and transform_model.dim() == 3
             and transform_model.shape[-2:] == (3, 3) and transform_model.shape[0] in (1, img_src.shape[0])
