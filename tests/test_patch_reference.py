@@ -119,3 +119,22 @@ def test_config3_pipeline_parameter_replay_on_the_host_build():
     assert out32.dtype == torch.float32 and torch.allclose(out32, ref, atol=1e-5, rtol=0), (out32 - ref).abs().max()
     err16 = (out16.float() - ref_smooth).abs()
     assert out16.dtype == torch.bfloat16 and err16.mean().item() < 5e-3 and err16.max().item() < 0.15, (err16.mean(), err16.max())
+
+
+def test_reference_own_tests_pass_on_the_native_path():
+    """The reference's own test files for the hot path and its callers (14 files, ~840 cases: known-answer literals, gradchecks,
+    error conventions, modules) with the reference patched, every hot call going to the native kernels (their host build).
+    Deselected, with the reasons in tests/run_reference_tests_on_native.py: the torch.jit.script cases and one unseeded
+    random-tolerance case."""
+    import re
+    import subprocess
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("host build of the kernels needs ROCm's clang++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "run_reference_tests_on_native.py")], capture_output=True, text=True, timeout=1500)
+    text = re.sub(r"\x1b\[[0-9;]*m", "", r.stdout + r.stderr)
+    assert r.returncode == 0, text[-3000:]
+    passed = int(re.search(r"(\d+) passed", text).group(1))
+    launches = int(re.search(r"kernel launches during the run: (\d+)", text).group(1))
+    assert passed >= 820 and " failed" not in text and launches >= 2000, text[-1500:]
