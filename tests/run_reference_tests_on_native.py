@@ -30,6 +30,9 @@ DEFAULT_FILES = [
     "filters/test_blur.py",
     "filters/test_laplacian.py",
     "filters/test_unsharp_mask.py",
+    # the augmentation layer that drives config 3: every 2-D augmentation and the containers
+    "augmentation/test_augmentation.py",
+    "augmentation/container",
 ]
 # not expected to pass on a patched function, for reasons that are not about results:
 KNOWN = [
