@@ -122,7 +122,7 @@ def test_config3_pipeline_parameter_replay_on_the_host_build():
 
 
 def test_reference_own_tests_pass_on_the_native_path():
-    """The reference's own test files for the hot path, its callers and the augmentation layer (20 files, ~1700 cases: known-answer
+    """The reference's own test files for the hot path, its callers and the augmentation layer (23 files, ~2100 cases: known-answer
     literals, gradchecks, error conventions, modules, containers) with the reference patched, every hot call going to the native kernels (their host build).
     Deselected, with the reasons in tests/run_reference_tests_on_native.py: the torch.jit.script cases and one unseeded
     random-tolerance case."""
@@ -137,4 +137,4 @@ def test_reference_own_tests_pass_on_the_native_path():
     assert r.returncode == 0, text[-3000:]
     passed = int(re.search(r"(\d+) passed", text).group(1))
     launches = int(re.search(r"kernel launches during the run: (\d+)", text).group(1))
-    assert passed >= 1650 and " failed" not in text and launches >= 4000, text[-1500:]
+    assert passed >= 2050 and " failed" not in text and launches >= 4000, text[-1500:]
