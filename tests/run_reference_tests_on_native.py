@@ -5,7 +5,7 @@ the reference's `--device=cpu` tensors standing in for device memory.
 
     python tests/run_reference_tests_on_native.py [pytest args / test files relative to /root/reference/tests]
 
-Exit code = pytest's.  tests/test_patch_reference.py::test_reference_own_tests_pass_on_the_native_path runs it as a subprocess."""
+KM_REF_DTYPE=float64 (or float32,float64) selects the reference's --dtype.  Exit code = pytest's.  tests/test_patch_reference.py::test_reference_own_tests_pass_on_the_native_path runs it as a subprocess."""
 import os
 import sys
 
@@ -69,7 +69,7 @@ def main() -> int:
         try:
             before = emu_lib.stats()["launches"]
             rc = pytest.main(["-q", "-p", "no:cacheprovider", f"--rootdir={ref}", "-c", os.path.join(ref, "pyproject.toml"),
-                              *[os.path.join(ref, "tests", f) for f in files], "--device=cpu", "--dtype=float32", "-m", "not slow",
+                              *[os.path.join(ref, "tests", f) for f in files], "--device=cpu", "--dtype=" + os.environ.get("KM_REF_DTYPE", "float32"), "-m", "not slow",
                               *[f"--deselect=tests/{k}" for k in KNOWN], *extra])
             print(f"[native] kernel launches during the run: {emu_lib.stats()['launches'] - before}")
         finally:
