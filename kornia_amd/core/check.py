@@ -17,6 +17,8 @@ __all__ = [
     "KORNIA_CHECK_IS_TENSOR",
     "KORNIA_CHECK_SHAPE",
     "are_checks_enabled",
+    "device_value_checks",
+    "set_device_value_checks",
     "disable_checks",
     "enable_checks",
 ]
@@ -44,6 +46,23 @@ def disable_checks() -> None:
 def enable_checks() -> None:
     global _ENABLED
     _ENABLED = True
+
+
+# Checks on the VALUES of device tensors (e.g. ``(sigma > 0).all()`` in gaussian_blur2d, kornia/filters/gaussian.py:103-108)
+# need a device -> host read that drains the stream.  The native path does not make them by default;
+# KORNIA_AMD_DEVICE_VALUE_CHECKS=1 or set_device_value_checks(True) restores the reference's behaviour.
+_DEVICE_VALUE_CHECKS: bool = os.getenv("KORNIA_AMD_DEVICE_VALUE_CHECKS", "0").lower() in ("1", "true", "yes", "on")
+
+
+def device_value_checks() -> bool:
+    return _DEVICE_VALUE_CHECKS and _ENABLED
+
+
+def set_device_value_checks(enabled: bool) -> bool:
+    """Returns the previous setting."""
+    global _DEVICE_VALUE_CHECKS
+    old, _DEVICE_VALUE_CHECKS = _DEVICE_VALUE_CHECKS, bool(enabled)
+    return old
 
 
 def _fail_shape(x: torch.Tensor, shape: list[str], head: str, msg: Optional[str]):

@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from .. import _native as N
-from ..core.check import KORNIA_CHECK, KORNIA_CHECK_IS_TENSOR, KORNIA_CHECK_SHAPE
+from ..core.check import KORNIA_CHECK, KORNIA_CHECK_IS_TENSOR, KORNIA_CHECK_SHAPE, device_value_checks
 from .filter import filter2d, filter2d_separable
 from .kernels import _check_kernel_size, _unpack_2d_ks, get_gaussian_kernel1d, get_gaussian_kernel2d
 
@@ -20,10 +20,13 @@ def _cached_taps(ky: int, kx: int, sigma: tuple, dtype: torch.dtype, device: tor
     """1-D Gaussian taps for a Python-float sigma: evaluated once on the HOST with the reference's
     own formula (bit-identical to its CPU result) and kept resident on the device, so the steady
     state of ``gaussian_blur2d(x, k, (sy, sx))`` is exactly one kernel launch and no H2D copy."""
-    s = torch.tensor([sigma], dtype=dtype)  # (1,2) on CPU, rounded to the input dtype like gaussian.py:96
-    kernel_x = get_gaussian_kernel1d(kx, s[:, 1].view(1, 1))
-    kernel_y = get_gaussian_kernel1d(ky, s[:, 0].view(1, 1))
-    return kernel_x.to(device), kernel_y.to(device)
+    # built outside inference mode: a cached inference tensor could not be saved for backward by a later
+    # differentiable call with the same key (the reference has no such dependence on call history)
+    with torch.inference_mode(False), torch.no_grad():
+        s = torch.tensor([sigma], dtype=dtype)  # (1,2) on CPU, rounded to the input dtype like gaussian.py:96
+        kernel_x = get_gaussian_kernel1d(kx, s[:, 1].view(1, 1))
+        kernel_y = get_gaussian_kernel1d(ky, s[:, 0].view(1, 1))
+        return kernel_x.to(device), kernel_y.to(device)
 
 
 def _check_host_sigma(sigma: tuple) -> tuple[float, float]:
@@ -35,12 +38,23 @@ def _check_host_sigma(sigma: tuple) -> tuple[float, float]:
 
 
 def _check_tensor_sigma(sigma: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
-    """A tensor sigma goes through the reference's own test, ``(sigma > 0).all()``, which synchronises on a device tensor."""
+    """A tensor sigma is validated where its values live on the host (the reference's ``bool((sigma > 0).all())``,
+    gaussian.py:103-108).  A sigma that is already on the device is NOT read back: that would drain the stream in the
+    middle of an augmentation pipeline; the Gaussian only uses sigma^2, so a negative entry then acts as
+    its magnitude and a zero gives non-finite taps, like any other bad device value.  ``kornia_amd.core.check.set_device_value_checks(True)`` restores the
+    reference's synchronising check (the reference's own tests run with it)."""
     KORNIA_CHECK_IS_TENSOR(sigma)
+    on_host = sigma.device.type == "cpu"
+    sigma_in = sigma
     sigma = sigma.to(device=like.device, dtype=like.dtype)
     KORNIA_CHECK_SHAPE(sigma, ["B", "2"])
     if not torch.compiler.is_compiling():
-        KORNIA_CHECK(bool((sigma > 0).all()), f"sigma must be positive, got {sigma}")
+        if on_host:  # the values are host data: test them there (rounded to the input dtype like the reference does)
+            positive = bool((sigma_in.to(like.dtype) > 0).all())
+            KORNIA_CHECK(positive, "sigma must be positive" if positive else f"sigma must be positive, got {sigma_in}")
+        elif device_value_checks():
+            positive = bool((sigma > 0).all())
+            KORNIA_CHECK(positive, "sigma must be positive" if positive else f"sigma must be positive, got {sigma}")
     return sigma
 
 

@@ -54,7 +54,10 @@ class HomographyWarper(nn.Module):
 
     def precompute_warp_grid(self, src_homo_dst: torch.Tensor) -> None:
         """Remember the homography/ies ((1,3,3), (N,3,3) or (N,1,3,3)) for later ``forward(patch)``."""
-        self._precomputed_homography = src_homo_dst.reshape(-1, 3, 3)
+        # a snapshot, like the reference's warp_grid(self.grid, src_homo_dst) at this point (homography_warper.py:134):
+        # later in-place updates of ``src_homo_dst`` (an optimiser step on a Parameter) must not change forward(patch).
+        # clone() keeps the autograd link, so a differentiable precompute stays differentiable.
+        self._precomputed_homography = src_homo_dst.reshape(-1, 3, 3).clone()
         self._warped_grid_cache = None
 
     def forward(self, patch_src: torch.Tensor, src_homo_dst: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -103,10 +103,16 @@ def _color_jitter_apply(original: Callable) -> Callable:
             and all(isinstance(params.get(k), torch.Tensor) for k in keys)
             and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
         )
+        order = None
+        if ok:
+            order = self._fixed_order if getattr(self, "_fixed_order", None) is not None else params["order"].tolist()
+            order = [int(i) for i in order]
+            # the fused kernel applies each stage at most once per pass and takes ONE contrast mean; the reference accepts any
+            # sequence of ids in 0..3, so anything else stays on its own implementation
+            ok = len(order) <= 4 and all(0 <= i <= 3 for i in order) and len(set(order)) == len(order)
         if not ok:
             return original(self, input, params, flags, transform)
         bf, cf, sf, hf = (params[k].to(input.device) for k in keys)
-        order = self._fixed_order if getattr(self, "_fixed_order", None) is not None else params["order"].tolist()
         enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
         return _e.color_jitter(input, bf, cf, sf, hf, order, enable=enable)
 

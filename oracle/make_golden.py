@@ -409,6 +409,33 @@ def main():
     dcn["mag_gray_k3"], dcn["edges_gray_k3"] = F.canny(xc[:, :1], 0.05, 0.3, (3, 3), (0.8, 0.8))
     save("canny", **dcn)
 
+    # ---- BASELINE config 3 at its own spatial size: AugmentationSequential(RandomAffine, ColorJitter, RandomGaussianBlur) on 224x224 -------
+    # (parity by parameter replay; the GPU box has no reference, so the sampled parameters and the reference's
+    #  fp32 output travel as a fixture.  The image holds bf16-representable values so that the bf16 leg starts from the same pixels.)
+    A = K.augmentation
+    torch.manual_seed(7)
+    aug = A.AugmentationSequential(
+        A.RandomAffine(degrees=15.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=1.0),
+        A.ColorJitter(0.2, 0.2, 0.2, 0.1, p=1.0),
+        A.RandomGaussianBlur((5, 5), (0.1, 2.0), p=1.0),
+    )
+    x3 = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(33)).bfloat16()
+    out3 = aug(x3.float())
+    d3 = {"x_bf16_bits": x3.view(torch.int16).numpy().view(np.uint16), "out": out3}
+    names = ("affine", "jitter", "blur")
+    for name, p3 in zip(names, aug._params):
+        for k, v in p3.data.items():
+            if isinstance(v, torch.Tensor):
+                d3[f"{name}__{k}"] = v
+    d3["affine__matrix"] = aug[0].transform_matrix
+    # stage outputs of the first image (the pipeline re-run module by module with the same parameters) for localising a mismatch
+    st = x3.float()
+    for name, mod, p3 in zip(names, aug, aug._params):
+        st = mod(st, params=p3.data)
+        d3[f"stage_{name}_img0"] = st[0].clone()
+    assert torch.equal(st, out3)
+    save("config3", **d3)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

@@ -46,6 +46,16 @@ def _worker(rank, world, port, batch, out_dir):
         local = sharded_apply(op, x, M, gather=False)
         lo, hi = shard_bounds(batch, world, rank)
         assert torch.equal(local, full[lo:hi])
+        # direct peer exchange and the chunked (compute / exchange overlapped) form give the same tensor
+        assert torch.equal(sharded_apply(op, x, M, mode="p2p"), full)
+        for k in (2, 3):
+            assert torch.equal(sharded_apply(op, x, M, chunks=k), full), f"chunks={k}"
+        # a (batch,) vector is only sliced when it is declared batched; a (3,) fill value with batch == 3 never is by shape
+        scale = torch.arange(1.0, batch + 1.0)
+        got_s = sharded_apply(lambda xs, s: xs * s.view(-1, 1, 1, 1), x, scale, batched=(0, 1))
+        assert torch.equal(got_s, x * scale.view(-1, 1, 1, 1))
+        got_f = sharded_apply(lambda xs, f: xs + f.view(1, -1, 1, 1), x, torch.tensor([1.0, 2.0, 3.0]))
+        assert torch.equal(got_f, x + torch.tensor([1.0, 2.0, 3.0]).view(1, -1, 1, 1))
         # a shared (1,2,3) matrix is replicated, not sliced
         got2 = sharded_apply(lambda xs, A: oracle.warp_affine(xs, A, (32, 40)), x, shared_A)
         assert torch.equal(got2, oracle.warp_affine(x, shared_A, (32, 40)))
@@ -54,7 +64,7 @@ def _worker(rank, world, port, batch, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch", [6, 5])  # even and uneven split
+@pytest.mark.parametrize("batch", [6, 5, 3])  # even and uneven split; 3 = the channel count (a (3,) fill value is not a batch)
 def test_sharded_apply_world2_gloo(tmp_path, batch):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, batch, str(tmp_path)), nprocs=2, join=True)
@@ -71,6 +81,11 @@ def test_shard_bounds():
     x, m = torch.zeros(8, 3), torch.zeros(1, 3, 3)
     xs, ms, n = shard_batch([x, m, None], 8, 4, 1)
     assert xs.shape[0] == 2 and ms is m and n is None
+    v = torch.zeros(8)
+    assert shard_batch([x, v], 8, 4, 1)[1] is v  # one-dimensional tensors are not batched by shape ...
+    assert shard_batch([x, v], 8, 4, 1, batched=(0, 1))[1].shape[0] == 2  # ... only by declaration
+    with pytest.raises(ValueError):
+        shard_batch([x, m], 8, 4, 1, batched=(0, 1))
 
 
 def _worker_product(rank, world, port, batch, out_dir):

@@ -1,0 +1,189 @@
+"""GPU: the HIP path against the CPU oracle (and, for config 3, against a fixture produced by the reference itself)
+at the spatial sizes of BASELINE.json's configs - 512x512 (config 2), 224x224 bf16 (config 3), 1080x1920 (config 4),
+256x256 with a learned homography (config 5).  The batch is cut to what the plain-C oracle finishes in seconds; everything
+that changes with the image size (fp32 coordinate rounding at 2/(n-1), the linspace halves, the 64x64 owner-tile grid of the
+backward, the box of output pixels per tile) is at its BASELINE value.
+
+Tolerances (BASELINE.json north_star: 1e-5 fp32, 1e-2 bf16):
+  forward fp32                       bit-identical to the oracle (torch.equal)
+  grad wrt the image                 |d| <= 1e-5 (fixed-point accumulation, <= 2e-6 * max|grad_out| per DESIGN 4.1)
+  grad wrt the matrix                relative to the largest entry: <= 5e-5 vs the fp32 oracle (same sampling positions)
+  bicubic                            <= 1e-6 (cubic coefficient chain, different accumulation order of 16 taps)
+  homography_warp / warp_grid        <= 1e-5 (the reference's bmm is BLAS-kernel dependent)
+"""
+import math
+
+import pytest
+import torch
+
+from _util import flagship_homographies, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item()
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+def test_config2_512_fwd_bwd_matches_oracle(oracle, smooth):
+    """warp_perspective + gaussian_blur2d, 3x512x512 images, flagship homographies (8 px corner jitter), fwd + bwd."""
+    import kornia_amd as K
+
+    B, S = 3, 512
+    g = torch.Generator().manual_seed(20)
+    if smooth:
+        v, u = torch.meshgrid(torch.linspace(0, 1, S), torch.linspace(0, 1, S), indexing="ij")
+        x = (0.5 + 0.5 * torch.sin(6 * math.pi * u) * torch.cos(4 * math.pi * v)).expand(B, 3, S, S).contiguous()
+    else:
+        x = torch.rand(B, 3, S, S, generator=g)
+    M = flagship_homographies(B, S, S, S, S, g)
+    go = torch.rand(B, 3, S, S, generator=g)
+
+    xg, Mg = x.cuda().requires_grad_(), M.cuda().requires_grad_()
+    w = K.warp_perspective(xg, Mg, (S, S))
+    y = K.gaussian_blur2d(w, (5, 5), (1.5, 1.5))
+    y.backward(go.cuda())
+
+    w_o = oracle.warp_perspective(x, M, (S, S))
+    assert torch.equal(w.detach().cpu(), w_o), "warp forward differs from the oracle at 512x512"
+    y_o = oracle.gaussian_blur2d(w_o, (5, 5), (1.5, 1.5))
+    assert torch.equal(y.detach().cpu(), y_o), "blur forward differs from the oracle at 512x512"
+    gw_o = oracle.gaussian_blur2d_backward(go, w_o, (5, 5), (1.5, 1.5))
+    gx_o, gM_o = oracle.warp_perspective_backward(gw_o, x, M, (S, S))
+    assert (xg.grad.cpu() - gx_o).abs().max().item() <= 1e-5
+    assert _rel(Mg.grad.cpu(), gM_o) <= 5e-5, _rel(Mg.grad.cpu(), gM_o)
+
+
+def test_config2_512_rotated_and_scaled_homographies(oracle):
+    """Same size, matrices far from the identity (rotation, 0.6x - 1.7x scale, strong perspective): the owner-tile boxes of the
+    backward and the wave-uniform fast paths of the forward take their other branches."""
+    import kornia_amd as K
+
+    S = 512
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(4, 3, S, S, generator=g)
+    c = (S - 1) / 2.0
+    Ms = []
+    for ang, sc, px, py in ((0.35, 1.0, 0.0, 0.0), (-1.1, 0.6, 0.0, 0.0), (0.1, 1.7, 2e-4, -1e-4), (2.4, 0.9, -3e-4, 2e-4)):
+        ca, sa = sc * math.cos(ang), sc * math.sin(ang)
+        A = torch.tensor([[ca, -sa, c - ca * c + sa * c], [sa, ca, c - sa * c - ca * c], [px, py, 1.0]])
+        Ms.append(A)
+    M = torch.stack(Ms)
+    go = torch.rand(4, 3, S, S, generator=g)
+    xg, Mg = x.cuda().requires_grad_(), M.cuda().requires_grad_()
+    w = K.warp_perspective(xg, Mg, (S, S))
+    w.backward(go.cuda())
+    assert torch.equal(w.detach().cpu(), oracle.warp_perspective(x, M, (S, S)))
+    gx_o, gM_o = oracle.warp_perspective_backward(go, x, M, (S, S))
+    assert (xg.grad.cpu() - gx_o).abs().max().item() <= 2e-5  # up to ~3 footprints per source pixel at 0.6x
+    assert _rel(Mg.grad.cpu(), gM_o) <= 5e-5
+
+
+def test_config3_224_pipeline_replays_the_reference_fixture():
+    """AugmentationSequential(RandomAffine, ColorJitter, RandomGaussianBlur) at 224x224: the parameters the reference sampled
+    and its fp32 output are the fixture (oracle/make_golden.py, 'config3'); the native pipeline replays them on the device in
+    fp32 (<= 1e-5) and in bf16 (<= 1e-2 against the fp32 reference, BASELINE.json)."""
+    import kornia_amd.augmentation as A
+
+    d = golden("config3")
+    x = torch.from_numpy(d["x_bf16_bits"].view("int16")).view(torch.bfloat16)
+    ref = torch.from_numpy(d["out"])
+    P = {name: {k.split("__", 1)[1]: torch.from_numpy(v) for k, v in d.items() if k.startswith(name + "__")} for name in ("affine", "jitter", "blur")}
+    # the matrix the reference's module built from the same parameters
+    M = A.affine_matrix(P["affine"], torch.device("cuda"))
+    assert torch.allclose(M.cpu(), torch.from_numpy(d["affine__matrix"]), rtol=0, atol=2e-5 * 224)
+
+    x32 = x.float().cuda()
+    s1 = A.random_affine(x32, P["affine"])
+    s2 = A.color_jitter(s1, P["jitter"])
+    s3 = A.random_gaussian_blur(s2, P["blur"])
+    for name, got in (("affine", s1), ("jitter", s2), ("blur", s3)):
+        err = (got[0].cpu() - torch.from_numpy(d[f"stage_{name}_img0"])).abs().max().item()
+        assert err <= 1e-5, f"stage {name}: {err:.2e}"
+    assert (s3.cpu() - ref).abs().max().item() <= 1e-5
+    assert torch.equal(A.apply_sequence(x32, P["affine"], P["jitter"], P["blur"]), s3)
+
+    out16 = A.apply_sequence(x.cuda(), P["affine"], P["jitter"], P["blur"])
+    assert out16.dtype == torch.bfloat16
+    err16 = (out16.float().cpu() - ref).abs()
+    assert err16.max().item() <= 1e-2, err16.max().item()
+
+    # per-sample apply probability (base.py:380-393): a skipped sample passes through untouched, the other is unchanged
+    Pa = dict(P["affine"]); Pa["batch_prob"] = torch.tensor([1.0, 0.0])
+    Pj = dict(P["jitter"]); Pj["batch_prob"] = torch.tensor([0.0, 1.0])
+    Pb = dict(P["blur"]); Pb["batch_prob"] = torch.tensor([0.0, 0.0])
+    m1 = A.random_affine(x32, Pa)
+    assert torch.equal(m1[0], s1[0]) and torch.equal(m1[1], x32[1])
+    m2 = A.color_jitter(s1, Pj)
+    assert torch.equal(m2[1], s2[1]) and torch.equal(m2[0], s1[0])
+    assert torch.equal(A.random_gaussian_blur(s2, Pb), s2)
+
+
+def test_config4_1080p_sobel_and_bicubic_match_oracle(oracle):
+    """SpatialGradient(sobel) bit-identical and bicubic warp_affine <= 1e-6 on 1080x1920 frames (rotation 2 deg about the
+    centre + (3, -2) px)."""
+    import kornia_amd as K
+
+    H, W = 1080, 1920
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(2, 1, H, W, generator=g)
+    assert torch.equal(K.spatial_gradient(x.cuda()).cpu(), oracle.spatial_gradient(x))
+    assert torch.equal(K.sobel(x.cuda()).cpu(), oracle.sobel(x))
+    a = math.radians(2.0)
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    ca, sa = math.cos(a), math.sin(a)
+    A = torch.tensor([[[ca, sa, (1 - ca) * cx - sa * cy + 3.0], [-sa, ca, sa * cx + (1 - ca) * cy - 2.0]]]).repeat(2, 1, 1)
+    for mode, tol in (("bicubic", 1e-6), ("bilinear", 0.0)):
+        got = K.warp_affine(x.cuda(), A.cuda(), (H, W), mode=mode).cpu()
+        exp = oracle.warp_affine(x, A, (H, W), mode=mode)
+        err = (got - exp).abs().max().item()
+        assert err <= tol, f"{mode}: {err:.2e}"
+
+
+def test_config5_256_learned_homography_grad_matches_fp64_oracle(oracle):
+    """homography_warp (normalised dst->src H, align_corners=False) on 4x3x256x256 with an l1 loss: forward <= 1e-5, H.grad
+    against the oracle evaluated in float64 on the same fp32 inputs (the fp32 reference itself is only ~1e-1
+    on this quantity) and against the fp32 oracle that shares the kernel's sampling positions."""
+    import kornia_amd as K
+
+    B, S = 4, 256
+    g = torch.Generator().manual_seed(23)
+    v, u = torch.meshgrid(torch.linspace(0, 1, S), torch.linspace(0, 1, S), indexing="ij")
+    smooth = (0.5 + 0.3 * torch.sin(9.0 * u + 1.0) * torch.cos(7.0 * v) + 0.2 * u * v)[None, None]
+    x = (smooth + 0.02 * torch.rand(B, 3, S, S, generator=g)).contiguous()
+    target = torch.rand(B, 3, S, S, generator=g)
+    Hm = torch.eye(3)[None] + 0.01 * torch.randn(B, 3, 3, generator=g)
+    Hg = Hm.cuda().requires_grad_()
+    y = K.homography_warp(x.cuda(), Hg, (S, S))
+    loss = torch.nn.functional.l1_loss(y, target.cuda())
+    loss.backward()
+    y_o = oracle.homography_warp(x, Hm, (S, S))
+    assert (y.detach().cpu() - y_o).abs().max().item() <= 1e-5
+    go = torch.sign(y_o - target) / y_o.numel()
+    _, gH32 = oracle.homography_warp_backward(go, x, Hm, (S, S))
+    _, gH64 = oracle.homography_warp_backward(go.double(), x.double(), Hm.double(), (S, S))
+    assert _rel(Hg.grad.cpu(), gH32) <= 5e-4, _rel(Hg.grad.cpu(), gH32)
+    assert _rel(Hg.grad.cpu(), gH64) <= 2e-2, _rel(Hg.grad.cpu(), gH64)
+
+
+def test_warp_grid_non_identity_homographies(oracle):
+    """warp_grid (imgwarp.py:323-353) with general homographies, directly on the device: (N,h,w,2) against the oracle's
+    transform_points of the meshgrid, and through HomographyWarper's cached-grid forward."""
+    import kornia_amd as K
+    from kornia_amd.geometry.grid import create_meshgrid
+
+    h, w = 48, 64
+    g = torch.Generator().manual_seed(24)
+    Hm = torch.eye(3)[None] + 0.05 * torch.randn(3, 3, 3, generator=g)
+    Hm[2, 2, 0], Hm[2, 2, 1] = 0.3, -0.2  # a real projective row
+    grid = create_meshgrid(h, w, normalized_coordinates=True)
+    got = K.warp_grid(grid.cuda(), Hm.cuda())
+    exp = oracle.transform_points(Hm, grid.view(1, -1, 2).expand(3, -1, -1).contiguous()).view(3, h, w, 2)
+    assert got.shape == (3, h, w, 2) and (got.cpu() - exp).abs().max().item() <= 1e-5
+    x = torch.rand(3, 2, h, w, generator=g)
+    warper = K.HomographyWarper(h, w)
+    warper.precompute_warp_grid(Hm.cuda())
+    y = warper(x.cuda())
+    assert (y.cpu() - oracle.homography_warp(x, Hm, (h, w))).abs().max().item() <= 1e-5
+    assert (K.grid_sample(x.cuda(), got, align_corners=False).cpu() - oracle.grid_sample(x, exp, align_corners=False)).abs().max().item() <= 1e-5

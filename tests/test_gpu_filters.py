@@ -112,8 +112,18 @@ def test_gaussian_blur2d_backward_and_errors(oracle):
     assert torch.allclose(xg.grad.cpu(), oracle.gaussian_blur2d_backward(go, x, (5, 5), (1.5, 1.5)), atol=1e-5)
     with pytest.raises(BaseError, match="sigma must be positive"):
         K.gaussian_blur2d(x.cuda(), (5, 5), (0.0, 1.0))
-    with pytest.raises(BaseError, match="sigma must be positive"):
-        K.gaussian_blur2d(x.cuda(), (5, 5), torch.tensor([[1.0, -1.0]]).cuda())
+    with pytest.raises(BaseError, match="sigma must be positive"):  # host values are tested on the host
+        K.gaussian_blur2d(x.cuda(), (5, 5), torch.tensor([[1.0, -1.0]]))
+    # values already on the device are not read back by default (no stream drain) ...
+    from kornia_amd.core.check import set_device_value_checks
+
+    K.gaussian_blur2d(x.cuda(), (5, 5), torch.tensor([[1.0, -1.0]]).cuda())
+    old = set_device_value_checks(True)  # ... unless the reference's synchronising check is asked for
+    try:
+        with pytest.raises(BaseError, match="sigma must be positive"):
+            K.gaussian_blur2d(x.cuda(), (5, 5), torch.tensor([[1.0, -1.0]]).cuda())
+    finally:
+        set_device_value_checks(old)
     with pytest.raises(BaseError, match="Kernel size must be"):
         K.gaussian_blur2d(x.cuda(), (4, 5), (1.0, 1.0))
     with pytest.raises(ShapeError):
