@@ -32,6 +32,12 @@ int km_check_launch(const char* what);
 #define KM_CHECK_ALIGNED(p, bytes) ((void)0)
 #endif
 
+// float -> int32 conversion of a value that may be anything: v_cvt_i32_f32 saturates and turns NaN into 0.  (In C++ the cast
+// is undefined for such values; the host build of the kernels substitutes a function with the instruction's semantics.)
+#ifndef KM_F2I
+#define KM_F2I(v) ((int)(v))
+#endif
+
 // ---- storage types ----------------------------------------------------------------------------
 struct km_bf16 {
     uint16_t bits;
@@ -133,6 +139,11 @@ __device__ __forceinline__ void km_ld4u(const km_f16* p, float (&o)[4]) {
 template <typename T>
 __device__ __forceinline__ const T* km_at(const T* base, uint32_t elem_off) {
     return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + elem_off * (uint32_t)sizeof(T));
+}
+
+template <typename T>
+__device__ __forceinline__ T* km_at_mut(T* base, uint32_t elem_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + elem_off * (uint32_t)sizeof(T));
 }
 
 // ---- explicitly fused / explicitly rounded arithmetic ---------------------------------------

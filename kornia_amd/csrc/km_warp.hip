@@ -16,7 +16,7 @@
 // (read grad_out, read src, write grad_src) - see DESIGN.md.
 #include <stdlib.h>
 
-#include "km_sampler.h"
+#include "km_warp_stage.h"
 
 #ifndef KM_ROWS
 #define KM_ROWS 4   // output rows per thread
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Specialised forward for the hot configuration: bilinear + zeros padding (any coordinate mode, any dtype).
+// Bilinear + zeros forward for the cases the lean kernel below does not take (explicit grids, fp64): any coordinate mode, any dtype.
 // Same arithmetic as the generic kernel (bit-identical results) with everything that costs scalar/branch
 // instructions per pixel removed: no padding-mode dispatch, channel count known at compile time for RGB,
 // rows predicated instead of early-exited, (x0, x0+1) fetched with one load when the whole wave samples
@@ -319,6 +319,150 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Specialised forward for the hot configuration: bilinear + zeros padding, fp32 compute (any coordinate mode, fp32 / bf16 /
+// f16 storage).  Same arithmetic as the generic kernel, bit for bit, on the lean front end of km_lean.h: the kernel is bound
+// by the NUMBER of vector instructions per pixel (ablation on MI355X, 256x3x512^2: ALU/issue alone 0.29 ms, loads +0.12,
+// stores +0.11 with the first version's 107 VALU instructions per pixel, 24 of them two IEEE divisions and 9 64-bit address
+// computations), so everything per pixel that is not arithmetic the reference performs is gone:
+//   * row halves of the numerators (m1 v, m4 v, m7 v) come from a per-block LDS table, column halves are per-thread constants;
+//   * both quotients share one refined reciprocal when the block's operands are in the safe range (kml_div_guard's test,
+//     evaluated per row by the threads that fill the table);
+//   * one inside / not-inside decision for the 2 x 2 footprint; all KM_ROWS rows' loads are issued back to back when the
+//     whole wave samples inside the image, with 32-bit offsets from wave-uniform plane bases (saddr form);
+//   * (x0, x0 + 1) come with one 8-byte load; RGB / grey unrolled.
+// A wave instruction covers a KM_PATCH_W x (64 / KM_PATCH_W) patch of the output rather than a 64 x 1 row: under rotation
+// the taps of a 64 x 1 row are spread over up to 64 sin(angle) source rows (one cache line each), a squarer patch keeps
+// them within ~(PW sin + PH cos) rows.  Stores stay KM_PATCH_W * 4-byte contiguous runs.
+template <typename T, int CM, int NC, int ALIGN, bool FAST, int PH = 64 / KM_PATCH_W>  // PH: tile rows between a thread's consecutive rows
+__device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, const float (&m)[9], const float4* s_rv, uint32_t b, int j, int li_base,
+                                                      int i_base) {
+    const KmWarpGeom<float>& g = a.g;
+    const int W = g.W, H = g.H;
+    const int C = (NC > 0) ? NC : g.C;
+    const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
+    const T* __restrict__ src_b = a.src + (size_t)b * C * src_plane;
+    T* __restrict__ dst_b = a.dst + (size_t)b * C * dst_plane;
+    const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2, Wm2 = (float)(W - 2), Hm2 = (float)(H - 2);
+    const KmlHalf cu = kml_col_half<CM>(m, km_base_x<float, CM>(g, j));
+
+    KmlTaps t[KM_ROWS];
+    float xs[KM_ROWS], ys[KM_ROWS];
+    bool inside = true;
+#pragma unroll
+    for (int r = 0; r < KM_ROWS; ++r) {
+        const float4 rv4 = s_rv[li_base + r * PH];
+        KmlHalf rv;
+        rv.a = rv4.x; rv.b = rv4.y; rv.c = rv4.z;
+        KmlPos p;
+        kml_position<CM, FAST>(m, cu, rv, p);
+        xs[r] = kml_unnormalize<ALIGN>(p.gx, Wm1, hW);
+        ys[r] = kml_unnormalize<ALIGN>(p.gy, Hm1, hH);
+        kml_taps(xs[r], ys[r], t[r]);
+        inside = inside & kml_inside(t[r], Wm2, Hm2) & (i_base + r * PH < g.h);  // (no short circuit: straight-line code)
+    }
+    const uint32_t out0 = (uint32_t)i_base * (uint32_t)g.w + (uint32_t)j;
+    if (NC > 0 && __all(inside)) {
+        constexpr int NCC = NC > 0 ? NC : 1;
+        const T* __restrict__ sp[NCC];
+        T* __restrict__ dp[NCC];
+#pragma unroll
+        for (int c = 0; c < NCC; ++c) { sp[c] = src_b + c * src_plane; dp[c] = dst_b + c * dst_plane; }  // wave-uniform plane bases
+        float v[KM_ROWS][NCC][4];
+#pragma unroll
+        for (int r = 0; r < KM_ROWS; ++r) {
+            const uint32_t off = (uint32_t)__mul24((int)t[r].yf, W) + (uint32_t)(int)t[r].xf;
+#pragma unroll
+            for (int c = 0; c < NCC; ++c) {
+                km_ld2(km_at(sp[c], off), v[r][c][0], v[r][c][1]);
+                km_ld2(km_at(sp[c], off + (uint32_t)W), v[r][c][2], v[r][c][3]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < KM_ROWS; ++r) {
+            const float w00 = t[r].wx1 * t[r].wy1, w01 = t[r].wx0 * t[r].wy1, w10 = t[r].wx1 * t[r].wy0, w11 = t[r].wx0 * t[r].wy0;
+            const uint32_t oo = out0 + (uint32_t)(r * PH) * (uint32_t)g.w;
+#pragma unroll
+            for (int c = 0; c < NCC; ++c) {
+                const float acc = km_fma(v[r][c][3], w11, km_fma(v[r][c][2], w10, km_fma(v[r][c][1], w01, km_fma(v[r][c][0], w00, 0.0f))));
+                km_st(km_at_mut(dp[c], oo), acc);
+            }
+        }
+        return;
+    }
+    // some lane touches the border (or the tile hangs over the bottom edge): per row, taps predicated individually
+#pragma unroll
+    for (int r = 0; r < KM_ROWS; ++r) {
+        const bool row_ok = i_base + r * PH < g.h;
+        KmBilin<float> tr;
+        km_bilinear_setup(xs[r], ys[r], W, H, tr);
+        T* __restrict__ out_px = dst_b + (size_t)(row_ok ? i_base + r * PH : 0) * g.w + j;
+        if (__all(tr.b00 && tr.b01 && tr.b10 && tr.b11)) {
+            for (int c = 0; c < C; ++c) {
+                const T* img = src_b + (size_t)c * src_plane;
+                float v00, v01, v10, v11;
+                km_ld2(img + tr.i00, v00, v01);
+                km_ld2(img + tr.i10, v10, v11);
+                const float acc = km_fma(v11, tr.w11, km_fma(v10, tr.w10, km_fma(v01, tr.w01, km_fma(v00, tr.w00, 0.0f))));
+                if (row_ok) km_st(out_px + (size_t)c * dst_plane, acc);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                const T* img = src_b + (size_t)c * src_plane;
+                const float v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01);
+                const float v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
+                float acc = 0;
+                acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
+                acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
+                acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
+                acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+                if (row_ok) km_st(out_px + (size_t)c * dst_plane, acc);
+            }
+        }
+    }
+}
+
+template <typename T, int CM, int NC, int ALIGN>  // NC = 3 / 1: RGB / grey unrolled ; NC = 0: runtime channel loop
+__global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<T> a) {
+    const KmWarpGeom<float>& g = a.g;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+    constexpr int PW = KM_PATCH_W, PH = 64 / PW, WA = 64 / PW;  // patch, waves across the 64-wide tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
+    const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // row inside the tile of this thread's row r: li_base + r * PH
+    const int i_base = (int)ty * KM_TILE_H + li_base;
+    __shared__ float4 s_rv[KM_TILE_H];
+    __shared__ int s_fast;
+
+    float m[9];
+    {
+        const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+    }
+    if (wave == 0) {  // row halves of the numerators + the per-row division guard, combined over the tile's rows
+        bool ok = true;
+        if (lane < KM_TILE_H) {
+            const float v = km_base_y<float, CM>(g, (int)ty * KM_TILE_H + lane);
+            const KmlHalf h = kml_row_half<CM>(m, v);
+            s_rv[lane] = make_float4(h.a, h.b, h.c, 0.f);
+            ok = kml_row_guard<CM>(g, m, v);
+        }
+        const bool all_ok = __all(ok);
+        if (lane == 0) s_fast = all_ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (j >= g.w) return;
+    if (__builtin_amdgcn_readfirstlane(s_fast))
+        km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true>(a, m, s_rv, b, j, li_base, i_base);
+    else
+        km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false>(a, m, s_rv, b, j, li_base, i_base);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,11 +643,157 @@ static bool km_fwd_generic_forced() {
     return v == 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged forward (bilinear + zeros, RGB / grey, fp32 compute): the default for the hot configuration.
+//
+// The gather forward above is bound by the texture-address path, not by HBM or the ALUs: every output pixel issues two
+// 8-byte gathers per channel and a wave-wide gather costs ~30 cycles of address processing whatever it hits
+// (profiles/r02_*: 51 % of the wave time is spent waiting to ISSUE memory instructions; halving the VALU count changed
+// nothing).  Here a 256-thread block owns a KMF_T x KMF_T tile of the OUTPUT, finds the box of source pixels its footprint
+// covers (the four tile corners pushed through the forward's own coordinate arithmetic + 1 px; a projective map sends the
+// tile to a convex quad), copies that box - all channels - into LDS with 16-byte row loads (zeros outside the image, which
+// is what zeros padding samples there: fma(0, w, acc) == acc), and samples from LDS with two-dword reads.  Per pixel the
+// memory pipeline sees 3 dword stores instead of 6 gathers + 3 stores; everything else is the lean front end.
+//   * every pixel checks that its 2 x 2 footprint lies inside the staged box (wave-uniform); a wave where one does not -
+//     a box larger than the LDS tile under strong minification, a tile crossed by the vanishing line, NaN positions - takes
+//     the gather path for its rows, so the result never depends on the box being right;
+//   * same fma chain (nw, ne, sw, se from 0), same positions: bit-identical to the other forwards and to the oracle.
+template <typename T, int CM, int NC, int ALIGN>
+__global__ __launch_bounds__(256) void km_warp_fwd_lds_kernel(const KmWarpArgs<T> a) {
+    const KmWarpGeom<float>& g = a.g;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+    const int tid = threadIdx.x;
+    const int j = (int)tx * KMF_T + (tid % KMF_T);
+    const int li_base = tid / KMF_T;                 // this thread's rows: li_base + r * KMF_RSTEP
+    const int i_base = (int)ty * KMF_T + li_base;
+    __shared__ float4 s_rv[KMF_T];
+    __shared__ int s_info[8];
+    __shared__ __attribute__((aligned(16))) float s_src[KMF_ROWS * NC * KMF_PITCH];  // [row][channel][x]
+
+    float m[9];
+    {
+        const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+    }
+    kmf_tile_setup<CM, ALIGN>(g, m, (int)tx * KMF_T, (int)ty * KMF_T, s_rv, s_info, false);
+    __syncthreads();
+    const KmfBox bx = kmf_read_box(s_info);
+    if (!bx.staged) {  // block-uniform
+        if (j >= g.w) return;
+        if (bx.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
+        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
+        return;
+    }
+    const int W = g.W, H = g.H;
+    const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
+    const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
+    const T* __restrict__ src_b = a.src + (size_t)b * NC * src_plane;
+    T* __restrict__ dst_b = a.dst + (size_t)b * NC * dst_plane;
+    float oob[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) oob[c] = 0.f;
+    kmf_stage_box<T, NC>(src_b, src_plane, W, H, bx, s_src, oob);
+    __syncthreads();
+    if (j >= g.w) return;
+
+    // ---- sample ----
+    const KmlHalf cu = kml_col_half<CM>(m, km_base_x<float, CM>(g, j));
+    KmlTaps t[KMF_RPT];
+    bool inbox = true;
+#pragma unroll
+    for (int r = 0; r < KMF_RPT; ++r) {
+        const float4 rv4 = s_rv[li_base + r * KMF_RSTEP];
+        KmlHalf rv;
+        rv.a = rv4.x; rv.b = rv4.y; rv.c = rv4.z;
+        KmlPos p;
+        if (bx.fast) kml_position<CM, true>(m, cu, rv, p);
+        else kml_position<CM, false>(m, cu, rv, p);
+        kml_taps(kml_unnormalize<ALIGN>(p.gx, Wm1, hW), kml_unnormalize<ALIGN>(p.gy, Hm1, hH), t[r]);
+        // (rows of the tile below the image bottom are not stored: no constraint)
+        inbox = inbox & (kmf_in_box(t[r], bx) | (i_base + r * KMF_RSTEP >= g.h));
+    }
+    if (!__all(inbox)) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
+        if (bx.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
+        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
+        return;
+    }
+    T* __restrict__ dp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dp[c] = dst_b + c * dst_plane;
+    const uint32_t out0 = (uint32_t)i_base * (uint32_t)g.w + (uint32_t)j;
+#pragma unroll
+    for (int r = 0; r < KMF_RPT; ++r) {
+        const bool row_ok = i_base + r * KMF_RSTEP < g.h;
+        const float* q0 = kmf_tap_ptr<NC>(s_src, t[r], bx, row_ok);  // rows below the image bottom read the box origin (never stored)
+        const float* q1 = q0 + NC * KMF_PITCH;
+        const float w00 = t[r].wx1 * t[r].wy1, w01 = t[r].wx0 * t[r].wy1, w10 = t[r].wx1 * t[r].wy0, w11 = t[r].wx0 * t[r].wy0;
+        const uint32_t oo = out0 + (uint32_t)(r * KMF_RSTEP) * (uint32_t)g.w;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float v00 = q0[c * KMF_PITCH], v01 = q0[c * KMF_PITCH + 1], v10 = q1[c * KMF_PITCH], v11 = q1[c * KMF_PITCH + 1];
+            const float acc = km_fma(v11, w11, km_fma(v10, w10, km_fma(v01, w01, km_fma(v00, w00, 0.0f))));
+            if (row_ok) km_st(km_at_mut(dp[c], oo), acc);
+        }
+    }
+}
+
+// the specialised forward: bilinear + zeros, fp32 compute, 32-bit byte offsets inside a plane, 24-bit row / column counts
+template <typename T, int CM>
+static bool km_fwd_lean_ok(const KmWarpArgs<T>& a) {
+    if (CM == KM_COORD_GRID || sizeof(typename KmTraits<T>::R) != sizeof(float)) return false;
+    if (a.g.pad != KM_PAD_ZEROS || a.g.W < 2 || km_fwd_generic_forced()) return false;
+    return (uint64_t)a.g.H * a.g.W * 4 < (1ull << 32) && (uint64_t)a.g.h * a.g.w * 4 < (1ull << 32) && a.g.W < (1 << 23) && a.g.H < (1 << 23);
+}
+template <typename T, int CM, int NC>
+static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
+    if (a.g.align)
+        hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
+}
+static int km_fwd_algo() {  // KM_WARP_FWD_ALGO: "generic" | "lds" (LDS-staged kernel, A/B timing) | default: the lean gather kernel
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("KM_WARP_FWD_ALGO"); v = (e && e[0] == 'l') ? 1 : 0; }
+    return v;
+}
+template <typename T, int CM, int NC>
+static void km_warp_fwd_lds_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
+    const uint32_t tiles_x = (uint32_t)((a.g.w + KMF_T - 1) / KMF_T), tiles_y = (uint32_t)((a.g.h + KMF_T - 1) / KMF_T);
+    KmWarpArgs<T> b = a;
+    b.tiles_x = tiles_x; b.tiles_y = tiles_y; b.nblocks = tiles_x * tiles_y * (uint32_t)a.g.B;
+    if (a.g.align)
+        hipLaunchKernelGGL((km_warp_fwd_lds_kernel<T, CM, NC, 1>), dim3(b.nblocks), dim3(256), 0, s, b);
+    else
+        hipLaunchKernelGGL((km_warp_fwd_lds_kernel<T, CM, NC, 0>), dim3(b.nblocks), dim3(256), 0, s, b);
+}
+template <typename T, int CM>
+static void km_warp_fwd_lean_launch(const KmWarpArgs<T>& a, hipStream_t s) {
+    if constexpr (CM != KM_COORD_GRID && sizeof(typename KmTraits<T>::R) == sizeof(float)) {  // (never instantiated otherwise)
+        // LDS staging: RGB / grey, rows of whole 4-element chunks (16-byte loads for fp32, 8-byte for the 16-bit types)
+        const uint64_t nb = (uint64_t)((a.g.w + KMF_T - 1) / KMF_T) * (uint64_t)((a.g.h + KMF_T - 1) / KMF_T) * (uint64_t)a.g.B;
+        if ((a.g.C == 3 || a.g.C == 1) && (a.g.W & 3) == 0 && ((uintptr_t)a.src % (4 * sizeof(T))) == 0 && nb < (1ull << 31) && km_fwd_algo() == 1) {
+            if (a.g.C == 3) km_warp_fwd_lds_launch_nc<T, CM, 3>(a, s);
+            else km_warp_fwd_lds_launch_nc<T, CM, 1>(a, s);
+            return;
+        }
+        if (a.g.C == 3) km_warp_fwd_lean_launch_nc<T, CM, 3>(a, s);
+        else if (a.g.C == 1) km_warp_fwd_lean_launch_nc<T, CM, 1>(a, s);
+        else km_warp_fwd_lean_launch_nc<T, CM, 0>(a, s);
+    }
+}
+
 template <typename T, int CM, int INTERP>
 static int km_warp_launch(bool bwd, const KmWarpArgs<T>& a, hipStream_t s) {
     if (bwd)
         hipLaunchKernelGGL((km_warp_bwd_kernel<T, CM, INTERP>), dim3(a.nblocks), dim3(256), 0, s, a);
-    else if (INTERP == KM_INTERP_BILINEAR && a.g.pad == KM_PAD_ZEROS && a.g.W >= 2 && !km_fwd_generic_forced()) {
+    else if (INTERP == KM_INTERP_BILINEAR && km_fwd_lean_ok<T, CM>(a)) {
+        km_warp_fwd_lean_launch<T, CM>(a, s);
+    } else if (INTERP == KM_INTERP_BILINEAR && a.g.pad == KM_PAD_ZEROS && a.g.W >= 2 && !km_fwd_generic_forced()) {
         if (a.g.C == 3)
             hipLaunchKernelGGL((km_warp_fwd_bz_kernel<T, CM, 3>), dim3(a.nblocks), dim3(256), 0, s, a);
         else if (a.g.C == 1)

@@ -26,7 +26,7 @@
 // the 12 quantise+atomic pairs), not HBM bound: see DESIGN.md for the counters.
 #include <stdlib.h>
 
-#include "km_sampler.h"
+#include "km_lean.h"
 
 #ifndef KMT_TW
 #define KMT_TW 64           // tile width  (the flush maps lane -> column: keep 64)
@@ -39,9 +39,10 @@
 #endif
 #define KMT_NW (KMT_NT / 64)
 #define KMT_CC 3            // channels per pass
-#define KMT_TAB 128         // capacity of the per-band coordinate tables (float4 entries)
+#define KMT_BAND_W 128      // output columns per band = capacity of the column table (float4 entries)
+#define KMT_TAB 128         // output rows per band = capacity of the row table (float4 entries)
 #define KMT_PLANE (KMT_TH * KMT_TW)
-#define KMT_LDS_BYTES (2 * KMT_TAB * 16 + KMT_CC * KMT_PLANE * 4)
+#define KMT_LDS_BYTES ((KMT_BAND_W + KMT_TAB) * 16 + KMT_CC * KMT_PLANE * 4)
 
 template <typename T>
 struct KmWarpTiledArgs {
@@ -218,14 +219,14 @@ __device__ __forceinline__ int kmt_uniform(int v) { return __builtin_amdgcn_read
 
 // fixed-point quantisation of one contribution: floor(v + 0.5) in ONE instruction (v_cvt_rpi_i32_f32) instead of
 // v_rndne_f32 + v_cvt_i32_f32.  Ties round up instead of to even; both are exact integers of the same
-// magnitude bound, and the result stays independent of the order of accumulation.
+// magnitude bound, and the result stays independent of the order of accumulation.  NaN -> 0.
 __device__ __forceinline__ int kmt_quant(float v) {
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
 
-// per-thread walk over the box in steps of KMT_NT elements: (qi, qj) of element e + KMT_NT from those of e
+// per-thread walk over a band in steps of KMT_NT elements: (qi, qj) of element e + KMT_NT from those of e
 __device__ __forceinline__ void kmt_advance(int& qi, int& qj, int di, int dj, int bw) {
     qj += dj;
     qi += di;
@@ -234,166 +235,382 @@ __device__ __forceinline__ void kmt_advance(int& qi, int& qj, int di, int dj, in
     qi = carry ? qi + 1 : qi;
 }
 
-// Column / row halves of the coordinate numerators, tabulated once per block so that a pixel needs adds only.
-// The products are the very ones km_gen_coord forms (m0*u, m1*v, ...), so the sums round identically.
-template <int CM>
-__device__ __forceinline__ float4 kmt_col_entry(const float (&m)[9], float u) {
-    return make_float4(m[0] * u, m[3] * u, m[6] * u, 0.f);  // homography mode: u*m0 - multiplication commutes bit for bit
-}
-template <int CM>
-__device__ __forceinline__ float4 kmt_row_entry(const float (&m)[9], float v) {
-    if (CM == KM_COORD_HOMOGRAPHY) return make_float4(v, 0.f, 0.f, 0.f);  // fma(v, m1, u*m0) needs v itself
-    return make_float4(m[1] * v, m[4] * v, m[7] * v, 0.f);
-}
-// normalised sampling coordinate of one pixel: same rounding sequence as km_gen_coord (km_sampler.h)
-template <int CM>
-__device__ __forceinline__ void kmt_coord(const float (&m)[9], const float4 cu, const float4 rv, float& gx, float& gy) {
-    if (CM == KM_COORD_PERSPECTIVE) {
-        const float den = (cu.z + rv.z) + m[8];
-        gx = ((cu.x + rv.x) + m[2]) / den;
-        gy = ((cu.y + rv.y) + m[5]) / den;
-    } else if (CM == KM_COORD_AFFINE) {
-        gx = (cu.x + rv.x) + m[2];
-        gy = (cu.y + rv.y) + m[5];
-    } else {
-        const float v = rv.x;
-        const float X = km_fma(v, m[1], cu.x) + m[2];
-        const float Y = km_fma(v, m[4], cu.y) + m[5];
-        const float Z = km_fma(v, m[7], cu.z) + m[8];
-        const float eps = 1e-8f;
-        const float s = (km_fabs(Z) > eps) ? 1.0f / (Z + eps) : 1.0f;
-        gx = s * X;
-        gy = s * Y;
-    }
+// Column / row halves of the coordinate numerators, tabulated once per band so that a pixel needs additions only
+// (kml_col_half / kml_row_half: the very products km_gen_coord forms, so the sums round identically).
+__device__ __forceinline__ KmlHalf kmt_half(const float4 e) {
+    KmlHalf h;
+    h.a = e.x; h.b = e.y; h.c = e.z;
+    return h;
 }
 
-// one output pixel of the scatter pass.  Branch-free up to the (exec-masked) atomics: every load is unconditional
-// so that the loads of the pixels processed back to back can be in flight together.
-// grad_out of one output pixel, all channels of the chunk (issued for every pixel of an unrolled group before any is used)
-template <typename T>
-__device__ __forceinline__ void kmt_load_go(const KmWarpGeom<float>& g, int qi, int qj, int j0, int ib, const T* const (&gout_c)[KMT_CC],
-                                           float (&go)[KMT_CC]) {
-    const uint32_t off = (uint32_t)(ib + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);  // the host guarantees 4 * h * w < 2^32
+// grad_out of one output pixel, all CC channels (issued for every pixel of an unrolled group before any is used)
+template <typename T, int CC>
+__device__ __forceinline__ void kmt_load_go(const T* const (&gout_c)[CC], uint32_t off, float (&go)[CC]) {
 #pragma unroll
-    for (int c = 0; c < KMT_CC; ++c) go[c] = (float)km_ld(km_at(gout_c[c], off));  // channels >= cc alias channel cc-1 (never used)
+    for (int c = 0; c < CC; ++c) go[c] = (float)km_ld(km_at(gout_c[c], off));
 }
 
-template <typename T, int CM, int ALIGN>
-__device__ __forceinline__ void kmt_scatter_q(const KmWarpGeom<float>& g, const float (&m)[9], int qi, int qj, bool valid, const float (&go)[KMT_CC],
-                                             const float4* s_u4, const float4* s_v4, int* s_acc, bool finite, float scale,
-                                             int cc, int X0, int TWc, int Y0, int THc, uint32_t& seen_bits) {
-    typedef float R;
+// One output pixel of the scatter pass: position (the forward's own instruction sequence, km_lean.h), footprint, and the
+// four contributions w * grad_out[q, c] to the taps that fall inside the tile.  FIXED: int32 fixed-point LDS accumulators;
+// otherwise IEEE float LDS atomics (slow; non-finite gradients, vanishing-line tiles, extreme magnification).
+template <int CM, int ALIGN, int CC, bool FAST, bool FIXED>
+__device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, bool valid, const float (&go)[CC], int* s_acc,
+                                          float scale, float Wm1, float hW, float Hm1, float hH, uint32_t X0, uint32_t TWc, uint32_t Y0,
+                                          uint32_t THc, uint32_t& seen_bits) {
     // the fixed-point scale was chosen for |grad_out| <= bound: remember the largest magnitude seen, as an integer
     // (sign cleared, IEEE bit patterns order like unsigned integers and NaN / inf sort above every finite value)
-    {
+    if (FIXED) {
         uint32_t mb = __float_as_uint(go[0]) & 0x7fffffffu;
 #pragma unroll
-        for (int c = 1; c < KMT_CC; ++c) mb = max(mb, __float_as_uint(go[c]) & 0x7fffffffu);
+        for (int c = 1; c < CC; ++c) mb = max(mb, __float_as_uint(go[c]) & 0x7fffffffu);
         seen_bits = max(seen_bits, mb);
     }
-    R gx, gy;
-    kmt_coord<CM>(m, s_u4[qj], s_v4[qi], gx, gy);
-    R mx, my;
-    const R x = km_unnormalize(gx, g.W, ALIGN, mx);
-    const R y = km_unnormalize(gy, g.H, ALIGN, my);
+    KmlPos p;
+    kml_position<CM, FAST>(m, cu, rv, p);
+    const float x = kml_unnormalize<ALIGN>(p.gx, Wm1, hW);
+    const float y = kml_unnormalize<ALIGN>(p.gy, Hm1, hH);
     // weights: the forward's own expressions ((x0 + 1) - x, x - x0), so grad_src = W^T grad_out for the very W it applied
-    const R xf = km_floor(x), yf = km_floor(y);
-    const R wx0 = x - xf, wx1 = (xf + 1) - x, wy0 = y - yf, wy1 = (yf + 1) - y;
-    // tile-relative tap position.  A tap inside the tile is inside the image, so the in-tile test is the whole
-    // predicate; clamping in float first sends NaN / huge coordinates (and the padding lanes) outside the tile
-    // (v_med3_f32 returns the smallest operand when one is NaN: -2, outside every tile)
-    const int ux = (int)__builtin_amdgcn_fmed3f(xf, (R)-2, (R)g.W) - X0;
-    const int uy = valid ? (int)__builtin_amdgcn_fmed3f(yf, (R)-2, (R)g.H) - Y0 : (1 << 20);
-    const bool in_x0 = (uint32_t)ux < (uint32_t)TWc, in_x1 = (uint32_t)(ux + 1) < (uint32_t)TWc;
-    const bool in_y0 = (uint32_t)uy < (uint32_t)THc, in_y1 = (uint32_t)(uy + 1) < (uint32_t)THc;
-    const bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;
-    const int l00 = uy * KMT_TW + ux;
-    // tap-outer order: one exec-mask region per tap (4 per pixel) instead of one per atomic (4 * C)
-    if (finite) {
-        // scale = 2^k: (wx * wy) * scale == wx * (wy * scale) bit for bit
-        const R wy0s = wy0 * scale, wy1s = wy1 * scale;
-        const R w00 = wx1 * wy1s, w01 = wx0 * wy1s, w10 = wx1 * wy0s, w11 = wx0 * wy0s;
+    KmlTaps t;
+    kml_taps(x, y, t);
+    // Tile-relative tap position in unsigned arithmetic.  A tap inside the tile is inside the image, so the in-tile test is
+    // the whole predicate: positions far outside saturate in the conversion and wrap to values >= 2^30, a NaN position
+    // converts to 0 - its weights are NaN, which the quantisation turns into 0 (FIXED) or which is excluded below (float path).
+    const uint32_t ux = (uint32_t)KM_F2I(t.xf) - X0;
+    const uint32_t uy = valid ? (uint32_t)KM_F2I(t.yf) - Y0 : 0x40000000u;
+    const bool in_x0 = ux < TWc, in_x1 = (ux + 1u) < TWc;
+    const bool in_y0 = uy < THc, in_y1 = (uy + 1u) < THc;
+    bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;  // (lane masks: s_and_b64)
+    const int l00 = (int)(uy * (uint32_t)KMT_TW + ux);
+    if (FIXED) {
+        // scale = 2^k: (wx * wy) * scale == wx * (wy * scale) bit for bit.  Tap-outer order: one exec-mask region per tap.
+        const float wy0s = t.wy0 * scale, wy1s = t.wy1 * scale;
+        const float w00 = t.wx1 * wy1s, w01 = t.wx0 * wy1s, w10 = t.wx1 * wy0s, w11 = t.wx0 * wy0s;
         int* accp = s_acc + l00;
         if (t00) {
 #pragma unroll
-            for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * KMT_PLANE, kmt_quant(w00 * go[c]));
+            for (int c = 0; c < CC; ++c) atomicAdd(accp + c * KMT_PLANE, kmt_quant(w00 * go[c]));
         }
         if (t01) {
 #pragma unroll
-            for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * KMT_PLANE + 1, kmt_quant(w01 * go[c]));
+            for (int c = 0; c < CC; ++c) atomicAdd(accp + c * KMT_PLANE + 1, kmt_quant(w01 * go[c]));
         }
         if (t10) {
 #pragma unroll
-            for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * KMT_PLANE + KMT_TW, kmt_quant(w10 * go[c]));
+            for (int c = 0; c < CC; ++c) atomicAdd(accp + c * KMT_PLANE + KMT_TW, kmt_quant(w10 * go[c]));
         }
         if (t11) {
 #pragma unroll
-            for (int c = 0; c < KMT_CC; ++c)
-                if (c < cc) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, kmt_quant(w11 * go[c]));
+            for (int c = 0; c < CC; ++c) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, kmt_quant(w11 * go[c]));
         }
     } else {
-        // inf / NaN in grad_out, vanishing-line tiles, extreme magnification: float LDS atomics
-        const R w00 = wx1 * wy1, w01 = wx0 * wy1, w10 = wx1 * wy0, w11 = wx0 * wy0;
+        const bool num = (x == x) & (y == y);  // a NaN position touches nothing (ATen: the converted index is out of bounds)
+        t00 = t00 && num; t01 = t01 && num; t10 = t10 && num; t11 = t11 && num;
+        const float w00 = t.wx1 * t.wy1, w01 = t.wx0 * t.wy1, w10 = t.wx1 * t.wy0, w11 = t.wx0 * t.wy0;
         float* accp = (float*)s_acc + l00;
 #pragma unroll
-        for (int c = 0; c < KMT_CC; ++c) {
-            if (c < cc) {
-                if (t00) atomicAdd(accp + c * KMT_PLANE, w00 * go[c]);
-                if (t01) atomicAdd(accp + c * KMT_PLANE + 1, w01 * go[c]);
-                if (t10) atomicAdd(accp + c * KMT_PLANE + KMT_TW, w10 * go[c]);
-                if (t11) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, w11 * go[c]);
+        for (int c = 0; c < CC; ++c) {
+            if (t00) atomicAdd(accp + c * KMT_PLANE, w00 * go[c]);
+            if (t01) atomicAdd(accp + c * KMT_PLANE + 1, w01 * go[c]);
+            if (t10) atomicAdd(accp + c * KMT_PLANE + KMT_TW, w10 * go[c]);
+            if (t11) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, w11 * go[c]);
+        }
+    }
+}
+
+struct KmtBand {
+    int jb, bwb;   // first output column of the band, its width (<= KMT_BAND_W)
+    int ib, nrows; // first output row of the band, its height (<= KMT_TAB)
+};
+
+// One band of the box, walked as a linear list of pixels: element e = base + tid, (row, column) = (e / bwb, e % bwb).  Lane
+// utilisation is bwb * nrows / (a multiple of KMT_NT) whatever the shape of the box, consecutive lanes read consecutive
+// grad_out pixels.  Two pixels in flight per thread (FIXED: the IEEE float path is not worth unrolling).
+template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED>
+__device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, const float (&m)[9], const KmtBand& bd, const T* const (&gout_c)[CC],
+                                                 const float4* s_u4, const float4* s_v4, int* s_acc, float scale, uint32_t X0, uint32_t TWc,
+                                                 uint32_t Y0, uint32_t THc, uint32_t& seen_bits) {
+    const int tid = threadIdx.x;
+    const float Wm1 = (float)(g.W - 1), Hm1 = (float)(g.H - 1), hW = (float)g.W / 2, hH = (float)g.H / 2;
+    const int bwb = bd.bwb;
+    const int di = kmt_uniform(KMT_NT / bwb), dj = kmt_uniform(KMT_NT % bwb);  // element e + KMT_NT is di rows, dj columns on
+    const int nq = bwb * bd.nrows;
+    // element e = base + tid  (tid < 2^24: the float quotient is off by at most one)
+    int qi = (int)(((float)tid + 0.5f) / (float)bwb), qj = tid - qi * bwb;
+    if (qj < 0) { qi -= 1; qj += bwb; }
+    if (qj >= bwb) { qi += 1; qj -= bwb; }
+    const uint32_t row0 = (uint32_t)bd.ib * (uint32_t)g.w + (uint32_t)bd.jb;  // the host guarantees 4 * h * w < 2^32
+    int base = 0;
+    if (FIXED) {
+        for (; base + 2 * KMT_NT <= nq; base += 2 * KMT_NT) {
+            const int qi0 = qi, qj0 = qj;
+            kmt_advance(qi, qj, di, dj, bwb);
+            const int qi1 = qi, qj1 = qj;
+            kmt_advance(qi, qj, di, dj, bwb);
+            float go0[CC], go1[CC];
+            kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi0 * (uint32_t)g.w + (uint32_t)qj0, go0);
+            kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi1 * (uint32_t)g.w + (uint32_t)qj1, go1);
+            const KmlHalf cu0 = kmt_half(s_u4[qj0]), rv0 = kmt_half(s_v4[qi0]), cu1 = kmt_half(s_u4[qj1]), rv1 = kmt_half(s_v4[qi1]);
+            kmt_pixel<CM, ALIGN, CC, FAST, FIXED>(m, cu0, rv0, true, go0, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc, seen_bits);
+            kmt_pixel<CM, ALIGN, CC, FAST, FIXED>(m, cu1, rv1, true, go1, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc, seen_bits);
+        }
+    }
+    for (; base < nq; base += KMT_NT) {
+        const bool valid = base + tid < nq;
+        const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
+        float go[CC];
+        kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)vqi * (uint32_t)g.w + (uint32_t)vqj, go);
+        kmt_pixel<CM, ALIGN, CC, FAST, FIXED>(m, kmt_half(s_u4[vqj]), kmt_half(s_v4[vqi]), valid, go, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc,
+                                              seen_bits);
+        kmt_advance(qi, qj, di, dj, bwb);
+    }
+}
+
+// One channel chunk (CC channels) of one tile: zero, choose the fixed-point scale, scatter, convert and write.
+//
+// gfx950 measurements that shape this (scratch micro-benchmark, 2048 blocks x 256 threads):
+//   ds_add_f32 / ds_add_rtn_f32    193 cycles per wave-instruction per CU   (float LDS atomics are ~40x slower
+//   ds_add_u32 / ds_add_rtn_u32      5 cycles per wave-instruction per CU    than integer ones)
+// so the per-tap contributions w * grad_out are accumulated as int32 fixed point: scale = 2^k with
+// k = 30 - hb - ceil(log2 M), M >= max |grad_out| over the visited pixels (hb = head-room bits for the number of taps that
+// can land on one source pixel, from the Jacobian bound), adding floor(w * g * scale + 0.5) with ds_add_u32.  Per-term error
+// <= 2^-(k+1), i.e. <= M * 2^-(27-hb): the same order as one fp32 ulp of M.  Integer addition is associative, so the result
+// is independent of the order in which waves run: bit-reproducible, unlike float atomics.
+//
+// The kernel is bound by the latency of its serial phases, not by instruction issue (profiles/r02_*: 62 % of the wave
+// time is spent waiting; halving the VALU count per pixel changed nothing), so the phases are arranged to overlap:
+//   * M is SPECULATED: 8 x (max over a KMT_NT-pixel sample) - reading the whole box twice would cost ~0.3 ms at
+//     256x3x512^2.  The sample is taken around the tile's own location in the output (the pre-image of a tile is there for
+//     the near-identity warps of the hot cases, and a gradient field has the same order of magnitude everywhere), so its
+//     loads are issued BEFORE the box is known and fly while wave 0 computes the box and the others zero the accumulators.
+//     The scatter pass tracks the largest magnitude it loads; only a tile that sees a larger one (or NaN / inf) is redone with
+//     the exact maximum over its box (attempt 1).  The factor 8 costs 3 bits of the fixed-point resolution;
+//   * three block barriers per tile (accumulators zeroed + box + sample | coordinate tables | scatter done) when the box
+//     fits one band of the tables - any warp that does not shrink the image by more than 2x.
+template <typename T, int CM, int ALIGN, int CC>
+__device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, const float (&m)[9], uint32_t b, int cbase, int X0, int Y0, int TWc, int THc,
+                                               bool box_pending, const int* s_box, float4* s_u4, float4* s_v4, int* s_acc, float* red_max) {
+    const KmWarpGeom<float>& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
+    float* gsrc_b = a.gsrc + (size_t)b * g.C * src_plane;
+    const T* gout_c[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)b * g.C + (size_t)(cbase + c)) * dst_plane;
+
+    // ---- speculative bound: one pixel per thread on a KMT_NT-point lattice over the tile's own location in the output ----
+    float vsample = 0.f;
+    if (g.h > 0 && g.w > 0) {
+        constexpr int LX = 32, LY = KMT_NT / LX;  // lattice
+        const float fx = (float)g.w / (float)g.W, fy = (float)g.h / (float)g.H;
+        const int sx = X0 + ((tid % LX) * KMT_TW + KMT_TW / 2) / LX, sy = Y0 + ((tid / LX) * KMT_TH + KMT_TH / 2) / LY;
+        const int jq = min(g.w - 1, max(0, (int)((float)sx * fx))), iq = min(g.h - 1, max(0, (int)((float)sy * fy)));
+        const uint32_t off = (uint32_t)iq * (uint32_t)g.w + (uint32_t)jq;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) vsample = fmaxf(vsample, km_fabs((float)km_ld(km_at(gout_c[c], off))));
+    }
+    // ---- zero the accumulators (while the first chunk's box is still being computed by wave 0, the other waves do it) ----
+    if (box_pending) {
+        if (wave != 0)
+            for (int e = tid - 64; e < CC * KMT_PLANE / 4; e += KMT_NT - 64) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);
+    } else {
+        for (int e = tid; e < CC * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);
+    }
+    {
+        vsample = vsample * 8.0f;
+        const bool bad = !(vsample <= 3.0e38f);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vsample = fmaxf(vsample, __shfl_down(vsample, off, 64));
+        const unsigned long long badmask = __ballot(bad);
+        if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vsample;
+    }
+    __syncthreads();  // accumulators zeroed, box published, sample maxima published
+    const int j0 = kmt_uniform(s_box[0]), j1 = kmt_uniform(s_box[1]), i0 = kmt_uniform(s_box[2]), i1 = kmt_uniform(s_box[3]);
+    const int hb = kmt_uniform(s_box[4]);
+    const bool fixed_ok = kmt_uniform(s_box[5]) != 0;  // fixed-point accumulation is accurate enough (bounded multiplicity)
+    const int bw = j1 - j0 + 1, bh = i1 - i0 + 1;
+    const bool empty = (bw <= 0 || bh <= 0);
+    const float inv_bw = kmt_uniform(bw > 0 ? 1.0f / (float)bw : 0.f);
+
+    float scale = 1.f, inv_scale = 1.f;
+    bool finite = false;
+    for (int attempt = (fixed_ok ? 0 : 1); attempt < 2; ++attempt) {
+        float M;
+        if (attempt == 0) {
+            M = red_max[0];
+#pragma unroll
+            for (int k = 1; k < KMT_NW; ++k) M = fmaxf(M, red_max[k]);
+        } else {
+            // the exact maximum over the box
+            float vmax = 0.f;
+            bool bad = false;
+            if (!empty) {
+                const int nq = bw * bh;
+                for (int base = 0; base < nq; base += 4 * KMT_NT) {
+                    float vv[4][CC];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int e = min(base + s4 * KMT_NT + tid, nq - 1);  // clamped: duplicates do not change a max
+                        int qi = (int)(((float)e + 0.5f) * inv_bw);
+                        int qj = e - qi * bw;
+                        if (qj < 0) { qi -= 1; qj += bw; }
+                        if (qj >= bw) { qi += 1; qj -= bw; }
+                        const uint32_t off = (uint32_t)(i0 + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) vv[s4][c] = km_fabs((float)km_ld(km_at(gout_c[c], off)));
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            bad = bad || !(vv[s4][c] <= 3.0e38f);
+                            vmax = fmaxf(vmax, vv[s4][c]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+            const unsigned long long badmask = __ballot(bad);
+            __syncthreads();  // red_max is still being read by attempt 0's readers
+            if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vmax;
+            __syncthreads();
+            M = red_max[0];
+#pragma unroll
+            for (int k = 1; k < KMT_NW; ++k) M = fmaxf(M, red_max[k]);
+        }
+        // scale = 2^k with |w * g * scale| * (taps per pixel) < 2^30
+        finite = (M <= 3.0e38f) && fixed_ok;  // else: IEEE float accumulation (slow ds_add_f32)
+        int kexp = 0;
+        if (finite && M > 0.f) {
+            int ex2;
+            (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
+            kexp = 30 - hb - ex2;
+            kexp = max(-126, min(126, kexp));
+        }
+        scale = kmt_uniform(ldexpf(1.0f, kexp));
+        inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
+        const float bound = finite ? M : __int_as_float(0x7f800000);  // the float path accepts anything
+
+        // ---- scatter pass ----
+        uint32_t seen_bits = 0;  // largest |grad_out| bit pattern this thread has loaded
+        if (!empty) {
+            // the box is walked in bands of at most KMT_BAND_W columns x KMT_TAB rows (one band for any warp that does not
+            // shrink the image by more than 2x), whose coordinate halves sit in the LDS tables
+            bool first_band = true;
+            for (int jb = j0; jb <= j1; jb += KMT_BAND_W) {
+                KmtBand bd;
+                bd.jb = jb;
+                bd.bwb = min(KMT_BAND_W, j1 - jb + 1);
+                for (int ib = i0; ib <= i1; ib += KMT_TAB) {
+                    bd.ib = ib;
+                    bd.nrows = min(i1, ib + KMT_TAB - 1) - ib + 1;
+                    if (!first_band) __syncthreads();  // the previous band's readers are done with the tables
+                    first_band = false;
+                    if (tid < bd.bwb && (ib == i0)) {
+                        const KmlHalf h = kml_col_half<CM>(m, km_base_x<float, CM>(g, jb + tid));
+                        s_u4[tid] = make_float4(h.a, h.b, h.c, 0.f);
+                    }
+                    bool okr = true;
+                    const int rt = tid - (KMT_NT - KMT_TAB);  // the row table is filled by the LAST threads: the first ones fill the columns
+                    if (rt >= 0 && rt < bd.nrows) {
+                        const float v = km_base_y<float, CM>(g, ib + rt);
+                        const KmlHalf h = kml_row_half<CM>(m, v);
+                        s_v4[rt] = make_float4(h.a, h.b, h.c, 0.f);
+                        okr = kml_row_guard<CM>(g, m, v);
+                    }
+                    const bool fast = __syncthreads_and((int)okr) != 0;  // every row of the band has safe division operands
+                    const uint32_t uX0 = (uint32_t)X0, uY0 = (uint32_t)Y0, uTW = (uint32_t)TWc, uTH = (uint32_t)THc;
+                    if (!finite) kmt_scatter_band<T, CM, ALIGN, CC, false, false>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
+                    else if (fast) kmt_scatter_band<T, CM, ALIGN, CC, true, true>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
+                    else kmt_scatter_band<T, CM, ALIGN, CC, false, true>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
+                }
+            }
+        }
+        // the fixed-point scale was chosen for |grad_out| <= bound; anything larger (or NaN) voids the attempt
+        const bool exceeded = seen_bits > __float_as_uint(bound);
+        const int redo = __syncthreads_or((int)exceeded);
+        if (attempt == 0 && redo) {
+            for (int e = tid; e < CC * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);  // discard the attempt
+            continue;  // the barriers at the top of attempt 1 order these stores before the next atomics
+        }
+        break;
+    }
+
+    // ---- convert and write the tile ----
+    if (TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0) {
+        // full-width tile, 16-byte aligned rows: 16 lanes x 16 bytes cover a tile row, a wave writes 4 rows per store
+        const int col4 = (tid & 15) * 4, row0 = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float* outp = gsrc_b + (size_t)(cbase + c) * src_plane + (size_t)(Y0 + row0) * g.W + (X0 + col4);
+            const int* accp = s_acc + c * KMT_PLANE + row0 * KMT_TW + col4;
+            const size_t ostep = (size_t)(KMT_NT / 16) * g.W;
+#pragma unroll 2
+            for (int r = row0; r < THc; r += KMT_NT / 16) {
+                KM_CHECK_ALIGNED(accp, 16);
+                KM_CHECK_ALIGNED(outp, 16);
+                const int4 q = *reinterpret_cast<const int4*>(accp);
+                float4 v;
+                if (finite) {
+                    v = make_float4((float)q.x * inv_scale, (float)q.y * inv_scale, (float)q.z * inv_scale, (float)q.w * inv_scale);
+                } else {
+                    v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
+                }
+                *reinterpret_cast<float4*>(outp) = v;
+                outp += ostep;
+                accp += (KMT_NT / 16) * KMT_TW;
+            }
+        }
+    } else {
+        // ragged right edge / unaligned rows: lane -> column, waves -> rows, one float per store
+        const int col = tid & (KMT_TW - 1), row0 = tid >> 6;
+        if (col < TWc) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                float* outp = gsrc_b + (size_t)(cbase + c) * src_plane + (size_t)(Y0 + row0) * g.W + (X0 + col);
+                const int* accp = s_acc + c * KMT_PLANE + row0 * KMT_TW + col;
+                const size_t ostep = (size_t)KMT_NW * g.W;
+#pragma unroll 4
+                for (int r = row0; r < THc; r += KMT_NW) {
+                    *outp = finite ? (float)(*accp) * inv_scale : *(const float*)accp;
+                    outp += ostep;
+                    accp += KMT_NW * KMT_TW;
+                }
             }
         }
     }
 }
 
-// Tile-owner SCATTER with fixed-point LDS accumulators.
-//
-// gfx950 measurements that shape this kernel (scratch micro-benchmark, 2048 blocks x 256 threads):
-//   ds_add_f32 / ds_add_rtn_f32    193 cycles per wave-instruction per CU   (float LDS atomics are ~40x slower
-//   ds_add_u32 / ds_add_rtn_u32      5 cycles per wave-instruction per CU    than integer ones)
-// so the per-tap contributions w * grad_out are accumulated as int32 fixed point: the block first finds
-// M = max |grad_out| over the output pixels it will visit, picks scale = 2^k with
-// k = 30 - hb - ceil(log2 M) (hb = head-room bits for the number of taps that can land on one source pixel,
-// from the Jacobian bound), and adds floor(w * g * scale + 0.5) with ds_add_u32.  Per-term error <= 2^-(k+1),
-// i.e. <= M * 2^-(27-hb): the same order as one fp32 ulp of M.  Integer addition is associative, so the
-// result is independent of the order in which waves run: bit-reproducible, unlike float atomics.
+// Tile-owner SCATTER with fixed-point LDS accumulators (see the file header and kmt_tile_chunk).
 #ifndef KMT_MIN_WAVES
 #define KMT_MIN_WAVES 6
 #endif
-#ifndef KMT_UNROLL
-#define KMT_UNROLL 2
-#endif
 template <typename T, int CM, int ALIGN>
 __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
-    typedef float R;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ float red_max[KMT_NW];
     __shared__ int s_box[8];
+    static_assert(KMT_BAND_W + KMT_TAB <= KMT_NT || KMT_NT >= 2 * KMT_TAB, "the column and row tables are filled by disjoint threads");
 
-    const KmWarpGeom<R>& g = a.g;
+    const KmWarpGeom<float>& g = a.g;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int X0 = (int)tx * KMT_TW, Y0 = (int)ty * KMT_TH;
     const int X1 = min(X0 + KMT_TW, g.W), Y1 = min(Y0 + KMT_TH, g.H);  // tile = [X0,X1) x [Y0,Y1)
     const int TWc = X1 - X0, THc = Y1 - Y0;
 
-    R m[9];
+    float m[9];
     {
-        const R* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+        const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = mp[k];
     }
 
-    // ---- box of output pixels that can touch the tile: computed by wave 0 only (it is ~400 block-uniform
-    //      VALU instructions, ~15 % of a block's work if every wave repeats it), broadcast through LDS
+    // ---- box of output pixels that can touch the tile: computed by wave 0 only (~400 block-uniform VALU instructions),
+    //      published through LDS by the first barrier of the first channel chunk
     if (wave == 0) {
         const KmtBox bx = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
         if (lane == 0) {
@@ -402,201 +619,21 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
             s_box[5] = bx.fixed_ok ? 1 : 0;
         }
     }
-    __syncthreads();
-    const int j0 = kmt_uniform(s_box[0]), j1 = kmt_uniform(s_box[1]), i0 = kmt_uniform(s_box[2]), i1 = kmt_uniform(s_box[3]);
-    const int hb = kmt_uniform(s_box[4]);
-    const bool fixed_ok = kmt_uniform(s_box[5]) != 0;  // fixed-point accumulation is accurate enough (bounded multiplicity)
-    const int bw = j1 - j0 + 1, bh = i1 - i0 + 1;
-    const bool empty = (bw <= 0 || bh <= 0);
-    const float inv_bw = kmt_uniform(bw > 0 ? 1.0f / (float)bw : 0.f);
-
-    const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
-    const T* gout_b = a.gout + (size_t)b * g.C * dst_plane;
-    R* gsrc_b = a.gsrc + (size_t)b * g.C * src_plane;
 
     // LDS carve: coordinate tables, then the int32 accumulators [cc][TH][TW]
-    float4* s_u4 = (float4*)smem_raw;   // [KMT_TAB] per column of the box
-    float4* s_v4 = s_u4 + KMT_TAB;      // [KMT_TAB] per row of the current band
+    float4* s_u4 = (float4*)smem_raw;   // [KMT_BAND_W] per column of the band
+    float4* s_v4 = s_u4 + KMT_BAND_W;   // [KMT_TAB] per row of the band
     int* s_acc = (int*)(s_v4 + KMT_TAB);
 
-    for (int cbase = 0; cbase < g.C; cbase += KMT_CC) {
-        const int cc = min(KMT_CC, g.C - cbase);
-        for (int e = tid; e < cc * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);
-        const T* gout_c[KMT_CC];
-#pragma unroll
-        for (int c = 0; c < KMT_CC; ++c) gout_c[c] = gout_b + (size_t)(cbase + min(c, cc - 1)) * dst_plane;
-
-        // The scale needs an upper bound M on |grad_out| over the box.  Reading the whole box twice costs ~0.3 ms
-        // at 256x3x512^2, so attempt 0 SPECULATES: M = 8 x (max over a KMT_NT-pixel sample of the box); the scatter
-        // pass tracks the largest magnitude it loads, and only a tile that sees a larger one (or a NaN/inf) is redone
-        // with the exact maximum (attempt 1).  The guard factor costs 3 bits of the fixed-point resolution.
-        R scale = 1.f, inv_scale = 1.f;
-        bool finite = false;
-        for (int attempt = (fixed_ok ? 0 : 1); attempt < 2; ++attempt) {
-            R vmax = 0.f;
-            bool bad = false;
-            if (!empty) {
-                const int nq = bw * bh;
-                if (attempt == 0) {
-                    const int e = (int)(((long long)tid * nq) / KMT_NT);  // KMT_NT pixels spread over the box
-                    int qi = (int)(((float)e + 0.5f) * inv_bw);
-                    int qj = e - qi * bw;
-                    if (qj < 0) { qi -= 1; qj += bw; }
-                    if (qj >= bw) { qi += 1; qj -= bw; }
-                    const uint32_t off = (uint32_t)(i0 + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);
-#pragma unroll
-                    for (int c = 0; c < KMT_CC; ++c) vmax = fmaxf(vmax, km_fabs((R)km_ld(km_at(gout_c[c], off))));
-                    vmax = vmax * 8.0f;
-                    bad = !(vmax <= 3.0e38f);
-                } else {
-                    for (int base = 0; base < nq; base += 4 * KMT_NT) {
-                        R vv[4][KMT_CC];
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            const int e = min(base + s4 * KMT_NT + tid, nq - 1);  // clamped: duplicates do not change a max
-                            int qi = (int)(((float)e + 0.5f) * inv_bw);
-                            int qj = e - qi * bw;
-                            if (qj < 0) { qi -= 1; qj += bw; }
-                            if (qj >= bw) { qi += 1; qj -= bw; }
-                            const uint32_t off = (uint32_t)(i0 + qi) * (uint32_t)g.w + (uint32_t)(j0 + qj);
-#pragma unroll
-                            for (int c = 0; c < KMT_CC; ++c) vv[s4][c] = km_fabs((R)km_ld(km_at(gout_c[c], off)));
-                        }
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                            for (int c = 0; c < KMT_CC; ++c) {
-                                bad = bad || !(vv[s4][c] <= 3.0e38f);
-                                vmax = fmaxf(vmax, vv[s4][c]);
-                            }
-                    }
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-            const unsigned long long badmask = __ballot(bad);
-            __syncthreads();  // red_max may still be read by a previous attempt / channel chunk
-            if (lane == 0) red_max[wave] = badmask ? __int_as_float(0x7f800000) : vmax;
-            __syncthreads();
-            R M = red_max[0];
-#pragma unroll
-            for (int k = 1; k < KMT_NW; ++k) M = fmaxf(M, red_max[k]);
-            // scale = 2^k with |w * g * scale| * (taps per pixel) < 2^30
-            finite = (M <= 3.0e38f) && fixed_ok;  // else: IEEE float accumulation (slow ds_add_f32)
-            int kexp = 0;
-            if (finite && M > 0.f) {
-                int ex2;
-                (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
-                kexp = 30 - hb - ex2;
-                kexp = max(-126, min(126, kexp));
-            }
-            scale = kmt_uniform(ldexpf(1.0f, kexp));
-            inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
-            const R bound = finite ? M : __int_as_float(0x7f800000);  // the float path accepts anything
-
-            // ---- scatter pass ----
-            uint32_t seen_bits = 0;  // largest |grad_out| bit pattern this thread has loaded
-            if (!empty) {
-                // the box is walked in bands of at most KMT_TAB columns x KMT_TAB rows (one band for any warp that does
-                // not shrink the image by more than 2x), whose coordinate halves sit in the LDS tables
-                for (int jb = j0; jb <= j1; jb += KMT_TAB) {
-                    const int bwb = min(KMT_TAB, j1 - jb + 1);
-                    const int di = kmt_uniform(KMT_NT / bwb), dj = kmt_uniform(KMT_NT % bwb);  // element e + KMT_NT is di rows, dj columns on
-                    for (int ib = i0; ib <= i1; ib += KMT_TAB) {
-                        const int ie = min(i1, ib + KMT_TAB - 1);
-                        __syncthreads();
-                        if (tid < bwb && (ib == i0)) s_u4[tid] = kmt_col_entry<CM>(m, km_base_x<R, CM>(g, jb + tid));
-                        if (tid <= ie - ib) s_v4[tid] = kmt_row_entry<CM>(m, km_base_y<R, CM>(g, ib + tid));
-                        __syncthreads();
-                        const int nq = bwb * (ie - ib + 1);
-                        // element e = base + tid  (tid < 2^24: the float quotient is off by at most one)
-                        int qi = (int)(((float)tid + 0.5f) / (float)bwb), qj = tid - qi * bwb;
-                        if (qj < 0) { qi -= 1; qj += bwb; }
-                        if (qj >= bwb) { qi += 1; qj -= bwb; }
-                        int base = 0;
-                        for (; base + KMT_UNROLL * KMT_NT <= nq; base += KMT_UNROLL * KMT_NT) {
-                            int pqi[KMT_UNROLL], pqj[KMT_UNROLL];
-                            R go[KMT_UNROLL][KMT_CC];
-#pragma unroll
-                            for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {  // all loads of the group first
-                                pqi[s4] = qi; pqj[s4] = qj;
-                                kmt_load_go<T>(g, qi, qj, jb, ib, gout_c, go[s4]);
-                                kmt_advance(qi, qj, di, dj, bwb);
-                            }
-#pragma unroll
-                            for (int s4 = 0; s4 < KMT_UNROLL; ++s4)
-                                kmt_scatter_q<T, CM, ALIGN>(g, m, pqi[s4], pqj[s4], true, go[s4], s_u4, s_v4, s_acc, finite, scale, cc, X0, TWc, Y0, THc,
-                                                            seen_bits);
-                        }
-                        for (; base < nq; base += KMT_NT) {
-                            const bool valid = base + tid < nq;
-                            const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
-                            R go[KMT_CC];
-                            kmt_load_go<T>(g, vqi, vqj, jb, ib, gout_c, go);
-                            kmt_scatter_q<T, CM, ALIGN>(g, m, vqi, vqj, valid, go, s_u4, s_v4, s_acc, finite, scale, cc, X0, TWc, Y0, THc, seen_bits);
-                            kmt_advance(qi, qj, di, dj, bwb);
-                        }
-                    }
-                }
-            }
-            // the fixed-point scale was chosen for |grad_out| <= bound; anything larger (or NaN) voids the attempt
-            const bool exceeded = seen_bits > __float_as_uint(bound);
-            const int redo = __syncthreads_or((int)exceeded);
-            if (attempt == 0 && redo) {
-                for (int e = tid; e < cc * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);  // discard the attempt
-                continue;  // the barrier at the top of attempt 1 orders these stores before the next atomics
-            }
-            break;
-        }
-
-        // ---- convert and write the tile ----
-        if (TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0) {
-            // full-width tile, 16-byte aligned rows: 16 lanes x 16 bytes cover a tile row, a wave writes 4 rows per store
-            const int col4 = (tid & 15) * 4, row0 = tid >> 4;
-#pragma unroll
-            for (int c = 0; c < KMT_CC; ++c) {
-                if (c < cc) {
-                    R* outp = gsrc_b + (size_t)(cbase + c) * src_plane + (size_t)(Y0 + row0) * g.W + (X0 + col4);
-                    const int* accp = s_acc + c * KMT_PLANE + row0 * KMT_TW + col4;
-                    const size_t ostep = (size_t)(KMT_NT / 16) * g.W;
-#pragma unroll 2
-                    for (int r = row0; r < THc; r += KMT_NT / 16) {
-                        KM_CHECK_ALIGNED(accp, 16);
-                        KM_CHECK_ALIGNED(outp, 16);
-                        const int4 q = *reinterpret_cast<const int4*>(accp);
-                        float4 v;
-                        if (finite) {
-                            v = make_float4((R)q.x * inv_scale, (R)q.y * inv_scale, (R)q.z * inv_scale, (R)q.w * inv_scale);
-                        } else {
-                            v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
-                        }
-                        *reinterpret_cast<float4*>(outp) = v;
-                        outp += ostep;
-                        accp += (KMT_NT / 16) * KMT_TW;
-                    }
-                }
-            }
-        } else {
-            // ragged right edge / unaligned rows: lane -> column, waves -> rows, one float per store
-            const int col = tid & (KMT_TW - 1), row0 = tid >> 6;
-            if (col < TWc) {
-#pragma unroll
-                for (int c = 0; c < KMT_CC; ++c) {
-                    if (c < cc) {
-                        R* outp = gsrc_b + (size_t)(cbase + c) * src_plane + (size_t)(Y0 + row0) * g.W + (X0 + col);
-                        const int* accp = s_acc + c * KMT_PLANE + row0 * KMT_TW + col;
-                        const size_t ostep = (size_t)KMT_NW * g.W;
-#pragma unroll 4
-                        for (int r = row0; r < THc; r += KMT_NW) {
-                            *outp = finite ? (R)(*accp) * inv_scale : *(const float*)accp;
-                            outp += ostep;
-                            accp += KMT_NW * KMT_TW;
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
+    // channels in chunks of 3 (RGB: one pass); a remainder of 1 or 2 channels goes one channel at a time
+    int cbase = 0;
+    for (; cbase + KMT_CC <= g.C; cbase += KMT_CC) {
+        if (cbase) __syncthreads();  // the previous chunk's flush is done with the accumulators
+        kmt_tile_chunk<T, CM, ALIGN, KMT_CC>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max);
+    }
+    for (; cbase < g.C; ++cbase) {
+        if (cbase) __syncthreads();
+        kmt_tile_chunk<T, CM, ALIGN, 1>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max);
     }
 }
 

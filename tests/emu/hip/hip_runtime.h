@@ -81,6 +81,23 @@ inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 inline float __frcp_rn(float x) { return 1.0f / x; }
+// v_rcp_f32 is accurate to 1 ulp, not correctly rounded: the stand-in returns the rounded reciprocal moved by one ulp
+// up, down or not at all depending on the operand's bits, so code that claims an exact result after refining it
+// (kml_rcp_refined / kml_div_by, km_lean.h) is tested against every error the instruction is allowed to make
+inline float emu_rcpf(float x) {
+    float r = 1.0f / x;
+    if (r != r || r - r != 0.0f || r == 0.0f) return r;  // NaN, inf, zero
+    unsigned u;
+    memcpy(&u, &x, 4);
+    u = (u ^ (u >> 7) ^ (u >> 13)) * 2654435761u;
+    const unsigned k = (u >> 29) % 3u;
+    if (k == 1) r = nextafterf(r, 3.0e38f);
+    if (k == 2) r = nextafterf(r, -3.0e38f);
+    return r;
+}
+#define __builtin_amdgcn_rcpf(x) emu_rcpf(x)
+// v_mul_i32_i24: product of the sign-extended low 24 bits (callers guarantee that both operands fit)
+inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
 // v_cvt_rpi_i32_f32: floor(v + 0.5) with the conversion's hardware semantics (saturation, NaN -> 0)
 inline int emu_cvt_rpi_i32_f32(float v) {
     if (v != v) return 0;
@@ -89,6 +106,14 @@ inline int emu_cvt_rpi_i32_f32(float v) {
     if (f <= -2147483648.0f) return -2147483647 - 1;
     return (int)f;
 }
+// v_cvt_i32_f32: truncation toward zero, saturating, NaN -> 0
+inline int emu_cvt_i32_f32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return -2147483647 - 1;
+    return (int)v;
+}
+#define KM_F2I(v) emu_cvt_i32_f32(v)
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 
@@ -135,6 +160,7 @@ inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred != 0
 inline int __all(int pred) { return emu::wave_ballot(pred == 0) == 0ull; }  // no live lane with a false predicate
 inline int __any(int pred) { return emu::wave_ballot(pred != 0) != 0ull; }
 inline int __syncthreads_or(int pred) { return emu::syncthreads_or(pred); }
+inline int __syncthreads_and(int pred) { return !emu::syncthreads_or(!pred); }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu::launch((grid), (block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })
