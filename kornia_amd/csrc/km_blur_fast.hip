@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     const int H = a.H, W = a.W, border = a.border;
     const int c0 = gx * 4;
     const bool left = (c0 == 0), right = (c0 == W - 4);
+    const bool first16 = (lane & 15) == 0, last16 = (lane & 15) == 15;  // ends of a DPP row: no neighbour lane on that side
     const T* img = a.x + (size_t)bc * H * W;
     T* out = a.y + (size_t)bc * H * W;
     const int b = (int)(bc / a.C);
@@ -137,9 +138,24 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
                 if (srow >= 0) {
                     const T* rowp = img + (size_t)srow * W;
                     float l4[4], o4[4], r4[4];
-                    km_ld4(rowp + offL, l4);
                     km_ld4(rowp + c0, o4);
-                    km_ld4(rowp + offR, r4);
+                    if (border == KM_BORDER_CIRCULAR) {
+                        km_ld4(rowp + offL, l4);
+                        km_ld4(rowp + offR, r4);
+                    } else {
+                        // The neighbouring chunks are what the neighbouring lanes have just loaded: take them from their registers
+                        // (one DPP move each) instead of requesting them from memory again - the memory pipeline is bound by the
+                        // bytes the lanes request (profiles/r02_hbm_shapes.txt), and three 16-byte loads per 16 bytes of output
+                        // were two too many.  Only the first / last lane of a row of 16 lanes still loads its outer chunk.
+                        if (first16) km_ld4(rowp + offL, l4);
+                        if (last16) km_ld4(rowp + offR, r4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float pl = km_prev16(o4[q]), nr = km_next16(o4[q]);
+                            if (!first16) l4[q] = pl;
+                            if (!last16) r4[q] = nr;
+                        }
+                    }
                     if (border != KM_BORDER_CIRCULAR) {
                         if (BWD || border == KM_BORDER_CONSTANT) {
                             if (left) { l4[0] = l4[1] = l4[2] = l4[3] = 0.f; }

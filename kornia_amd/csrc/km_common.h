@@ -38,6 +38,19 @@ int km_check_launch(const char* what);
 #define KM_F2I(v) ((int)(v))
 #endif
 
+// Value held by the NEXT lane of the same row of 16 lanes (DPP row_shl:1 - one VALU move, no LDS traffic); the last lane of a
+// row gets its own value back.  (The host build of the kernels defines KM_NEXT16 and supplies the same function.)
+#ifndef KM_NEXT16
+__device__ __forceinline__ uint32_t km_next16(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x101, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float km_next16(float v) { return __uint_as_float(km_next16(__float_as_uint(v))); }
+// ... and by the PREVIOUS lane of the row (row_shr:1); the first lane of a row gets its own value back
+__device__ __forceinline__ float km_prev16(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x111, 0xf, 0xf, false));
+}
+#endif
+
 // ---- storage types ----------------------------------------------------------------------------
 struct km_bf16 {
     uint16_t bits;

@@ -370,16 +370,34 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
         T* __restrict__ dp[NCC];
 #pragma unroll
         for (int c = 0; c < NCC; ++c) { sp[c] = src_b + c * src_plane; dp[c] = dst_b + c * dst_plane; }  // wave-uniform plane bases
+        // The memory pipeline is bound by the BYTES the lanes request, whatever the instruction mix (profiles/r02_hbm_shapes.txt:
+        // a 2 x 2 footprint per pixel - 16 bytes for 4 bytes of output - costs 0.39 ms at this size, 8 bytes 0.30, a plain copy
+        // 0.29): a lane loads its own column of the footprint, (x0, y0) and (x0, y0 + 1), and takes the x0 + 1 column from
+        // the next lane when that lane's footprint starts exactly one pixel to the right - which it does for most lanes of any
+        // warp of scale ~1; the others (and the last lane of each row of 16) load it themselves.  Same values either way.
         float v[KM_ROWS][NCC][4];
+        bool nb[KM_ROWS];
 #pragma unroll
         for (int r = 0; r < KM_ROWS; ++r) {
             const uint32_t off = (uint32_t)__mul24((int)t[r].yf, W) + (uint32_t)(int)t[r].xf;
+            nb[r] = (km_next16(off) == off + 1u);  // (the last lane of a row of 16 reads itself: false)
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
-                km_ld2(km_at(sp[c], off), v[r][c][0], v[r][c][1]);
-                km_ld2(km_at(sp[c], off + (uint32_t)W), v[r][c][2], v[r][c][3]);
+                v[r][c][0] = (float)km_ld(km_at(sp[c], off));
+                v[r][c][2] = (float)km_ld(km_at(sp[c], off + (uint32_t)W));
+                if (!nb[r]) {
+                    v[r][c][1] = (float)km_ld(km_at(sp[c], off + 1u));
+                    v[r][c][3] = (float)km_ld(km_at(sp[c], off + (uint32_t)W + 1u));
+                }
             }
         }
+#pragma unroll
+        for (int r = 0; r < KM_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NCC; ++c) {
+                const float n0 = km_next16(v[r][c][0]), n2 = km_next16(v[r][c][2]);
+                if (nb[r]) { v[r][c][1] = n0; v[r][c][3] = n2; }
+            }
 #pragma unroll
         for (int r = 0; r < KM_ROWS; ++r) {
             const float w00 = t[r].wx1 * t[r].wy1, w01 = t[r].wx0 * t[r].wy1, w10 = t[r].wx1 * t[r].wy0, w11 = t[r].wx0 * t[r].wy0;
@@ -424,8 +442,17 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
     }
 }
 
+// A block takes KML_GROUPS vertically adjacent 64 x 16 groups of rows one after the other: what a block pays once - matrix
+// and argument loads, the row table with its IEEE divisions, a barrier, ~2 us before the first pixel - is spread over
+// 64 x 16 x KML_GROUPS pixels (measured: the kernel is bound by these serial latencies and the memory latency behind them,
+// not by bytes or instructions).
+#ifndef KML_GROUPS
+#define KML_GROUPS 2   // measured on one box, 256x3x512^2: 1 -> 0.49 ms, 2 -> 0.41, 4 -> 0.42 (round-1 kernel there: 0.44)
+#endif
+#define KML_TILE_H (KM_TILE_H * KML_GROUPS)
 template <typename T, int CM, int NC, int ALIGN>  // NC = 3 / 1: RGB / grey unrolled ; NC = 0: runtime channel loop
 __global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<T> a) {
+    static_assert(KML_TILE_H <= 64, "the row table is filled by one wave");
     const KmWarpGeom<float>& g = a.g;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t tx = bid % a.tiles_x;
@@ -435,9 +462,9 @@ __global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<
     constexpr int PW = KM_PATCH_W, PH = 64 / PW, WA = 64 / PW;  // patch, waves across the 64-wide tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
-    const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // row inside the tile of this thread's row r: li_base + r * PH
-    const int i_base = (int)ty * KM_TILE_H + li_base;
-    __shared__ float4 s_rv[KM_TILE_H];
+    const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // row inside a group of this thread's row r: li_base + r * PH
+    const int i_base = (int)ty * KML_TILE_H + li_base;
+    __shared__ float4 s_rv[KML_TILE_H];
     __shared__ int s_fast;
 
     float m[9];
@@ -448,8 +475,8 @@ __global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<
     }
     if (wave == 0) {  // row halves of the numerators + the per-row division guard, combined over the tile's rows
         bool ok = true;
-        if (lane < KM_TILE_H) {
-            const float v = km_base_y<float, CM>(g, (int)ty * KM_TILE_H + lane);
+        if (lane < KML_TILE_H) {
+            const float v = km_base_y<float, CM>(g, (int)ty * KML_TILE_H + lane);
             const KmlHalf h = kml_row_half<CM>(m, v);
             s_rv[lane] = make_float4(h.a, h.b, h.c, 0.f);
             ok = kml_row_guard<CM>(g, m, v);
@@ -459,10 +486,13 @@ __global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<
     }
     __syncthreads();
     if (j >= g.w) return;
-    if (__builtin_amdgcn_readfirstlane(s_fast))
-        km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true>(a, m, s_rv, b, j, li_base, i_base);
-    else
-        km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false>(a, m, s_rv, b, j, li_base, i_base);
+    const bool fast = __builtin_amdgcn_readfirstlane(s_fast) != 0;
+    for (int gr = 0; gr < KML_GROUPS; ++gr) {
+        const int ib = i_base + gr * KM_TILE_H;
+        if ((int)ty * KML_TILE_H + gr * KM_TILE_H >= g.h) break;  // block-uniform: the group lies below the image
+        if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -750,7 +780,10 @@ static bool km_fwd_lean_ok(const KmWarpArgs<T>& a) {
     return (uint64_t)a.g.H * a.g.W * 4 < (1ull << 32) && (uint64_t)a.g.h * a.g.w * 4 < (1ull << 32) && a.g.W < (1 << 23) && a.g.H < (1 << 23);
 }
 template <typename T, int CM, int NC>
-static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
+static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
+    KmWarpArgs<T> a = a0;
+    a.tiles_y = (uint32_t)((a.g.h + KML_TILE_H - 1) / KML_TILE_H);
+    a.nblocks = a.tiles_x * a.tiles_y * (uint32_t)a.g.B;  // (<= the 64 x 16 grid the caller checked)
     if (a.g.align)
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
@@ -862,8 +895,9 @@ static int km_warp_validate(const char* fn, const void* src, const void* mat, in
 // owner-computes grad_src for bilinear + zeros/fill (km_warp_bwd_tiled.hip)
 int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc);
 int km_warp_bwd_tiled_dims_ok(int h, int w);
-int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode,
-                          int norm_coords, int pad, int align, int dtype, hipStream_t s);
+int km_warp_bwd_tiled_fuses_gm(int H, int W);
+int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, const void* src, double* gmat, const void* fill, int B, int C, int H, int W,
+                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, int dtype, hipStream_t s);
 
 // matrix gradient of the bilinear warps (km_warp_gm.hip)
 int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, int w);
@@ -905,8 +939,11 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
     const bool gm_fast = gmat && km_warp_gm_supported(interp, pad, dtype, H, W, h, w);
     if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc)) {
         if (km_warp_bwd_tiled_dims_ok(h, w)) {
-            const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, dtype, s);
-            if (rc != 0 || !gmat) return rc;
+            // both gradients in one pass over grad_out when the tile-owner kernel can gather the source taps itself
+            const bool fuse = gmat && gm_fast && km_warp_bwd_tiled_fuses_gm(H, W);
+            const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, src, fuse ? gmat : nullptr, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad,
+                                                 align, dtype, s);
+            if (rc != 0 || !gmat || fuse) return rc;
             if (gm_fast) return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
             gsrc = nullptr;  // matrix gradient by the generic kernel below (W < 2)
         } else {

@@ -49,6 +49,9 @@ struct KmWarpTiledArgs {
     const T* gout;       // (B,C,h,w)
     const float* mat;    // (B_M,9)
     float* gsrc;         // (B,C,H,W) fp32, written completely (no pre-zeroing needed)
+    const T* src;        // (B,C,H,W): only read when gmat != nullptr
+    double* gmat;        // (B_M,9) fp64 accumulators, pre-zeroed; nullptr: image gradient only
+    const float* fill;   // (C), pad == fill only (the matrix gradient sees (v - fill))
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, nblocks;
 };
@@ -253,10 +256,22 @@ __device__ __forceinline__ void kmt_load_go(const T* const (&gout_c)[CC], uint32
 // One output pixel of the scatter pass: position (the forward's own instruction sequence, km_lean.h), footprint, and the
 // four contributions w * grad_out[q, c] to the taps that fall inside the tile.  FIXED: int32 fixed-point LDS accumulators;
 // otherwise IEEE float LDS atomics (slow; non-finite gradients, vanishing-line tiles, extreme magnification).
-template <int CM, int ALIGN, int CC, bool FAST, bool FIXED>
-__device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, bool valid, const float (&go)[CC], int* s_acc,
-                                          float scale, float Wm1, float hW, float Hm1, float hH, uint32_t X0, uint32_t TWc, uint32_t Y0,
-                                          uint32_t THc, uint32_t& seen_bits) {
+// matrix-gradient side of a pixel (GM): the pixel is counted by the ONE tile that owns its north-west tap (clamped into the image),
+// with the source taps gathered from global memory - grad_out is then read once for both gradients (3e bytes per element for the
+// backward instead of 4e with a separate matrix-gradient launch).
+template <typename T, int CC>
+struct KmtGm {
+    const T* src_c[CC];   // channel planes of the source image
+    float fill[CC];       // pad == fill: subtracted from every in-bounds tap
+    int W, H;
+    float mx, my;         // d (pixel) / d (normalised)
+    bool enabled;         // false while a tile is being redone with the exact scale (its matrix-gradient sums are already complete)
+};
+
+template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED, bool GM>
+__device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, float ub, float vb, bool valid, const float (&go)[CC],
+                                          int* s_acc, float scale, float Wm1, float hW, float Hm1, float hH, uint32_t X0, uint32_t TWc, uint32_t Y0,
+                                          uint32_t THc, uint32_t& seen_bits, const KmtGm<T, CC>& gm, float (&gacc)[9]) {
     // the fixed-point scale was chosen for |grad_out| <= bound: remember the largest magnitude seen, as an integer
     // (sign cleared, IEEE bit patterns order like unsigned integers and NaN / inf sort above every finite value)
     if (FIXED) {
@@ -315,6 +330,61 @@ __device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu
             if (t11) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, w11 * go[c]);
         }
     }
+    if (GM) {
+        // owner = the tile holding (max(x0, 0), max(y0, 0)); a pixel with no tap inside the image contributes nothing anywhere
+        const bool ox = in_x0 || ((X0 == 0u) && (ux == 0xffffffffu));
+        const bool oy = in_y0 || ((Y0 == 0u) && (uy == 0xffffffffu));
+        const bool own = ox && oy && (x == x) && (y == y) && gm.enabled;
+        if (__any(own)) {
+            float gix = 0.f, giy = 0.f;
+            const bool interior = kml_inside(t, (float)(gm.W - 2), (float)(gm.H - 2));
+            if (__all(!own || interior)) {
+                const uint32_t off = own ? (uint32_t)__mul24(KM_F2I(t.yf), gm.W) + (uint32_t)KM_F2I(t.xf) : 0u;
+                float sv[CC][4];
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    km_ld2(km_at(gm.src_c[c], off), sv[c][0], sv[c][1]);
+                    km_ld2(km_at(gm.src_c[c], off + (uint32_t)gm.W), sv[c][2], sv[c][3]);
+                }
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const float f = gm.fill[c];  // 0 unless pad == fill (same rounding sequence as the oracle: (v - fill) first)
+                    const float s00 = sv[c][0] - f, s01 = sv[c][1] - f, s10 = sv[c][2] - f, s11 = sv[c][3] - f;
+                    gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
+                    giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
+                }
+            } else {
+                KmBilin<float> tb;
+                km_bilinear_setup(x, y, gm.W, gm.H, tb);  // clamped indices (always valid addresses) + per-tap bounds
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const float f = gm.fill[c];
+                    const float v00 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i00)), v01 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i01));
+                    const float v10 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i10)), v11 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i11));
+                    const float s00 = tb.b00 ? v00 - f : 0.0f, s01 = tb.b01 ? v01 - f : 0.0f;
+                    const float s10 = tb.b10 ? v10 - f : 0.0f, s11 = tb.b11 ? v11 - f : 0.0f;
+                    gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
+                    giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
+                }
+            }
+            const float gx_ = own ? gix * gm.mx : 0.0f, gy_ = own ? giy * gm.my : 0.0f;
+            float ax, ay, az;
+            if (CM == KM_COORD_PERSPECTIVE) {
+                const float inv = FAST ? p.rinv : __frcp_rn(p.den);
+                ax = gx_ * inv; ay = gy_ * inv;
+                az = -km_fma(gx_, p.gx, gy_ * p.gy) * inv;
+            } else if (CM == KM_COORD_AFFINE) {
+                ax = gx_; ay = gy_; az = 0.f;
+            } else {
+                const float sc = p.den;
+                ax = gx_ * sc; ay = gy_ * sc;
+                az = p.live ? -km_fma(gx_, p.X, gy_ * p.Y) * sc * sc : 0.0f;
+            }
+            gacc[0] = km_fma(ax, ub, gacc[0]); gacc[1] = km_fma(ax, vb, gacc[1]); gacc[2] += ax;
+            gacc[3] = km_fma(ay, ub, gacc[3]); gacc[4] = km_fma(ay, vb, gacc[4]); gacc[5] += ay;
+            gacc[6] = km_fma(az, ub, gacc[6]); gacc[7] = km_fma(az, vb, gacc[7]); gacc[8] += az;
+        }
+    }
 }
 
 struct KmtBand {
@@ -325,10 +395,10 @@ struct KmtBand {
 // One band of the box, walked as a linear list of pixels: element e = base + tid, (row, column) = (e / bwb, e % bwb).  Lane
 // utilisation is bwb * nrows / (a multiple of KMT_NT) whatever the shape of the box, consecutive lanes read consecutive
 // grad_out pixels.  Two pixels in flight per thread (FIXED: the IEEE float path is not worth unrolling).
-template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED>
+template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED, bool GM>
 __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, const float (&m)[9], const KmtBand& bd, const T* const (&gout_c)[CC],
                                                  const float4* s_u4, const float4* s_v4, int* s_acc, float scale, uint32_t X0, uint32_t TWc,
-                                                 uint32_t Y0, uint32_t THc, uint32_t& seen_bits) {
+                                                 uint32_t Y0, uint32_t THc, uint32_t& seen_bits, const KmtGm<T, CC>& gm, float (&gacc)[9]) {
     const int tid = threadIdx.x;
     const float Wm1 = (float)(g.W - 1), Hm1 = (float)(g.H - 1), hW = (float)g.W / 2, hH = (float)g.H / 2;
     const int bwb = bd.bwb;
@@ -340,7 +410,9 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
     if (qj >= bwb) { qi += 1; qj -= bwb; }
     const uint32_t row0 = (uint32_t)bd.ib * (uint32_t)g.w + (uint32_t)bd.jb;  // the host guarantees 4 * h * w < 2^32
     int base = 0;
-    if (FIXED) {
+    if (FIXED && !GM) {  // (the fused form keeps one pixel in flight: its matrix-gradient side needs the registers)
+        // two pixels per thread and iteration, all their grad_out loads issued first.  (A software-pipelined form - the loads of
+        // iteration k + 1 issued before the pixels of iteration k - measured slower: 0.48 vs 0.45 ms on the same box.)
         for (; base + 2 * KMT_NT <= nq; base += 2 * KMT_NT) {
             const int qi0 = qi, qj0 = qj;
             kmt_advance(qi, qj, di, dj, bwb);
@@ -349,9 +421,11 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
             float go0[CC], go1[CC];
             kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi0 * (uint32_t)g.w + (uint32_t)qj0, go0);
             kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi1 * (uint32_t)g.w + (uint32_t)qj1, go1);
-            const KmlHalf cu0 = kmt_half(s_u4[qj0]), rv0 = kmt_half(s_v4[qi0]), cu1 = kmt_half(s_u4[qj1]), rv1 = kmt_half(s_v4[qi1]);
-            kmt_pixel<CM, ALIGN, CC, FAST, FIXED>(m, cu0, rv0, true, go0, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc, seen_bits);
-            kmt_pixel<CM, ALIGN, CC, FAST, FIXED>(m, cu1, rv1, true, go1, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc, seen_bits);
+            const float4 c0 = s_u4[qj0], r0 = s_v4[qi0], c1 = s_u4[qj1], r1 = s_v4[qi1];  // (.w: the base coordinate itself)
+            kmt_pixel<T, CM, ALIGN, CC, FAST, FIXED, GM>(m, kmt_half(c0), kmt_half(r0), c0.w, r0.w, true, go0, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc,
+                                                         seen_bits, gm, gacc);
+            kmt_pixel<T, CM, ALIGN, CC, FAST, FIXED, GM>(m, kmt_half(c1), kmt_half(r1), c1.w, r1.w, true, go1, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc,
+                                                         seen_bits, gm, gacc);
         }
     }
     for (; base < nq; base += KMT_NT) {
@@ -359,8 +433,9 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
         const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
         float go[CC];
         kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)vqi * (uint32_t)g.w + (uint32_t)vqj, go);
-        kmt_pixel<CM, ALIGN, CC, FAST, FIXED>(m, kmt_half(s_u4[vqj]), kmt_half(s_v4[vqi]), valid, go, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc,
-                                              seen_bits);
+        const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
+        kmt_pixel<T, CM, ALIGN, CC, FAST, FIXED, GM>(m, kmt_half(c0), kmt_half(r0), c0.w, r0.w, valid, go, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc,
+                                                     seen_bits, gm, gacc);
         kmt_advance(qi, qj, di, dj, bwb);
     }
 }
@@ -386,9 +461,10 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
 //     the exact maximum over its box (attempt 1).  The factor 8 costs 3 bits of the fixed-point resolution;
 //   * three block barriers per tile (accumulators zeroed + box + sample | coordinate tables | scatter done) when the box
 //     fits one band of the tables - any warp that does not shrink the image by more than 2x.
-template <typename T, int CM, int ALIGN, int CC>
+template <typename T, int CM, int ALIGN, int CC, bool GM>
 __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, const float (&m)[9], uint32_t b, int cbase, int X0, int Y0, int TWc, int THc,
-                                               bool box_pending, const int* s_box, float4* s_u4, float4* s_v4, int* s_acc, float* red_max) {
+                                               bool box_pending, const int* s_box, float4* s_u4, float4* s_v4, int* s_acc, float* red_max,
+                                               float (&gm_total)[9]) {
     const KmWarpGeom<float>& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
@@ -396,6 +472,16 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
     const T* gout_c[CC];
 #pragma unroll
     for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)b * g.C + (size_t)(cbase + c)) * dst_plane;
+    KmtGm<T, CC> gm;
+    gm.W = g.W; gm.H = g.H;
+    gm.mx = ALIGN ? (float)(g.W - 1) / 2 : (float)g.W / 2;
+    gm.my = ALIGN ? (float)(g.H - 1) / 2 : (float)g.H / 2;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+        gm.src_c[c] = GM ? a.src + ((size_t)b * g.C + (size_t)(cbase + c)) * src_plane : nullptr;
+        gm.fill[c] = (GM && g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : 0.0f;
+    }
+    gm.enabled = true;
 
     // ---- speculative bound: one pixel per thread on a KMT_NT-point lattice over the tile's own location in the output ----
     float vsample = 0.f;
@@ -506,22 +592,23 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
                     if (!first_band) __syncthreads();  // the previous band's readers are done with the tables
                     first_band = false;
                     if (tid < bd.bwb && (ib == i0)) {
-                        const KmlHalf h = kml_col_half<CM>(m, km_base_x<float, CM>(g, jb + tid));
-                        s_u4[tid] = make_float4(h.a, h.b, h.c, 0.f);
+                        const float u = km_base_x<float, CM>(g, jb + tid);
+                        const KmlHalf h = kml_col_half<CM>(m, u);
+                        s_u4[tid] = make_float4(h.a, h.b, h.c, u);
                     }
                     bool okr = true;
                     const int rt = tid - (KMT_NT - KMT_TAB);  // the row table is filled by the LAST threads: the first ones fill the columns
                     if (rt >= 0 && rt < bd.nrows) {
                         const float v = km_base_y<float, CM>(g, ib + rt);
                         const KmlHalf h = kml_row_half<CM>(m, v);
-                        s_v4[rt] = make_float4(h.a, h.b, h.c, 0.f);
+                        s_v4[rt] = make_float4(h.a, h.b, h.c, v);
                         okr = kml_row_guard<CM>(g, m, v);
                     }
                     const bool fast = __syncthreads_and((int)okr) != 0;  // every row of the band has safe division operands
                     const uint32_t uX0 = (uint32_t)X0, uY0 = (uint32_t)Y0, uTW = (uint32_t)TWc, uTH = (uint32_t)THc;
-                    if (!finite) kmt_scatter_band<T, CM, ALIGN, CC, false, false>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
-                    else if (fast) kmt_scatter_band<T, CM, ALIGN, CC, true, true>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
-                    else kmt_scatter_band<T, CM, ALIGN, CC, false, true>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
+                    if (!finite) kmt_scatter_band<T, CM, ALIGN, CC, false, false, GM>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits, gm, gm_total);
+                    else if (fast) kmt_scatter_band<T, CM, ALIGN, CC, true, true, GM>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits, gm, gm_total);
+                    else kmt_scatter_band<T, CM, ALIGN, CC, false, true, GM>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits, gm, gm_total);
                 }
             }
         }
@@ -530,6 +617,7 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
         const int redo = __syncthreads_or((int)exceeded);
         if (attempt == 0 && redo) {
             for (int e = tid; e < CC * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);  // discard the attempt
+            gm.enabled = false;  // the matrix-gradient sums do not depend on the scale: attempt 0 has formed them
             continue;  // the barriers at the top of attempt 1 order these stores before the next atomics
         }
         break;
@@ -584,11 +672,12 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
 #ifndef KMT_MIN_WAVES
 #define KMT_MIN_WAVES 6
 #endif
-template <typename T, int CM, int ALIGN>
+template <typename T, int CM, int ALIGN, bool GM>
 __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ float red_max[KMT_NW];
     __shared__ int s_box[8];
+    __shared__ double red_gm[GM ? KMT_NW : 1][9];
     static_assert(KMT_BAND_W + KMT_TAB <= KMT_NT || KMT_NT >= 2 * KMT_TAB, "the column and row tables are filled by disjoint threads");
 
     const KmWarpGeom<float>& g = a.g;
@@ -626,31 +715,55 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
     int* s_acc = (int*)(s_v4 + KMT_TAB);
 
     // channels in chunks of 3 (RGB: one pass); a remainder of 1 or 2 channels goes one channel at a time
+    float gm_total[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gm_total[k] = 0.f;
     int cbase = 0;
     for (; cbase + KMT_CC <= g.C; cbase += KMT_CC) {
         if (cbase) __syncthreads();  // the previous chunk's flush is done with the accumulators
-        kmt_tile_chunk<T, CM, ALIGN, KMT_CC>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max);
+        kmt_tile_chunk<T, CM, ALIGN, KMT_CC, GM>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max, gm_total);
     }
     for (; cbase < g.C; ++cbase) {
         if (cbase) __syncthreads();
-        kmt_tile_chunk<T, CM, ALIGN, 1>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max);
+        kmt_tile_chunk<T, CM, ALIGN, 1, GM>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max, gm_total);
+    }
+    if (GM) {  // per-thread fp32 partial sums -> fp64 wave / block reduction -> 9 fp64 atomics per block
+        if (CM == KM_COORD_AFFINE) gm_total[6] = gm_total[7] = gm_total[8] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double sum = km_wave_sum((double)gm_total[k]);
+            if (lane == 0) red_gm[wave][k] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            double sum = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < KMT_NW; ++wv) sum += red_gm[wv][threadIdx.x];
+            if (sum != 0.0) km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + threadIdx.x, sum);
+        }
     }
 }
 
+template <typename T, int CM, bool GM>
+static void kmt_launch_gm(const KmWarpTiledArgs<T>& a, hipStream_t s) {
+    if (a.g.align)
+        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 1, GM>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 0, GM>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+}
 template <typename T, int CM>
 static int kmt_launch(const KmWarpTiledArgs<T>& a, hipStream_t s) {
-    if (a.g.align)
-        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 1>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
-    else
-        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 0>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+    if (a.gmat) kmt_launch_gm<T, CM, true>(a, s);
+    else kmt_launch_gm<T, CM, false>(a, s);
     return km_check_launch("km_warp2d_bwd(tiled)");
 }
 
 template <typename T>
-static int kmt_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode,
-                   int norm_coords, int pad, int align, hipStream_t s) {
+static int kmt_run(const void* gout, const void* mat, void* gsrc, const void* src, double* gmat, const void* fill, int B, int C, int H, int W, int h, int w,
+                   int B_M, int coord_mode, int norm_coords, int pad, int align, hipStream_t s) {
     KmWarpTiledArgs<T> a;
     a.gout = (const T*)gout; a.mat = (const float*)mat; a.gsrc = (float*)gsrc;
+    a.src = (const T*)src; a.gmat = gmat; a.fill = (const float*)fill;
     KmWarpGeom<float>& g = a.g;
     km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, KM_INTERP_BILINEAR, pad, align);
     a.tiles_x = (uint32_t)((W + KMT_TW - 1) / KMT_TW);
@@ -680,12 +793,26 @@ int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc
 // 32-bit byte offsets inside a grad_out plane (the caller falls back to the generic kernel otherwise)
 int km_warp_bwd_tiled_dims_ok(int h, int w) { return ((uint64_t)h * (uint64_t)w * 4 < (1ull << 32)) ? 1 : 0; }
 
-// grad_src only; pad (zeros / fill) does not change it
-int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode,
-                          int norm_coords, int pad, int align, int dtype, hipStream_t s) {
+// 1 if the tile-owner kernel should also form the matrix gradient (one read of grad_out for both gradients)
+int km_warp_bwd_tiled_fuses_gm(int H, int W) {
+    // Measured on MI355X (256x3x512^2): fused 1.32 ms against 0.79 ms for the two launches - the gathers of the source taps
+    // serialise behind each pixel's grad_out load in the tile-owner loop, and their registers take away the second pixel in
+    // flight.  Kept for A/B timing: KM_WARP_BWD_FUSE=1.
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("KM_WARP_BWD_FUSE");
+        off = (e && e[0] == '1') ? 0 : 1;
+    }
+    // 32-bit byte offsets inside a source plane, 24-bit row / column counts, pair loads need two columns
+    return (!off && W >= 2 && (uint64_t)H * W * 4 < (1ull << 32) && W < (1 << 23) && H < (1 << 23)) ? 1 : 0;
+}
+
+// grad_src (pad zeros / fill does not change it) and, when gmat != nullptr, the matrix gradient (src and, for pad == fill, fill are read then)
+int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, const void* src, double* gmat, const void* fill, int B, int C, int H, int W,
+                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, int dtype, hipStream_t s) {
     switch (dtype) {
-        case KM_F32: return kmt_run<float>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
-        case KM_BF16: return kmt_run<km_bf16>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
-        default: return kmt_run<km_f16>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        case KM_F32: return kmt_run<float>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        case KM_BF16: return kmt_run<km_bf16>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        default: return kmt_run<km_f16>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
     }
 }

@@ -108,6 +108,7 @@ __device__ __forceinline__ void km_warp_gm_rows(const KmWarpGmArgs<T>& a, const 
             const T* __restrict__ gp[NCC];
 #pragma unroll
             for (int c = 0; c < NCC; ++c) { sp[c] = src_b + c * src_plane; gp[c] = gout_b + c * dst_plane; }  // wave-uniform plane bases
+            // (taking the x0 + 1 column from the next lane, as the forward does, measured slower here: 0.40 vs 0.38 ms)
             float go[KMG_GROUP][NCC], v[KMG_GROUP][NCC][4];
 #pragma unroll
             for (int q = 0; q < KMG_GROUP; ++q) {

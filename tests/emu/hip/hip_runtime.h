@@ -151,6 +151,20 @@ template <typename T> inline T __shfl_down(T v, unsigned off, int width = 64) {
     memcpy(&r, &got, sizeof(T));
     return ok ? r : v;
 }
+// DPP row_shl:1 (km_common.h km_next16): lane i of a row of 16 reads lane i + 1, the last lane of the row its own value
+#define KM_NEXT16 1
+inline uint32_t km_next16(uint32_t v) { return __shfl_down(v, 1, 16); }
+inline float km_next16(float v) { return __shfl_down(v, 1, 16); }
+inline float km_prev16(float v) {  // row_shr:1
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(float));
+    const int lane = emu::lane_id();
+    bool ok = false;
+    const uint64_t got = emu::wave_exchange(bits, (lane & 15) ? lane - 1 : lane, &ok);
+    float r;
+    memcpy(&r, &got, sizeof(float));
+    return ok ? r : v;
+}
 inline int emu_readfirstlane(int v) {
     bool ok = false;
     return (int)(uint32_t)emu::wave_exchange((uint64_t)(uint32_t)v, -1, &ok);
