@@ -4,16 +4,25 @@
     y = gaussian_blur2d(warp_perspective(x, M, (512, 512)), (5, 5), (1.5, 1.5));  y.backward(grad_out)
 
 with x (B,3,512,512) fp32 requiring grad and M (B,3,3) requiring grad - BASELINE.json configs[1]
-(B = 256 per GPU; inputs follow benchmarks/geometry/flagship.py:89-107 of the reference:
-uniform-noise images, image quad perturbed by 8*randn).  Batches shard across GPUs with no
-data-path collective (weak scaling: every rank owns B images).
+(inputs follow benchmarks/geometry/flagship.py:89-107 of the reference: uniform-noise images, image quad
+perturbed by 8*randn).  Batches shard across GPUs with no data-path collective.
 
-    python bench.py                      # 1 GPU, prints ONE JSON line
+    python bench.py                      # 1 GPU, B = 256, prints ONE JSON line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong] [--gather p2p]
 
-The JSON line carries `roofline` (dominant kernel, HIP-event timed on the launch stream, algorithmic
-bytes from SURVEY.md 8(d)) and `cpu_baseline` (the reference's op sequence on the host cores).
+  --scaling weak    every rank owns --batch images (default; total work grows with N)
+  --scaling strong  --batch images in total, rank r owns its contiguous slice (B = 256 over N GPUs)
+  --gather MODE     additionally time the reassembly of the outputs on every rank (never part of `value`):
+                    all_gather | p2p (direct peer exchange) | chunked (compute and exchange overlapped, 4 sub-batches)
+
+The JSON line carries
+  roofline       the dominant public op of the step (HIP-event timed through the C ABI on the launch stream) against its
+                 ALGORITHMIC bytes per SURVEY.md 8(d): warp fwd 2e, blur fwd 2e, blur bwd 2e, warp bwd 3e per element;
+                 `kernels` holds every launch with the bytes that launch itself must move
+  cpu_baseline   the reference's op sequence on the host cores (thread sweep, median + IQR, benchmarks/common.py:45-60 style)
+  generic_gpu    the same op sequence through PyTorch-ROCm's generic kernels (grid chain + F.grid_sample + pad + conv2d) on
+                 this GPU: what the north star says not to be
 """
 from __future__ import annotations
 
@@ -28,7 +37,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (measured streaming copy on these boxes: 6.2 TB/s)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse_args():
@@ -36,12 +46,15 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--batch", type=int, default=256, help="images per GPU")
+    p.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling) or in total (strong scaling)")
     p.add_argument("--size", type=int, default=512)
     p.add_argument("--channels", type=int, default=3)
+    p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    p.add_argument("--gather", choices=("none", "all_gather", "p2p", "chunked"), default="none",
+                   help="also time the reassembly of the outputs on every rank (reported separately)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-batch", type=int, default=16, help="images in the CPU baseline sample")
-    p.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the outputs (reported separately)")
+    p.add_argument("--no-extras", action="store_true", help="skip other_configs / generic_gpu (profiling runs)")
+    p.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU baseline sample")
     return p.parse_args()
 
 
@@ -76,8 +89,8 @@ def event_time_ms(fn, iters):
 
 
 def kernel_roofline(x, M, go, size, iters):
-    """Times each of the four hot kernels by calling the C ABI directly (pre-allocated buffers, no
-    allocator / autograd in the timed loop) and returns per-kernel stats."""
+    """Times every launch of the step and the four public ops by calling the C ABI directly (pre-allocated buffers, no allocator /
+    autograd in the timed loop).  Returns (per-launch stats, per-op stats)."""
     from kornia_amd import _native as N
     from kornia_amd.filters.gaussian import _cached_taps
 
@@ -112,99 +125,170 @@ def kernel_roofline(x, M, go, size, iters):
     def warp_bwd_gmat():  # forward-shaped reduction: grad wrt the homography
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), None, gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wm")
 
-    def warp_bwd():  # the public op = both kernels back to back
+    def warp_bwd():  # the public op = both launches back to back
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
 
-    # algorithmic bytes per launch = compulsory traffic of what the kernel computes (DESIGN.md "Roofline accounting"):
-    # every tensor it must read once + every tensor it must write once, e bytes per element
-    stats = {}
-    for name, fn, nbytes in (
-        ("km_warp_fwd_bz_kernel", warp_fwd, 2 * e * n_el),        # read src, write out
-        ("km_blur_reg_kernel<fwd>", blur_fwd, 2 * e * n_el),      # read x, write y
-        ("km_blur_reg_kernel<bwd>", blur_bwd, 2 * e * n_el),      # read grad_y, write grad_x
-        ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el),  # read grad_out, write grad_src
-        ("km_warp_gm_kernel", warp_bwd_gmat, 2 * e * n_el),       # read grad_out, read src
+    # per LAUNCH: the bytes that launch itself must move (every tensor it reads once + every tensor it writes once); the two
+    # backward launches both read grad_out, so their sum (4e) exceeds the op's algorithmic 3e - which is why the op line exists
+    kernels = {}
+    for name, fn, nbytes, what in (
+        ("km_warp_fwd_lean_kernel", warp_fwd, 2 * e * n_el, "read src, write out"),
+        ("km_blur_reg_kernel<fwd>", blur_fwd, 2 * e * n_el, "read x, write y"),
+        ("km_blur_reg_kernel<bwd>", blur_bwd, 2 * e * n_el, "read grad_y, write grad_x"),
+        ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el, "read grad_out, write grad_src"),
+        ("km_warp_gm_kernel", warp_bwd_gmat, 2 * e * n_el, "read grad_out, read src"),
     ):
         ms = event_time_ms(fn, iters)
-        stats[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1)}
-    ms = event_time_ms(warp_bwd, iters)
-    # the public op km_warp2d_bwd (both launches) against SURVEY 8(d)'s 3e: read grad_out, read src, write grad_src
-    stats["op:km_warp2d_bwd"] = {"ms": round(ms, 4), "alg_bytes": 3 * e * n_el, "GBps": round(3 * e * n_el / ms / 1e6, 1)}
-    return stats
+        kernels[name] = {"ms": round(ms, 4), "launch_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "moves": what}
+    # per PUBLIC OP: SURVEY 8(d)'s algorithmic bytes (compulsory traffic at the API boundary)
+    ops = {}
+    for name, fn, mult in (("km_warp2d_fwd", warp_fwd, 2), ("km_filter2d_sep_fwd", blur_fwd, 2), ("km_filter2d_sep_bwd_input", blur_bwd, 2),
+                           ("km_warp2d_bwd", warp_bwd, 3)):
+        ms = kernels["km_warp_fwd_lean_kernel"]["ms"] if name == "km_warp2d_fwd" else (
+            kernels["km_blur_reg_kernel<fwd>"]["ms"] if name == "km_filter2d_sep_fwd" else (
+                kernels["km_blur_reg_kernel<bwd>"]["ms"] if name == "km_filter2d_sep_bwd_input" else event_time_ms(fn, iters)))
+        nbytes = mult * e * n_el
+        ops[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return kernels, ops
+
+
+def generic_torch_step_factory():
+    """The reference's op sequence for the headline step written with plain torch ops (what kornia executes on a GPU today:
+    normalise / invert the homography, build the (B,h,w,2) grid, F.grid_sample, reflect-pad + depthwise conv2d twice)."""
+    import torch.nn.functional as F
+
+    def inv3(m):
+        a, b, c = m[..., 0], m[..., 1], m[..., 2]
+        bc, ca, ab = torch.linalg.cross(b, c), torch.linalg.cross(c, a), torch.linalg.cross(a, b)
+        det = (a * bc).sum(-1, keepdim=True)
+        return torch.stack([bc, ca, ab], dim=-2) / det[..., None]
+
+    def npix(hh, ww, dev):
+        return torch.tensor([[2.0 / (ww - 1), 0.0, -1.0], [0.0, 2.0 / (hh - 1), -1.0], [0.0, 0.0, 1.0]], device=dev)[None]
+
+    def step(x, M, go, S):
+        x = x.detach().requires_grad_()
+        M = M.detach().requires_grad_()
+        dev = x.device
+        A = npix(S, S, dev) @ (M @ inv3(npix(x.shape[-2], x.shape[-1], dev)))
+        m = inv3(A)
+        ys, xs = torch.meshgrid(torch.linspace(-1, 1, S, device=dev), torch.linspace(-1, 1, S, device=dev), indexing="ij")
+        u, v = xs[None], ys[None]
+        den = m[:, 2, 0, None, None] * u + m[:, 2, 1, None, None] * v + m[:, 2, 2, None, None]
+        gx = (m[:, 0, 0, None, None] * u + m[:, 0, 1, None, None] * v + m[:, 0, 2, None, None]) / den
+        gy = (m[:, 1, 0, None, None] * u + m[:, 1, 1, None, None] * v + m[:, 1, 2, None, None]) / den
+        w = F.grid_sample(x, torch.stack([gx, gy], -1), mode="bilinear", padding_mode="zeros", align_corners=True)
+        k = torch.tensor([0.12007838, 0.23388076, 0.29208172, 0.23388076, 0.12007838], device=dev)
+        C = x.shape[1]
+        y = F.conv2d(F.pad(w, [2, 2, 0, 0], mode="reflect"), k.view(1, 1, 1, 5).expand(C, 1, 1, 5), groups=C)
+        y = F.conv2d(F.pad(y, [0, 0, 2, 2], mode="reflect"), k.view(1, 1, 5, 1).expand(C, 1, 5, 1), groups=C)
+        y.backward(go)
+        return y
+
+    return step
+
+
+def generic_gpu_baseline(dev, S, C):
+    B = 32
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, C, S, S, generator=g).to(dev)
+    M = flagship_homographies(B, S, S, g).to(dev)
+    go = torch.rand(B, C, S, S, generator=g).to(dev)
+    step = generic_torch_step_factory()
+    for _ in range(2):
+        step(x, M, go, S)
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        step(x, M, go, S)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B * S * S / dt / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(dt * 1e3, 3),
+            "sample": f"B={B}x{C}x{S}x{S} fp32 fwd+bwd, torch {torch.__version__}: grid chain + F.grid_sample + reflect pad + depthwise conv2d (MIOpen)"}
 
 
 def other_configs(dev):
-    """Informational: the parity configurations of BASELINE.json (configs[2..4]) timed through the public Python API on one
-    GPU (HIP events, 10 iterations).  Not part of `value`; failures here never affect the bench line."""
+    """Informational: the parity configurations of BASELINE.json (configs[2..4]) and the callers of the path, timed through the public
+    Python API on one GPU (HIP events, 10 iterations).  Not part of `value`; failures here never affect the bench line."""
     import kornia_amd as K
+    import kornia_amd.augmentation as A
 
     out = {}
 
-    def t(fn):
-        return round(event_time_ms(fn, 10), 4)
+    def t(fn, n=10):
+        return round(event_time_ms(fn, n), 4)
 
-    try:
+    try:  # config 3: 256 images per GPU, bf16, RandomAffine + ColorJitter + RandomGaussianBlur with device-resident parameters (p = 1)
         with torch.no_grad():
             B = 256
+            g = torch.Generator().manual_seed(0)
             x = torch.rand(B, 3, 224, 224, device=dev).bfloat16()
-            ang = (torch.rand(B, device=dev) - 0.5) * 30
-            A = K.get_affine_matrix2d(torch.zeros(B, 2, device=dev), torch.full((B, 2), 111.5, device=dev), 0.8 + 0.4 * torch.rand(B, 2, device=dev), ang)
-            f = [0.8 + 0.4 * torch.rand(B, device=dev) for _ in range(3)] + [(torch.rand(B, device=dev) - 0.5) * 0.2]
-            sig = 0.1 + 1.9 * torch.rand(B, 2, device=dev)
-            out["cfg3_bf16_256x3x224_affine+colorjitter+blur_ms"] = t(
-                lambda: K.gaussian_blur2d(K.enhance.color_jitter(K.warp_affine(x, A[:, :2], (224, 224), align_corners=False), *f), (5, 5), sig))
+            Pa = {"translations": (torch.rand(B, 2, generator=g) - 0.5) * 44.8, "center": torch.full((B, 2), 111.5), "scale": (0.8 + 0.4 * torch.rand(B, 1, generator=g)).expand(B, 2).contiguous(),
+                  "angle": (torch.rand(B, generator=g) - 0.5) * 30, "shear_x": (torch.rand(B, generator=g) - 0.5) * 10, "shear_y": torch.zeros(B)}
+            Pj = {"brightness_factor": 0.8 + 0.4 * torch.rand(B, generator=g), "contrast_factor": 0.8 + 0.4 * torch.rand(B, generator=g),
+                  "saturation_factor": 0.8 + 0.4 * torch.rand(B, generator=g), "hue_factor": (torch.rand(B, generator=g) - 0.5) * 0.2}
+            Pb = {"sigma": 0.1 + 1.9 * torch.rand(B, generator=g)}
+            Pa, Pj, Pb = ({k: v.to(dev) for k, v in d.items()} for d in (Pa, Pj, Pb))
+            order = [0, 2, 3, 1]
+
+            def seq(xx, a, j, b):
+                return A.random_gaussian_blur(A.color_jitter(A.random_affine(xx, a), j, order), b)
+
+            M = A.affine_matrix(Pa, dev)
+            w = K.warp_affine(x, M[:, :2], (224, 224), align_corners=False)
+            c = A.color_jitter(w, Pj, order)
+            out["cfg3_bf16_256x3x224_eager_ms"] = t(lambda: seq(x, Pa, Pj, Pb))
+            out["cfg3_breakdown_ms"] = {
+                "affine_matrix": t(lambda: A.affine_matrix(Pa, dev)), "warp_affine": t(lambda: K.warp_affine(x, M[:, :2], (224, 224), align_corners=False)),
+                "color_jitter": t(lambda: A.color_jitter(w, Pj, order)), "gaussian_blur(per-sample sigma)": t(lambda: A.random_gaussian_blur(c, Pb))}
+        step = K.graph.capture(seq, x, Pa, Pj, Pb, no_grad=True)
+        out["cfg3_bf16_256x3x224_hip_graph_replay_ms"] = t(step.replay)
+    except Exception as e:  # informational only
+        out["error_cfg3"] = f"{type(e).__name__}: {e}"
+    try:
+        with torch.no_grad():
             x = torch.rand(64, 1, 1080, 1920, device=dev)
             R = K.get_rotation_matrix2d(torch.tensor([[959.5, 539.5]], device=dev).repeat(64, 1), torch.full((64,), 2.0, device=dev), torch.ones(64, 2, device=dev))
             out["cfg4_64x1x1080x1920_spatial_gradient_ms"] = t(lambda: K.spatial_gradient(x))
             out["cfg4_64x1x1080x1920_warp_affine_bicubic_ms"] = t(lambda: K.warp_affine(x, R, (1080, 1920), mode="bicubic"))
+            del x
         x = torch.rand(128, 3, 256, 256, device=dev)
         H = (torch.eye(3, device=dev)[None] + 0.01 * torch.randn(128, 3, 3, device=dev)).requires_grad_()
-        go = torch.rand(128, 3, 256, 256, device=dev)
+        tgt = torch.rand(128, 3, 256, 256, device=dev)
 
-        def learn_h():
-            (g,) = torch.autograd.grad(K.homography_warp(x, H, (256, 256)), H, go)
-            return g
+        def learn_h(a, hm, tg):
+            (gh,) = torch.autograd.grad(torch.nn.functional.l1_loss(K.homography_warp(a, hm, (256, 256)), tg), hm)
+            return gh
 
-        out["cfg5_128x3x256x256_homography_warp_fwd+gradH_ms"] = t(learn_h)
-    except Exception as e:  # informational only
-        out["error"] = f"{type(e).__name__}: {e}"
-    try:  # SURVEY 8(f) rank 3: the pyramid / registration stack that consumes config 5
+        out["cfg5_128x3x256x256_l1(homography_warp)+gradH_eager_ms"] = t(lambda: learn_h(x, H, tgt))
+        gstep = K.graph.capture(learn_h, x, H, tgt)
+        out["cfg5_128x3x256x256_l1(homography_warp)+gradH_hip_graph_replay_ms"] = t(gstep.replay)
+        T = K.geometry.transform
+
+        def fused(a, hm, tg):
+            (gh,) = torch.autograd.grad(T.masked_warp_loss(a, tg, hm, threshold=None), hm)
+            return gh
+
+        out["cfg5_128x3x256x256_fused_loss+gradH_one_launch_eager_ms"] = t(lambda: fused(x, H, tgt))
+        out["cfg5_128x3x256x256_fused_loss+gradH_one_launch_hip_graph_replay_ms"] = t(K.graph.capture(fused, x, H, tgt).replay)
+        # transform_points at config 5's grid size (512 x 65536 x 2 is one GPU's share of warp_grid): 2e bytes per coordinate
+        P = torch.rand(512, 65536, 2, device=dev)
+        Tm = torch.eye(3, device=dev)[None].repeat(512, 1, 1) + 0.01 * torch.randn(512, 3, 3, device=dev)
+        with torch.no_grad():
+            ms = event_time_ms(lambda: K.transform_points(Tm, P), 10)
+        out["transform_points_512x65536x2"] = {"ms": round(ms, 4), "GBps": round(2 * P.numel() * 4 / ms / 1e6, 1), "mfma": "not used: K = 3 contraction, 15 flop per 16 bytes (profiles/README.md)"}
+        del P
+    except Exception as e:
+        out["error_cfg45"] = f"{type(e).__name__}: {e}"
+    try:  # SURVEY 8(f) ranks 3-4: the pyramid / registration stack and the remaining callers
         T = K.geometry.transform
         with torch.no_grad():
             x = torch.rand(256, 3, 512, 512, device=dev)
-            out["pyrdown_256x3x512x512_fused_ms"] = t(lambda: T.pyrdown(x))
-            os.environ["KM_PYRDOWN_ALGO"] = "separable"  # the opt-in 5 + 5 tap evaluation (csrc/km_pyramid.hip), timed for the A/B decision
-            try:
-                out["pyrdown_256x3x512x512_separable_variant_ms"] = t(lambda: T.pyrdown(x))
-            finally:
-                del os.environ["KM_PYRDOWN_ALGO"]
+            out["pyrdown_256x3x512x512_ms"] = t(lambda: T.pyrdown(x))
             out["build_pyramid_5_levels_256x3x512x512_ms"] = t(lambda: T.build_pyramid(x, 5))
             del x
-        xs = torch.rand(128, 3, 256, 256, device=dev)
-        xd = torch.rand(128, 3, 256, 256, device=dev)
-        H = (torch.eye(3, device=dev)[None] + 0.01 * torch.randn(128, 3, 3, device=dev)).requires_grad_()
-
-        def level_loss():
-            (g,) = torch.autograd.grad(T.masked_warp_loss(xs, xd, H), H)
-            return g
-
-        out["cfg5_128x3x256x256_masked_l1_loss+gradH_one_launch_ms"] = t(level_loss)
-
-        def cfg5_step():
-            (g,) = torch.autograd.grad(T.masked_warp_loss(xs, xd, H, threshold=None), H)
-            return g
-
-        out["cfg5_128x3x256x256_l1_loss(homography_warp)+gradH_one_launch_ms"] = t(cfg5_step)
-    except Exception as e:  # informational only
-        out["error_next_rows"] = f"{type(e).__name__}: {e}"
-    try:  # the remaining callers of the path (SURVEY 8(f) ranks 3-4), small so that the default run stays short
-        T = K.geometry.transform
-        with torch.no_grad():
             x = torch.rand(64, 3, 256, 256, device=dev)
             out["pyrup_64x3x256x256_to_512_ms"] = t(lambda: T.pyrup(x))
-            x = torch.rand(8, 1, 512, 512, device=dev)
-            sp = T.ScalePyramid().to(dev)
-            out["scale_pyramid_8x1x512x512_ms"] = t(lambda: sp(x))
             x = torch.rand(16, 3, 512, 512, device=dev)
             out["canny_16x3x512x512_ms"] = t(lambda: K.filters.canny(x))
     except Exception as e:  # informational only
@@ -213,26 +297,33 @@ def other_configs(dev):
 
 
 def cpu_baseline(size, channels, cpu_batch):
-    """The reference's CPU path (its torch op sequence, oracle/torch_ref.py) on the host cores, on a
-    bounded sample of the same workload."""
+    """The reference's CPU path (its torch op sequence, oracle/torch_ref.py) on the host cores of this box, on a bounded sample of
+    the same workload: median + IQR per thread count (torch.utils.benchmark blocked_autorange, like benchmarks/common.py:45-60),
+    the best thread count is `value`.  Mpix/s is batch-normalised, so the sample batch is stated, not scaled."""
+    import torch.utils.benchmark as tbench
+
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_ref  # test infrastructure: baseline leg only
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    logical = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     x = torch.rand(cpu_batch, channels, size, size, generator=g)
     M = flagship_homographies(cpu_batch, size, size, g)
     go = torch.rand(cpu_batch, channels, size, size, generator=g)
-    torch_ref.headline_step(x, M, go, (size, size))  # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        torch_ref.headline_step(x, M, go, (size, size))
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 20:
-            break
-    mpix = cpu_batch * size * size * reps / dt / 1e6
+    sweep = {}
+    candidates = sorted({min(logical, n) for n in (8, 32, max(1, logical // 2))})
+    old = torch.get_num_threads()
+    try:
+        for nt in candidates:
+            torch.set_num_threads(nt)
+            torch_ref.headline_step(x, M, go, (size, size))  # warm-up
+            m = tbench.Timer(stmt="f(x, M, go, s)", globals={"f": torch_ref.headline_step, "x": x, "M": M, "go": go, "s": (size, size)},
+                             num_threads=nt).blocked_autorange(min_run_time=3.0)
+            sweep[str(nt)] = {"median_ms": round(m.median * 1e3, 2), "iqr_ms": round(m.iqr * 1e3, 2), "runs": len(m.times),
+                              "Mpix_s": round(cpu_batch * size * size / m.median / 1e6, 3)}
+    finally:
+        torch.set_num_threads(old)
+    best = max(sweep, key=lambda k: sweep[k]["Mpix_s"])
     # second CPU figure: the plain-C oracle (OpenMP over the same host cores), fwd + bwd of the same sample
     import oracle as c_oracle
 
@@ -242,14 +333,25 @@ def cpu_baseline(size, channels, cpu_batch):
     gw = c_oracle.gaussian_blur2d_backward(go, w, (5, 5), (1.5, 1.5))
     c_oracle.warp_perspective_backward(gw, x, M, (size, size))
     c_dt = time.perf_counter() - t1
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
-        "value": round(mpix, 3),
+        "value": sweep[best]["Mpix_s"],
         "unit": "Mpix/s",
-        "cores": torch.get_num_threads(),
+        "cores": int(best),
         "kind": "port",
-        "sample": f"{reps} fwd+bwd steps of B={cpu_batch}x{channels}x{size}x{size} fp32 through the reference's PyTorch-CPU op sequence (oracle/torch_ref.py), {dt:.1f} s",
+        "sample": f"fwd+bwd steps of B={cpu_batch}x{channels}x{size}x{size} fp32 through the reference's PyTorch-CPU op sequence (oracle/torch_ref.py), "
+                  f"blocked_autorange >= 3 s per thread count; median {sweep[best]['median_ms']} ms, IQR {sweep[best]['iqr_ms']} ms at {best} threads",
+        "host": f"{model}, {logical} logical CPUs",
+        "thread_sweep": sweep,
         "c_oracle_value": round(cpu_batch * size * size / c_dt / 1e6, 3),
-        "c_oracle_note": f"plain-C oracle (OpenMP, {os.cpu_count()} threads), one fwd+bwd of the same sample in {c_dt:.2f} s",
+        "c_oracle_note": f"plain-C oracle (OpenMP, {logical} threads), one fwd+bwd of the same sample in {c_dt:.2f} s",
     }
 
 
@@ -279,8 +381,14 @@ def main():
             dist.init_process_group(backend=backend)
 
     import kornia_amd as K
+    from kornia_amd.distributed import gather_batch, shard_bounds
 
-    B, C, S = args.batch, args.channels, args.size
+    C, S = args.channels, args.size
+    if args.scaling == "strong":
+        lo, hi = shard_bounds(args.batch, world, rank)
+        B, global_batch = hi - lo, args.batch
+    else:
+        B, global_batch = args.batch, world * args.batch
     gen = torch.Generator().manual_seed(1000 * rank)
     ggen = torch.Generator(device=dev).manual_seed(1000 * rank)
     x = torch.rand(B, C, S, S, device=dev, generator=ggen).requires_grad_()
@@ -325,47 +433,78 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    gather_ms = None
-    if args.gather and dist is not None and backend == "nccl":
-        outs = torch.empty(world * B, C, S, S, device=dev)
-        dist.all_gather_into_tensor(outs, y.detach())
-        barrier()
-        t1 = time.perf_counter()
-        dist.all_gather_into_tensor(outs, y.detach())
-        barrier()
-        gather_ms = (time.perf_counter() - t1) * 1e3
-        del outs
+    # ---- optional: the reassembly of the (global_batch, C, S, S) output on every rank, timed on its own ----
+    gather = None
+    if args.gather != "none" and dist is not None:
+        yd = y.detach()
+        with torch.no_grad():
+            def fwd_only(xs, Ms):
+                return K.gaussian_blur2d(K.warp_perspective(xs, Ms, (S, S)), (5, 5), (1.5, 1.5))
+
+            def do():
+                if args.gather == "chunked":  # forward of sub-batch i+1 overlapped with the exchange of sub-batch i (forward only)
+                    from kornia_amd.distributed import _peer_exchange  # noqa: F401  (documented in kornia_amd/distributed.py)
+                    outs = torch.empty(global_batch, C, S, S, device=dev)
+                    spans_all = [shard_bounds(global_batch, world, r) for r in range(world)]
+                    pend = []
+                    for c4 in range(4):
+                        spans = []
+                        for rlo, rhi in spans_all:
+                            clo, chi = shard_bounds(rhi - rlo, 4, c4)
+                            spans.append((rlo + clo, rlo + chi))
+                        clo, chi = spans[rank]
+                        llo = clo - spans_all[rank][0]
+                        outs[clo:chi].copy_(fwd_only(x.detach()[llo:llo + (chi - clo)], M.detach()[llo:llo + (chi - clo)]))
+                        pend.extend(_peer_exchange(outs, spans, None))
+                    for r in pend:
+                        r.wait()
+                    return outs
+                return gather_batch(yd, global_batch, None, "p2p" if args.gather == "p2p" else "all_gather")
+
+            do()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                do()
+            barrier()
+            gms = (time.perf_counter() - t1) / 5 * 1e3
+        gather = {"mode": args.gather, "ms": round(gms, 3), "bytes_received_per_rank": (global_batch - B) * C * S * S * 4,
+                  "note": "chunked = forward of 4 sub-batches overlapped with their peer exchange; others = exchange of a finished output"}
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * S * S * args.steps / elapsed / 1e6
+    value = global_batch * S * S * args.steps / elapsed / 1e6
 
     if rank == 0:
         with torch.no_grad():
-            kstats = kernel_roofline(x.detach(), M.detach(), go, S, max(5, min(args.steps, 20)))
-        dom = max((k for k in kstats if not k.startswith("op:")), key=lambda k: kstats[k]["ms"])
-        achieved = kstats[dom]["GBps"]
-        # HBM traffic of the dominant kernel: rocprofv3 PMC cannot run inside this process, so the figure is the
-        # committed measurement of this very command/config (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE)
+            kstats, ops = kernel_roofline(x.detach(), M.detach(), go, S, max(5, min(args.steps, 20)))
+        dom_op = max(ops, key=lambda k: ops[k]["ms"])
+        dom_kernel = max(kstats, key=lambda k: kstats[k]["ms"])
+        # HBM traffic of the dominant op: rocprofv3 PMC cannot run inside this process, so the figure is the committed
+        # measurement of this very command / config (profiles/r02_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if (B, C, S) == (256, 3, 512) and os.path.exists(tpath):
-            rocname = {"km_warp_bwd_tiled_kernel": "km_warp_bwd_tiled_kernel", "km_warp_gm_kernel": "km_warp_gm_kernel",
-                       "km_warp_fwd_bz_kernel": "km_warp_fwd_bz_kernel", "km_blur_reg_kernel<fwd>": "km_blur_reg_kernel<float, 5, false>",
-                       "km_blur_reg_kernel<bwd>": "km_blur_reg_kernel<float, 5, true>"}[dom]
-            for kname, rec in json.load(open(tpath))["kernels"].items():
-                if rocname in kname:
-                    traffic = rec["hbm_bytes_per_launch"]
+        if (B, C, S) == (256, 3, 512) and os.path.exists(PMC_FILE):
+            pmc = json.load(open(PMC_FILE)).get("kernels", {})
+            want = {"km_warp2d_bwd": ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_lean_kernel",),
+                    "km_filter2d_sep_fwd": ("km_blur_reg_kernel<float, 5, false>",), "km_filter2d_sep_bwd_input": ("km_blur_reg_kernel<float, 5, true>",)}[dom_op]
+            tot = 0
+            for frag in want:
+                hit = [rec["hbm_bytes_per_launch"] for kname, rec in pmc.items() if frag in kname]
+                tot = tot + hit[0] if hit and tot is not None else None
+            traffic = tot
         roofline = {
             "bound": "hbm",
-            "kernel": dom,
-            "achieved": achieved,
+            "kernel": {"km_warp2d_bwd": "km_warp2d_bwd = km_warp_bwd_tiled_kernel + km_warp_gm_kernel (dominant launch: " + dom_kernel + ")"}.get(dom_op, dom_op),
+            "achieved": ops[dom_op]["GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac": ops[dom_op]["frac_of_hbm_peak"],
             "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)" if traffic else None,
-            "kernel_ms": kstats[dom]["ms"],
-            "alg_bytes_per_launch": kstats[dom]["alg_bytes"],
+            "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)" if traffic else None,
+            "op_ms": ops[dom_op]["ms"],
+            "alg_bytes_per_call": ops[dom_op]["alg_bytes"],
+            "accounting": "SURVEY.md 8(d): warp fwd 2e, blur fwd 2e, blur bwd 2e, warp bwd 3e bytes per element; op = every launch of the public entry point",
+            "dominant_launch": {"name": dom_kernel, **kstats[dom_kernel], "frac_of_hbm_peak": round(kstats[dom_kernel]["GBps"] / HBM_PEAK_GBS, 4)},
+            "measured_streaming_copy_GBps": 6200.0,
         }
         alg_step_bytes = 36 * B * C * S * S
         result = {
@@ -377,23 +516,28 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: warp_perspective bilinear + GaussianBlur2d k=5 sigma=1.5, B={B}x{C}x{S}x{S} fp32 fwd+bwd (grad wrt image and homography), per GPU",
-                "global_batch": world * B,
-                "parallelism": f"batch-shard x{world}, no data-path collective",
+                "workload": f"configs[1]: warp_perspective bilinear + GaussianBlur2d k=5 sigma=1.5, B={B}x{C}x{S}x{S} fp32 fwd+bwd (grad wrt image and homography) per GPU",
+                "global_batch": global_batch,
+                "parallelism": f"batch-shard x{world} ({args.scaling} scaling), no data-path collective",
             },
             "step_GBps_algorithmic": round(alg_step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_frac_of_hbm_peak": round(alg_step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roofline,
+            "ops": ops,
             "kernels": kstats,
         }
-        if gather_ms is not None:
-            result["all_gather_ms"] = round(gather_ms, 3)
-        if world == 1:
+        if gather is not None:
+            result["gather"] = gather
+        if world == 1 and not args.no_extras:
+            try:
+                result["generic_gpu"] = generic_gpu_baseline(dev, S, C)
+            except Exception as e:  # informational only
+                result["generic_gpu"] = {"error": f"{type(e).__name__}: {e}"}
             result["other_configs"] = other_configs(x.device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(S, C, args.cpu_batch)

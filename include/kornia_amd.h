@@ -164,6 +164,10 @@ int km_pyrdown_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, i
                    int dtype, void* stream);
 int km_resize_bilinear_fwd(const void* x, void* y, int B, int C, int H, int W, int oh, int ow, int align, int dtype,
                            void* stream);
+/* adjoint of the resize (aten::upsample_bilinear2d_backward): gy (B,C,oh,ow) -> gx (B,C,H,W), written completely;
+ * gather form, deterministic */
+int km_resize_bilinear_bwd(const void* gy, void* gx, int B, int C, int H, int W, int oh, int ow, int align, int dtype,
+                           void* stream);
 
 /* ---- masked photometric loss of a warp + its matrix gradient, one launch ------------------------
  * Replaces ImageRegistrator.get_single_level_loss (kornia/geometry/transform/image_registrator.py:225-245) and its
@@ -186,6 +190,18 @@ int km_transform_points_fwd(const void* T, const void* pts, void* out, int B, in
 /* gpts (B,N,D) nullable; gT (B_T,(D+1)^2) float64 accumulators, zeroed by the caller, nullable */
 int km_transform_points_bwd(const void* gout, const void* T, const void* pts, void* gpts, void* gT, int B, int N, int D,
                             int B_T, int dtype, void* stream);
+
+/* ---- augmentation layer ---------------------------------------------------
+ * km_gaussian_taps_fwd replaces get_gaussian_kernel1d x 2 inside gaussian_blur2d for a per-sample sigma
+ * (kornia/filters/kernels.py:77-120, kornia/filters/gaussian.py:111-114; RandomGaussianBlur.apply_transform,
+ * kornia/augmentation/_2d/intensity/gaussian_blur.py:95-114):  sigma (B,2) fp32 = (sigma_y, sigma_x) per sample,
+ * taps_x (B,kx) from sigma[:,1], taps_y (B,ky) from sigma[:,0], fp32, normalised to sum 1; 1 <= kx, ky <= 64.
+ * km_select_samples_fwd replaces the per-sample probability blend of _AugmentationBase.transform_inputs
+ * (kornia/augmentation/base.py:348-393, torch.where(to_apply, transformed, input)):
+ * out[b] = apply[b] ? transformed[b] : original[b], apply (B) uint8 on the device, n_per_sample elements of dtype per sample. */
+int km_gaussian_taps_fwd(const void* sigma, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream);
+int km_select_samples_fwd(const void* transformed, const void* original, const void* apply, void* out, int B,
+                          long long n_per_sample, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ The ops run hand-written HIP kernels through a C-ABI shared library (``include/k
 ``kornia_amd/lib/libkornia_amd.so``, built by ``python -m kornia_amd.build``).  There is no
 PyTorch/CPU fallback: tensors must be on a HIP device and the library must be built.
 """
-from . import core, enhance, filters, geometry
+from . import augmentation, core, enhance, filters, geometry, graph
 from ._native import NativeLibraryError, is_built, library_path
 from .filters import (
     GaussianBlur2d,

@@ -49,7 +49,10 @@ _PROTOTYPES = {
     "km_color_jitter_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "km_pyrdown_fwd": [_P, _P] + [_I] * 9 + [_P],
     "km_resize_bilinear_fwd": [_P, _P] + [_I] * 8 + [_P],
+    "km_resize_bilinear_bwd": [_P, _P] + [_I] * 8 + [_P],
     "km_warp_masked_loss": [_P, _P, _P, _P] + [_I] * 11 + [c_double, _I, _P],
+    "km_gaussian_taps_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "km_select_samples_fwd": [_P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P],
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
     "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
 }

@@ -6,12 +6,14 @@ _2d/intensity/color_jitter.py:126-159, _2d/intensity/gaussian_blur.py:95-114) sp
 blend of ``_AugmentationBase.transform_inputs``, augmentation/base.py:348-393).  This module is the second half, taking the
 parameter dictionaries the reference's generators produce (or a replay of them, ``AugmentationSequential(x, params=...)``):
 
-* :func:`random_affine` - parameters (B,...) -> pixel matrix (``km_affine_matrix2d_fwd``) -> normalise / invert -> sample,
-  with the per-sample apply mask folded into the matrix (a skipped sample gets the identity, which the sampler reproduces
-  bit for bit when source and destination sizes agree);
-* :func:`color_jitter` - the four adjustments in the sampled order, one fused kernel;
-* :func:`random_gaussian_blur` - per-sample sigma -> taps -> separable blur;
-* :func:`apply_sequence` - the three in the order of BASELINE config 3.
+* :func:`random_affine` - parameters (B,...) -> pixel matrix (``km_affine_matrix2d_fwd``, one launch) -> normalise / invert
+  (``km_homography_chain_fwd``) -> sample;
+* :func:`color_jitter` - the four adjustments in the sampled order, one fused kernel (+ one reduction pass for the contrast mean);
+* :func:`random_gaussian_blur` - per-sample sigma -> taps (``km_gaussian_taps_fwd``, one launch) -> fused separable blur;
+* the per-sample apply probability (``batch_prob``) as :func:`select_samples` - one pass that reads only the kept side of each
+  sample (2e bytes per element against 3e for ``torch.where``), skipped entirely when the parameters carry no draw (p = 1);
+* :func:`apply_sequence` - the three stages in the order of BASELINE config 3.  It captures into a HIP graph
+  (``kornia_amd.graph.capture``) when the parameters are device tensors: nothing in it synchronises.
 
 Parameters stay in float32 whatever the image dtype (the reference rounds them to the image dtype first, which costs a
 third of a pixel in bfloat16).  No host synchronisation anywhere: the apply masks are device data.
@@ -25,11 +27,12 @@ import torch
 
 from . import _native as N
 from .enhance.adjust import color_jitter as _color_jitter
+from .filters.filter import filter2d_separable
 from .filters.gaussian import gaussian_blur2d
 from .geometry.transform.builders import get_affine_matrix2d
 from .geometry.transform.imgwarp import warp_affine
 
-__all__ = ["apply_sequence", "color_jitter", "random_affine", "random_gaussian_blur"]
+__all__ = ["affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "select_samples"]
 
 
 def _p(params: Mapping[str, Any], key: str, device) -> torch.Tensor:
@@ -41,6 +44,37 @@ def _apply_mask(params: Mapping[str, Any], device) -> Optional[torch.Tensor]:
     if "batch_prob" not in params or params["batch_prob"] is None:
         return None
     return torch.atleast_1d(torch.as_tensor(params["batch_prob"]).to(device) > 0.5)
+
+
+def select_samples(transformed: torch.Tensor, original: torch.Tensor, apply: Optional[torch.Tensor]) -> torch.Tensor:
+    """``torch.where(apply[:, None, None, None], transformed, original)`` (base.py:348-361) as one native pass that reads only the
+    side it keeps; ``apply`` (B,) bool on the device, ``None`` = every sample was transformed."""
+    if apply is None:
+        return transformed
+    if (transformed.shape != original.shape or transformed.dtype != original.dtype or transformed.dtype not in (torch.float32, torch.bfloat16, torch.float16)
+            or apply.shape[0] != transformed.shape[0] or (torch.is_grad_enabled() and (transformed.requires_grad or original.requires_grad))):
+        return torch.where(apply.view(-1, *([1] * (transformed.dim() - 1))), transformed, original)
+    t, o = transformed.contiguous(), original.contiguous()
+    flags = apply.to(device=t.device, dtype=torch.uint8).contiguous()
+    out = torch.empty_like(t)
+    B = t.shape[0]
+    with N.device_guard(t.device):
+        N.check(N.lib().km_select_samples_fwd(t.data_ptr(), o.data_ptr(), flags.data_ptr(), out.data_ptr(), B, t.numel() // max(B, 1),
+                                              N.dtype_code(t.dtype), N.stream_ptr(t.device)), "km_select_samples_fwd")
+    return out
+
+
+def gaussian_taps(sigma: torch.Tensor, kernel_size) -> tuple:
+    """Per-sample 1-D Gaussian taps from ``sigma`` (B,2) = (sigma_y, sigma_x): ``(taps_x (B,kx), taps_y (B,ky))`` in float32, one
+    launch (``km_gaussian_taps_fwd``) for the ~16 elementwise launches of the reference's two ``get_gaussian_kernel1d`` calls."""
+    ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+    s = sigma.detach().to(torch.float32).contiguous()
+    B = s.shape[0]
+    tx = torch.empty(B, kx, device=s.device, dtype=torch.float32)
+    ty = torch.empty(B, ky, device=s.device, dtype=torch.float32)
+    with N.device_guard(s.device):
+        N.check(N.lib().km_gaussian_taps_fwd(s.data_ptr(), tx.data_ptr(), ty.data_ptr(), B, kx, ky, N.stream_ptr(s.device)), "km_gaussian_taps_fwd")
+    return tx, ty
 
 
 def affine_matrix(params: Mapping[str, Any], device) -> torch.Tensor:
@@ -58,9 +92,7 @@ def random_affine(input: torch.Tensor, params: Mapping[str, Any], resample: str 
     M = affine_matrix(params, input.device)
     mask = _apply_mask(params, input.device)
     out = warp_affine(input, M[:, :2, :], (input.shape[-2], input.shape[-1]), resample, padding_mode, align_corners, fill_value)
-    if mask is None:
-        return out
-    return torch.where(mask.view(-1, 1, 1, 1), out, input)
+    return select_samples(out, input, mask)
 
 
 def color_jitter(input: torch.Tensor, params: Mapping[str, Any], order: Optional[Sequence[int]] = None) -> torch.Tensor:
@@ -73,8 +105,7 @@ def color_jitter(input: torch.Tensor, params: Mapping[str, Any], order: Optional
         order = torch.as_tensor(params["order"]).tolist()  # sampled on the host by the reference's generator
     enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
     out = _color_jitter(input, bf, cf, sf, hf, [int(i) for i in order], enable=enable)
-    mask = _apply_mask(params, dev)
-    return out if mask is None else torch.where(mask.view(-1, 1, 1, 1), out, input)
+    return select_samples(out, input, _apply_mask(params, dev))
 
 
 def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_size=(5, 5), border_type: str = "reflect",
@@ -82,9 +113,14 @@ def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_
     """RandomGaussianBlur.apply_transform (gaussian_blur.py:95-114): per-sample ``sigma`` (B,), same in both directions."""
     N.require_device(input, "input")
     sigma = _p(params, "sigma", input.device).unsqueeze(-1).expand(-1, 2)
-    out = gaussian_blur2d(input, kernel_size, sigma, border_type, separable)
-    mask = _apply_mask(params, input.device)
-    return out if mask is None else torch.where(mask.view(-1, 1, 1, 1), out, input)
+    if separable and input.dtype in (torch.float32, torch.bfloat16, torch.float16):
+        # taps in float32 from the float32 sigma (the reference rounds sigma to the image dtype first), cast to the image dtype by
+        # filter2d_separable exactly as it casts any kernel (kornia/filters/filter.py:126)
+        taps_x, taps_y = gaussian_taps(sigma, kernel_size)
+        out = filter2d_separable(input, taps_x, taps_y, border_type)
+    else:
+        out = gaussian_blur2d(input, kernel_size, sigma.to(input.dtype), border_type, separable)
+    return select_samples(out, input, _apply_mask(params, input.device))
 
 
 def apply_sequence(input: torch.Tensor, affine: Mapping[str, Any], jitter: Mapping[str, Any], blur: Mapping[str, Any],

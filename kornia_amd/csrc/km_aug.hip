@@ -1,0 +1,105 @@
+// kornia_amd - small kernels of the augmentation layer's fast path: the pieces between the
+// reference's parameter dictionaries and the hot kernels that cost it a dozen tiny launches each.
+//
+//   km_gaussian_taps_fwd   per-sample sigma (B,2) -> normalised 1-D Gaussian taps (B,kx), (B,ky) in one launch
+//                          (kornia/filters/kernels.py:77-120 `gaussian`: x = arange(k) - k // 2 (+ 0.5 if k is even),
+//                          g = exp(-x^2 / (2 sigma^2)), g / sum(g); called by gaussian_blur2d, kornia/filters/gaussian.py:111-114,
+//                          with sigma[:, 1] for the horizontal and sigma[:, 0] for the vertical kernel) - the reference spends
+//                          ~8 elementwise launches per axis on B x 5 numbers;
+//   km_select_samples_fwd  out[b] = apply[b] ? transformed[b] : original[b] - the per-sample probability blend of
+//                          _AugmentationBase.transform_inputs (kornia/augmentation/base.py:348-393, `torch.where` on a
+//                          broadcast mask), reading only the side that is kept: 2e bytes per element instead of 3e.
+#include "km_regtile.h"
+
+template <int MAXK>
+__global__ __launch_bounds__(64) void km_gaussian_taps_kernel(const float* __restrict__ sigma, float* __restrict__ taps_x, float* __restrict__ taps_y, int B,
+                                                              int kx, int ky) {
+    const int t = blockIdx.x * 64 + threadIdx.x;  // one thread per (sample, axis)
+    if (t >= 2 * B) return;
+    const int b = t >> 1, axis = t & 1;           // axis 0: horizontal taps from sigma[:, 1]; axis 1: vertical from sigma[:, 0]
+    const int k = axis ? ky : kx;
+    const float s = sigma[(size_t)b * 2 + (axis ? 0 : 1)];
+    float* out = (axis ? taps_y : taps_x) + (size_t)b * k;
+    const float mean = (float)(k / 2);
+    const float den = 2.0f * (s * s);
+    float g[MAXK];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+        if (i < k) {
+            float x = (float)i - mean;
+            if ((k & 1) == 0) x = x + 0.5f;
+            g[i] = expf(-(x * x) / den);
+            sum = sum + g[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i)
+        if (i < k) out[i] = g[i] / sum;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void km_select_samples_kernel(const T* __restrict__ transformed, const T* __restrict__ original, const uint8_t* __restrict__ apply,
+                                                                T* __restrict__ out, uint32_t chunks_per_sample, size_t n_per_sample, int vec) {
+    const uint32_t b = blockIdx.x / chunks_per_sample, chunk = blockIdx.x % chunks_per_sample;
+    const T* __restrict__ src = (apply[b] ? transformed : original) + (size_t)b * n_per_sample;  // block-uniform
+    T* __restrict__ dst = out + (size_t)b * n_per_sample;
+    if (vec) {
+        const size_t i = ((size_t)chunk * 256 + threadIdx.x) * 4;
+        if (i < n_per_sample) {
+            float v[4];
+            km_ld4(src + i, v);
+            km_st4(dst + i, v);
+        }
+    } else {
+        const size_t i0 = (size_t)chunk * 1024 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = i0 + (size_t)k * 256;
+            if (i < n_per_sample) dst[i] = src[i];
+        }
+    }
+}
+
+template <typename T>
+static int km_select_run(const void* transformed, const void* original, const void* apply, void* out, int B, size_t n, hipStream_t s) {
+    const bool vec = (n % 4 == 0) && ((uintptr_t)transformed % (4 * sizeof(T)) == 0) && ((uintptr_t)original % (4 * sizeof(T)) == 0) &&
+                     ((uintptr_t)out % (4 * sizeof(T)) == 0);
+    const uint64_t chunks = (n + 1023) / 1024;
+    KM_REQUIRE(chunks * (uint64_t)B < (1ull << 31), "km_select_samples_fwd: grid too large");
+    hipLaunchKernelGGL(km_select_samples_kernel<T>, dim3((uint32_t)(chunks * B)), dim3(256), 0, s, (const T*)transformed, (const T*)original,
+                       (const uint8_t*)apply, (T*)out, (uint32_t)chunks, n, vec ? 1 : 0);
+    return km_check_launch("km_select_samples_fwd");
+}
+
+extern "C" {
+
+// sigma (B,2) fp32 on the device, (sigma_y, sigma_x) per sample like gaussian_blur2d's argument; taps_x (B,kx), taps_y (B,ky) fp32.
+int km_gaussian_taps_fwd(const void* sigma, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream) {
+    if (B == 0) return 0;
+    KM_REQUIRE(sigma && taps_x && taps_y, "km_gaussian_taps_fwd: null pointer");
+    KM_REQUIRE(B > 0 && kx > 0 && ky > 0 && kx <= 64 && ky <= 64, "km_gaussian_taps_fwd: bad sizes B=%d kx=%d ky=%d (1..64)", B, kx, ky);
+    const dim3 grid((2 * B + 63) / 64);
+    if (kx <= 8 && ky <= 8)
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (float*)taps_x, (float*)taps_y, B, kx, ky);
+    else
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (float*)taps_x, (float*)taps_y, B, kx, ky);
+    return km_check_launch("km_gaussian_taps_fwd");
+}
+
+// transformed, original, out: (B, n_per_sample) elements of `dtype`; apply: (B) uint8 on the device (non-zero: keep the transformed sample).
+int km_select_samples_fwd(const void* transformed, const void* original, const void* apply, void* out, int B, long long n_per_sample, int dtype,
+                          void* stream) {
+    if (B == 0 || n_per_sample == 0) return 0;
+    KM_REQUIRE(transformed && original && apply && out, "km_select_samples_fwd: null pointer");
+    KM_REQUIRE(B > 0 && n_per_sample > 0, "km_select_samples_fwd: bad sizes B=%d n=%lld", B, n_per_sample);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return km_select_run<float>(transformed, original, apply, out, B, (size_t)n_per_sample, s);
+        case KM_BF16: return km_select_run<km_bf16>(transformed, original, apply, out, B, (size_t)n_per_sample, s);
+        case KM_F16: return km_select_run<km_f16>(transformed, original, apply, out, B, (size_t)n_per_sample, s);
+        default: km_set_error("km_select_samples_fwd: dtype must be f32 / bf16 / f16"); return -1;
+    }
+}
+
+}  // extern "C"

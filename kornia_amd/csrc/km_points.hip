@@ -55,6 +55,45 @@ __global__ __launch_bounds__(256) void km_transform_points_fwd_kernel(const KmPo
     for (int k = 0; k < D; ++k) a.out[off + k] = s * hp[k];
 }
 
+// Vector form of the forward for fp32: a lane owns PPL consecutive points = a whole number of 16-byte words (D = 2: 2 points in
+// one float4; D = 3: 4 points in three float4), so a wave moves 1 KB per memory instruction instead of 256 B with a stride -
+// the memory pipeline issues about one wave-wide instruction per ~22 cycles per CU whatever its width (profiles/README.md),
+// which is what bounded the scalar form at a quarter of the streaming rate.  Same per-point arithmetic (km_point_fwd).
+template <int D>
+__global__ __launch_bounds__(256) void km_transform_points_fwd_vec_kernel(const KmPointsArgs<float, D> a) {
+    constexpr int E = D + 1, PPL = (D == 2) ? 2 : 4, NV = PPL * D / 4;
+    const int b = blockIdx.x / a.blocks_per_batch;
+    const int n = ((blockIdx.x % a.blocks_per_batch) * 256 + threadIdx.x) * PPL;
+    if (n >= a.N) return;
+    float t[E * E];
+    const float* tp = a.T + (size_t)(a.B_T == 1 ? 0 : b) * E * E;
+#pragma unroll
+    for (int k = 0; k < E * E; ++k) t[k] = tp[k];
+    const size_t off = ((size_t)b * a.N + n) * D;
+    float v[NV * 4];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        KM_CHECK_ALIGNED(a.pts + off + 4 * q, 16);
+        const float4 w = *reinterpret_cast<const float4*>(a.pts + off + 4 * q);
+        v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        float p[D], hp[E], s;
+        bool live;
+#pragma unroll
+        for (int k = 0; k < D; ++k) p[k] = v[i * D + k];
+        km_point_fwd<float, D>(t, p, hp, s, live);
+#pragma unroll
+        for (int k = 0; k < D; ++k) v[i * D + k] = s * hp[k];
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        KM_CHECK_ALIGNED(a.out + off + 4 * q, 16);
+        *reinterpret_cast<float4*>(a.out + off + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+}
+
 // out_k = s * h_k, s = 1/(h_D + eps) (live) ; dL/dh_k = g_k s ; dL/dh_D = -s^2 sum_k g_k h_k (live)
 // dL/dp_j = sum_r dL/dh_r T[r][j] ; dL/dT[r][j] = sum_n dL/dh_r p_j (p_D = 1)
 template <typename R, int D>
@@ -125,8 +164,18 @@ static int km_points_run(bool bwd, const void* T, const void* pts, void* out, co
     if (nb == 0) return 0;
     if (bwd)
         hipLaunchKernelGGL((km_transform_points_bwd_kernel<R, D>), dim3((uint32_t)nb), dim3(256), 0, s, a);
-    else
+    else {
+        if constexpr (sizeof(R) == sizeof(float)) {
+            constexpr int PPL = (D == 2) ? 2 : 4;
+            if ((N % PPL) == 0 && ((uintptr_t)pts % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+                KmPointsArgs<float, D> v = a;
+                v.blocks_per_batch = (uint32_t)((N / PPL + 255) / 256);
+                hipLaunchKernelGGL((km_transform_points_fwd_vec_kernel<D>), dim3(v.blocks_per_batch * (uint32_t)B), dim3(256), 0, s, v);
+                return km_check_launch("km_transform_points_fwd");
+            }
+        }
         hipLaunchKernelGGL((km_transform_points_fwd_kernel<R, D>), dim3((uint32_t)nb), dim3(256), 0, s, a);
+    }
     return km_check_launch(bwd ? "km_transform_points_bwd" : "km_transform_points_fwd");
 }
 

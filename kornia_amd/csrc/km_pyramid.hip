@@ -456,6 +456,80 @@ static int kmp_run(bool blur, const void* x, void* y, int B, int C, int H, int W
     return km_check_launch("km_resize_bilinear_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the bilinear resize (aten::upsample_bilinear2d_backward): grad_x[i][j] = sum over the output pixels (d, e) whose
+// 2 x 2 footprint holds (i, j) of  wy(d -> i) * wx(e -> j) * grad_y[d][e].  Gather form - one lane per INPUT pixel, no atomics, no
+// zero-fill, bit-reproducible: the source index of the forward (kmp_axis) is non-decreasing in the output index, so the outputs
+// that touch input row i are one contiguous range, found from the inverse of the index map and then corrected with the
+// forward's own arithmetic (so that rounding can neither drop nor double-count an output).
+template <typename R>
+__device__ __forceinline__ void kmp_adjoint_range(int i, int n_in, int n_out, int align, int& lo, int& hi) {
+    // estimate of the first output whose i0 >= i - 1 / last whose i0 <= i
+    const R scale = align ? (n_out > 1 ? (R)(n_in - 1) / (R)(n_out - 1) : (R)0) : (R)n_in / (R)n_out;
+    int a, b;
+    if (scale > (R)0) {
+        const R inv = (R)1 / scale;
+        a = (int)km_floor(align ? ((R)(i - 1)) * inv : ((R)(i - 1) + (R)0.5) * inv - (R)0.5) - 1;
+        b = (int)km_floor(align ? ((R)(i + 1)) * inv : ((R)(i + 1) + (R)0.5) * inv - (R)0.5) + 1;
+    } else {
+        a = 0; b = n_out - 1;
+    }
+    lo = min(max(a, 0), n_out - 1);
+    hi = min(max(b, 0), n_out - 1);
+    int i0, i1; R l0, l1;
+    // exact correction with the forward's index arithmetic
+    while (lo > 0) { kmp_axis<R>(lo - 1, n_in, n_out, align, i0, i1, l0, l1); if (i1 >= i) --lo; else break; }
+    while (lo < hi) { kmp_axis<R>(lo, n_in, n_out, align, i0, i1, l0, l1); if (i1 < i) ++lo; else break; }
+    while (hi < n_out - 1) { kmp_axis<R>(hi + 1, n_in, n_out, align, i0, i1, l0, l1); if (i0 <= i) ++hi; else break; }
+    while (hi > lo) { kmp_axis<R>(hi, n_in, n_out, align, i0, i1, l0, l1); if (i0 > i) --hi; else break; }
+}
+template <typename R>
+__device__ __forceinline__ R kmp_adjoint_weight(int d, int i, int n_in, int n_out, int align) {
+    int i0, i1; R l0, l1;
+    kmp_axis<R>(d, n_in, n_out, align, i0, i1, l0, l1);
+    return (i0 == i ? l0 : (R)0) + (i1 == i ? l1 : (R)0);  // (i1 == i0 on the last row: both weights land on it)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void km_resize_bilinear_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int H, int W, int oh, int ow, int align,
+                                                                     uint32_t tiles_x) {
+    typedef typename KmTraits<T>::R R;
+    const uint32_t tbx = blockIdx.x % tiles_x, i = blockIdx.x / tiles_x;  // one input row per block-row
+    const uint32_t bc = blockIdx.y;
+    const int j = (int)tbx * 256 + (int)threadIdx.x;
+    if (j >= W) return;
+    int ylo, yhi, xlo, xhi;
+    kmp_adjoint_range<R>((int)i, H, oh, align, ylo, yhi);
+    kmp_adjoint_range<R>(j, W, ow, align, xlo, xhi);
+    const T* g = gy + (size_t)bc * oh * ow;
+    R acc = (R)0;
+    for (int d = ylo; d <= yhi; ++d) {
+        const R wy = kmp_adjoint_weight<R>(d, (int)i, H, oh, align);
+        if (wy == (R)0) continue;
+        R row = (R)0;
+        for (int e = xlo; e <= xhi; ++e) {
+            const R wx = kmp_adjoint_weight<R>(e, j, W, ow, align);
+            row = row + wx * (R)km_ld(g + (size_t)d * ow + e);
+        }
+        acc = acc + wy * row;
+    }
+    km_st(gx + ((size_t)bc * H + i) * W + j, acc);
+}
+
+template <typename T>
+static int kmp_run_resize_bwd(const void* gy, void* gx, int B, int C, int H, int W, int oh, int ow, int align, hipStream_t s) {
+    const uint32_t tiles_x = (uint32_t)((W + 255) / 256);
+    const uint64_t planes = (uint64_t)B * C;
+    KM_REQUIRE((uint64_t)tiles_x * H < (1ull << 31) && planes < 65536ull * 65535ull, "km_resize_bilinear_bwd: grid too large");
+    // grid.y carries the planes (<= 65535 per launch)
+    for (uint64_t p0 = 0; p0 < planes; p0 += 65535) {
+        const uint32_t np = (uint32_t)(planes - p0 < 65535 ? planes - p0 : 65535);
+        hipLaunchKernelGGL((km_resize_bilinear_bwd_kernel<T>), dim3(tiles_x * (uint32_t)H, np), dim3(256), 0, s, (const T*)gy + p0 * (size_t)oh * ow,
+                           (T*)gx + p0 * (size_t)H * W, H, W, oh, ow, align, tiles_x);
+    }
+    return km_check_launch("km_resize_bilinear_bwd");
+}
+
 static int kmp_validate(const char* what, const void* x, const void* y, int B, int C, int H, int W, int oh, int ow, int dtype) {
     KM_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && oh >= 0 && ow >= 0, "%s: bad shape B=%d C=%d H=%d W=%d -> %dx%d", what, B, C, H, W, oh, ow);
     KM_REQUIRE(dtype >= KM_F32 && dtype <= KM_F16, "%s: unknown dtype code %d", what, dtype);
@@ -502,6 +576,22 @@ int km_resize_bilinear_fwd(const void* x, void* y, int B, int C, int H, int W, i
         }
     }
     return kmp_dispatch(false, x, y, B, C, H, W, oh, ow, 0, align ? 1 : 0, dtype, (hipStream_t)stream);
+}
+
+// Adjoint of km_resize_bilinear_fwd: gy (B,C,oh,ow) -> gx (B,C,H,W), written completely (no zero-fill needed); replaces
+// aten::upsample_bilinear2d_backward behind F.interpolate(mode='bilinear') in kornia/geometry/transform/pyramid.py:447,501.
+int km_resize_bilinear_bwd(const void* gy, void* gx, int B, int C, int H, int W, int oh, int ow, int align, int dtype, void* stream) {
+    KM_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "km_resize_bilinear_bwd: bad shape B=%d C=%d H=%d W=%d <- %dx%d", B, C, H, W, oh, ow);
+    KM_REQUIRE(dtype >= KM_F32 && dtype <= KM_F16, "km_resize_bilinear_bwd: unknown dtype code %d", dtype);
+    if ((uint64_t)B * C == 0) return 0;
+    KM_REQUIRE(gy && gx, "km_resize_bilinear_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return kmp_run_resize_bwd<float>(gy, gx, B, C, H, W, oh, ow, align ? 1 : 0, s);
+        case KM_F64: return kmp_run_resize_bwd<double>(gy, gx, B, C, H, W, oh, ow, align ? 1 : 0, s);
+        case KM_BF16: return kmp_run_resize_bwd<km_bf16>(gy, gx, B, C, H, W, oh, ow, align ? 1 : 0, s);
+        default: return kmp_run_resize_bwd<km_f16>(gy, gx, B, C, H, W, oh, ow, align ? 1 : 0, s);
+    }
 }
 
 }  // extern "C"

@@ -6,8 +6,8 @@ Reference behaviour mirrored: kornia/geometry/transform/pyramid.py - pyrdown :40
   * pyrdown is ONE launch, km_pyrdown_fwd (csrc/km_pyramid.hip): blur with the binomial kernel and bilinear decimation
     fused, the blurred image is never written (1.25 e instead of 3.25 e bytes per input element at factor 2);
   * pyrup is km_resize_bilinear_fwd + the register-tiled 5x5 km_filter2d_fwd;
-  * backward: both ops are linear, nothing of the forward is saved; the adjoint of the resize is ATen's
-    upsample_bilinear2d_backward, the adjoint of the blur is the native km_filter2d_bwd_input.
+  * backward: both ops are linear, nothing of the forward is saved; the adjoint of the resize is km_resize_bilinear_bwd (a
+    deterministic gather, no atomics), the adjoint of the blur km_filter2d_bwd_input - no ATen kernel in the path.
 """
 from __future__ import annotations
 
@@ -38,8 +38,19 @@ def _check_border(border_type: str) -> str:
     return str(border_type).lower()
 
 
+def _resize_adjoint(gy: torch.Tensor, shape, oh: int, ow: int, align: int, dtype) -> torch.Tensor:
+    """km_resize_bilinear_bwd: (B,C,oh,ow) gradient -> (B,C,H,W), one launch, written completely."""
+    B, C, H, W = shape
+    g = gy.detach().to(dtype).contiguous()
+    gx = torch.empty(B, C, H, W, device=g.device, dtype=dtype)
+    with N.device_guard(g.device):
+        N.check(N.lib().km_resize_bilinear_bwd(g.data_ptr(), gx.data_ptr(), B, C, H, W, oh, ow, align, N.dtype_code(dtype), N.stream_ptr(g.device)),
+                "km_resize_bilinear_bwd")
+    return gx
+
+
 class _ResizeBilinearFunction(torch.autograd.Function):
-    """Native forward (km_resize_bilinear_fwd); the adjoint is ATen's upsample_bilinear2d_backward."""
+    """Native forward (km_resize_bilinear_fwd) and adjoint (km_resize_bilinear_bwd)."""
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, oh: int, ow: int, align: int):
@@ -49,18 +60,18 @@ class _ResizeBilinearFunction(torch.autograd.Function):
         with N.device_guard(xc.device):
             N.check(N.lib().km_resize_bilinear_fwd(xc.data_ptr(), out.data_ptr(), B, C, H, W, oh, ow, align, N.dtype_code(xc.dtype),
                                                    N.stream_ptr(xc.device)), "km_resize_bilinear_fwd")
-        ctx.cfg = ((B, C, H, W), oh, ow, align)
+        ctx.cfg = ((B, C, H, W), oh, ow, align, xc.dtype)
         return out
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
-        shape, oh, ow, align = ctx.cfg
-        return torch.ops.aten.upsample_bilinear2d_backward(gy.contiguous(), [oh, ow], list(shape), bool(align), None, None), None, None, None
+        shape, oh, ow, align, dtype = ctx.cfg
+        return _resize_adjoint(gy, shape, oh, ow, align, dtype), None, None, None
 
 
 class _PyrDownFunction(torch.autograd.Function):
-    """Fused native forward (km_pyrdown_fwd).  Backward: the resize's adjoint (ATen) followed by the native adjoint of the 5x5
-    blur (km_filter2d_bwd_input) - both linear, so nothing of the forward needs to be kept."""
+    """Fused native forward (km_pyrdown_fwd).  Backward: the resize's adjoint (km_resize_bilinear_bwd) followed by the adjoint of the
+    5x5 blur (km_filter2d_bwd_input) - both native, both linear, so nothing of the forward needs to be kept."""
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, oh: int, ow: int, border: int, align: int):
@@ -76,7 +87,7 @@ class _PyrDownFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
         (B, C, H, W), oh, ow, border, align, dtype = ctx.cfg
-        g_blur = torch.ops.aten.upsample_bilinear2d_backward(gy.detach().to(dtype).contiguous(), [oh, ow], [B, C, H, W], bool(align), None, None).contiguous()
+        g_blur = _resize_adjoint(gy, (B, C, H, W), oh, ow, align, dtype)
         taps = _get_pyramid_gaussian_kernel().to(device=gy.device, dtype=N.compute_dtype(dtype)).contiguous()
         gx = torch.empty_like(g_blur)
         with N.device_guard(gy.device):

@@ -187,3 +187,29 @@ def test_warp_grid_non_identity_homographies(oracle):
     y = warper(x.cuda())
     assert (y.cpu() - oracle.homography_warp(x, Hm, (h, w))).abs().max().item() <= 1e-5
     assert (K.grid_sample(x.cuda(), got, align_corners=False).cpu() - oracle.grid_sample(x, exp, align_corners=False)).abs().max().item() <= 1e-5
+
+
+def test_augmentation_taps_and_sample_selection():
+    """km_gaussian_taps_fwd against the reference's formula (kernels.py:113-120, evaluated by torch in float32) and
+    km_select_samples_fwd against torch.where, odd / even kernel sizes, every storage dtype."""
+    import kornia_amd.augmentation as A
+
+    g = torch.Generator().manual_seed(25)
+    sigma = 0.1 + 1.9 * torch.rand(7, 2, generator=g)
+    for ks in ((5, 5), (3, 9), (4, 6), 23):
+        ky, kx = (ks, ks) if isinstance(ks, int) else ks
+        tx, ty = A.gaussian_taps(sigma.cuda(), ks)
+        for taps, k, s in ((tx, kx, sigma[:, 1:2]), (ty, ky, sigma[:, 0:1])):
+            x = (torch.arange(k, dtype=torch.float32) - float(k // 2)).expand(7, -1)
+            if k % 2 == 0:
+                x = x + 0.5
+            ref = torch.exp(-x.pow(2.0) / (2 * s.pow(2.0)))
+            ref = ref / ref.sum(-1, keepdim=True)
+            assert taps.shape == (7, k) and (taps.cpu() - ref).abs().max().item() <= 2e-7
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        for shape in ((5, 3, 20, 24), (5, 3, 7, 9)):  # vector and scalar paths
+            a = torch.rand(*shape, generator=g).to(dt).cuda()
+            b = torch.rand(*shape, generator=g).to(dt).cuda()
+            m = torch.tensor([True, False, True, True, False]).cuda()
+            assert torch.equal(A.select_samples(a, b, m), torch.where(m.view(-1, 1, 1, 1), a, b))
+    assert A.select_samples(a, b, None) is a

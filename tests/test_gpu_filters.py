@@ -256,10 +256,12 @@ def test_transform_points(oracle):
 
     g = torch.Generator().manual_seed(3)
     for D in (2, 3):
-        P = torch.rand(4, 1000, D, generator=g) * 2 - 1
         T = torch.eye(D + 1)[None] + 0.1 * torch.randn(4, D + 1, D + 1, generator=g)
-        assert torch.equal(K.transform_points(T.cuda(), P.cuda()).cpu(), oracle.transform_points(T, P))
-        assert torch.equal(K.transform_points(T[:1].cuda(), P.cuda()).cpu(), oracle.transform_points(T[:1], P))
+        for n_pts in (1000, 999, 1002, 3):  # whole 16-byte words per lane (vector kernel) and ragged counts (scalar kernel)
+            P = torch.rand(4, n_pts, D, generator=g) * 2 - 1
+            assert torch.equal(K.transform_points(T.cuda(), P.cuda()).cpu(), oracle.transform_points(T, P))
+            assert torch.equal(K.transform_points(T[:1].cuda(), P.cuda()).cpu(), oracle.transform_points(T[:1], P))
+        P = torch.rand(4, 1000, D, generator=g) * 2 - 1
         Td, Pd = T.double().cuda().requires_grad_(), P[:, :5].double().cuda().requires_grad_()
         assert torch.autograd.gradcheck(K.transform_points, (Td, Pd), nondet_tol=1e-8)
     assert K.transform_points(torch.eye(3)[None].cuda(), torch.zeros(1, 0, 2).cuda()).shape == (1, 0, 2)

@@ -139,3 +139,20 @@ def test_scale_pyramid_vs_reference():
             assert pyr[o].shape == d[f"{tag}_pyr_{o}"].shape
             assert torch.allclose(pyr[o].cpu(), d[f"{tag}_pyr_{o}"], atol=2e-6, rtol=0), (tag, o, (pyr[o].cpu() - d[f"{tag}_pyr_{o}"]).abs().max())
             assert torch.allclose(sig[o].cpu(), d[f"{tag}_sig_{o}"]) and torch.allclose(pd[o].cpu(), d[f"{tag}_pd_{o}"])
+
+
+def test_resize_adjoint_matches_aten():
+    """km_resize_bilinear_bwd (deterministic gather) against aten::upsample_bilinear2d_backward: up / down scaling, non-integer
+    factors, both align_corners settings, a size-1 axis, 16-bit storage."""
+    t = T()
+    g = torch.Generator().manual_seed(31)
+    for (H, W), (oh, ow) in (((12, 16), (24, 32)), ((24, 32), (12, 16)), ((9, 13), (14, 7)), ((17, 5), (5, 31)), ((1, 8), (4, 3)), ((6, 6), (6, 6))):
+        for align in (False, True):
+            x = torch.rand(2, 3, H, W, generator=g).cuda().requires_grad_()
+            go = torch.rand(2, 3, oh, ow, generator=g).cuda()
+            (got,) = torch.autograd.grad(t.resize_bilinear(x, (oh, ow), align), x, go)
+            ref = torch.ops.aten.upsample_bilinear2d_backward(go, [oh, ow], [2, 3, H, W], align, None, None)
+            assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2e-6, ((H, W), (oh, ow), align)
+    x = torch.rand(1, 2, 16, 16, generator=g).bfloat16().cuda().requires_grad_()
+    (gb,) = torch.autograd.grad(t.resize_bilinear(x, (8, 8)), x, torch.ones(1, 2, 8, 8, dtype=torch.bfloat16).cuda())
+    assert gb.dtype == torch.bfloat16 and torch.allclose(gb.float(), torch.full_like(gb.float(), 0.25))
