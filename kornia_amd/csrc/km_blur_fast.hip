@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     const int H = a.H, W = a.W, border = a.border;
     const int c0 = gx * 4;
     const bool left = (c0 == 0), right = (c0 == W - 4);
-    const bool first16 = (lane & 15) == 0, last16 = (lane & 15) == 15;  // ends of a DPP row: no neighbour lane on that side
     const T* img = a.x + (size_t)bc * H * W;
     T* out = a.y + (size_t)bc * H * W;
     const int b = (int)(bc / a.C);
@@ -144,16 +143,18 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
                         km_ld4(rowp + offR, r4);
                     } else {
                         // The neighbouring chunks are what the neighbouring lanes have just loaded: take them from their registers
-                        // (one DPP move each) instead of requesting them from memory again - the memory pipeline is bound by the
-                        // bytes the lanes request (profiles/r02_hbm_shapes.txt), and three 16-byte loads per 16 bytes of output
-                        // were two too many.  Only the first / last lane of a row of 16 lanes still loads its outer chunk.
-                        if (first16) km_ld4(rowp + offL, l4);
-                        if (last16) km_ld4(rowp + offR, r4);
+                        // (one wave-wide DPP shift each) instead of requesting them from memory again.  The texture-address
+                        // unit is the busiest unit of this kernel (TA_TA_BUSY 86 % with three 16-byte loads per row,
+                        // profiles/r02_pmc_units.json) and it charges ~25 cycles per wave instruction however few lanes
+                        // are active, so the two chunks no lane holds - left of lane 0, right of lane 63 - come with ONE load.
+                        const bool e0 = (lane == 0), e63 = (lane == 63);
+                        float e4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (e0 || e63) km_ld4(rowp + (e0 ? offL : offR), e4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float pl = km_prev16(o4[q]), nr = km_next16(o4[q]);
-                            if (!first16) l4[q] = pl;
-                            if (!last16) r4[q] = nr;
+                            const float pl = km_prev64(o4[q]), nr = km_next64(o4[q]);
+                            l4[q] = e0 ? e4[q] : pl;
+                            r4[q] = e63 ? e4[q] : nr;
                         }
                     }
                     if (border != KM_BORDER_CIRCULAR) {

@@ -49,6 +49,13 @@ __device__ __forceinline__ float km_next16(float v) { return __uint_as_float(km_
 __device__ __forceinline__ float km_prev16(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x111, 0xf, 0xf, false));
 }
+// The same across the whole wave (gfx9 DPP wave_shl:1 / wave_shr:1, verified on gfx950: lane 63 / lane 0 - and a lane whose
+// neighbour has exited - get their own value back)
+__device__ __forceinline__ uint32_t km_next64(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float km_next64(float v) { return __uint_as_float(km_next64(__float_as_uint(v))); }
+__device__ __forceinline__ float km_prev64(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));
+}
 #endif
 
 // ---- storage types ----------------------------------------------------------------------------

@@ -374,13 +374,13 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
         // a 2 x 2 footprint per pixel - 16 bytes for 4 bytes of output - costs 0.39 ms at this size, 8 bytes 0.30, a plain copy
         // 0.29): a lane loads its own column of the footprint, (x0, y0) and (x0, y0 + 1), and takes the x0 + 1 column from
         // the next lane when that lane's footprint starts exactly one pixel to the right - which it does for most lanes of any
-        // warp of scale ~1; the others (and the last lane of each row of 16) load it themselves.  Same values either way.
+        // warp of scale ~1; the others (and the last lane of each output row of the patch) load it themselves.  Same values either way.
         float v[KM_ROWS][NCC][4];
         bool nb[KM_ROWS];
 #pragma unroll
         for (int r = 0; r < KM_ROWS; ++r) {
             const uint32_t off = (uint32_t)__mul24((int)t[r].yf, W) + (uint32_t)(int)t[r].xf;
-            nb[r] = (km_next16(off) == off + 1u);  // (the last lane of a row of 16 reads itself: false)
+            nb[r] = (km_next64(off) == off + 1u);  // (lane 63 reads itself: false; lane 31's neighbour is on another row: false)
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
                 v[r][c][0] = (float)km_ld(km_at(sp[c], off));
@@ -395,7 +395,7 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
         for (int r = 0; r < KM_ROWS; ++r)
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
-                const float n0 = km_next16(v[r][c][0]), n2 = km_next16(v[r][c][2]);
+                const float n0 = km_next64(v[r][c][0]), n2 = km_next64(v[r][c][2]);
                 if (nb[r]) { v[r][c][1] = n0; v[r][c][3] = n2; }
             }
 #pragma unroll

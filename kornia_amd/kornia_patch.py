@@ -149,6 +149,56 @@ def _registrator_level_loss(original: Callable) -> Callable:
     return get_single_level_loss
 
 
+def _blend_by_prob(original: Callable) -> Callable:
+    """_AugmentationBase._blend_by_prob (kornia/augmentation/base.py:348-361): the per-sample probability blend of every augmentation,
+    ``torch.where(to_apply, transformed, input)``, as one native pass that reads only the side it keeps (km_select_samples_fwd)."""
+    from .augmentation import select_samples
+
+    def blend(transformed, not_transformed, to_apply):
+        ok = (
+            isinstance(transformed, torch.Tensor) and isinstance(not_transformed, torch.Tensor) and isinstance(to_apply, torch.Tensor)
+            and _N.on_device(transformed) and _N.on_device(not_transformed) and transformed.shape == not_transformed.shape
+            and transformed.dim() >= 2 and to_apply.dim() == 1 and transformed.shape[0] == to_apply.shape[0]
+            and transformed.dtype == not_transformed.dtype and transformed.dtype in _COLOR_DTYPES
+            and not (torch.is_grad_enabled() and (transformed.requires_grad or not_transformed.requires_grad))
+            and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
+        )
+        if not ok:
+            return original(transformed, not_transformed, to_apply)
+        return select_samples(transformed, not_transformed, to_apply.to(transformed.device))
+
+    blend.__wrapped__ = original
+    return staticmethod(blend)
+
+
+def _gaussian_blur_apply(original: Callable) -> Callable:
+    """RandomGaussianBlur.apply_transform (kornia/augmentation/_2d/intensity/gaussian_blur.py:95-114): the instance holds the reference's
+    gaussian_blur2d captured at construction (:93), so the method itself is replaced - per-sample taps in one launch
+    (km_gaussian_taps_fwd) and the fused separable blur, nothing synchronises on the sampled sigmas."""
+    from .augmentation import gaussian_taps
+    from .filters.filter import filter2d_separable
+
+    @functools.wraps(original)
+    def apply_transform(self, input, params, flags, transform=None):
+        sigma = params.get("sigma") if hasattr(params, "get") else None
+        ok = (
+            isinstance(input, torch.Tensor) and _N.on_device(input) and input.dim() == 4 and input.dtype in _COLOR_DTYPES
+            and isinstance(sigma, torch.Tensor) and sigma.dim() == 1 and flags.get("separable", True)
+            and not (torch.is_grad_enabled() and (input.requires_grad or sigma.requires_grad))
+            and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
+        )
+        if not ok:
+            return original(self, input, params, flags, transform)
+        s2 = sigma.to(device=input.device, dtype=torch.float32).unsqueeze(-1).expand(-1, 2)
+        if getattr(self, "same_on_batch", False):
+            s2 = s2[:1]
+        taps_x, taps_y = gaussian_taps(s2, flags["kernel_size"])
+        return filter2d_separable(input, taps_x, taps_y, flags["border_type"].name.lower())
+
+    apply_transform.__wrapped__ = original
+    return apply_transform
+
+
 def patch() -> int:
     """Activate the native path inside Kornia. Returns the number of rebound module attributes."""
     if _patched:
@@ -179,7 +229,16 @@ def patch() -> int:
     original = ir_mod.ImageRegistrator.get_single_level_loss
     ir_mod.ImageRegistrator.get_single_level_loss = _registrator_level_loss(original)
     _patched_methods.append((ir_mod.ImageRegistrator, "get_single_level_loss", original))
-    return count + 2
+    # the augmentation layer: the probability blend of every augmentation and RandomGaussianBlur's apply step
+    base_mod = importlib.import_module("kornia.augmentation.base")
+    original = base_mod._AugmentationBase.__dict__["_blend_by_prob"]  # the staticmethod object itself
+    base_mod._AugmentationBase._blend_by_prob = _blend_by_prob(original.__func__)
+    _patched_methods.append((base_mod._AugmentationBase, "_blend_by_prob", original))
+    gb_mod = importlib.import_module("kornia.augmentation._2d.intensity.gaussian_blur")
+    original = gb_mod.RandomGaussianBlur.apply_transform
+    gb_mod.RandomGaussianBlur.apply_transform = _gaussian_blur_apply(original)
+    _patched_methods.append((gb_mod.RandomGaussianBlur, "apply_transform", original))
+    return count + 4
 
 
 def unpatch() -> int:

@@ -165,6 +165,18 @@ inline float km_prev16(float v) {  // row_shr:1
     memcpy(&r, &got, sizeof(float));
     return ok ? r : v;
 }
+inline uint32_t km_next64(uint32_t v) { return __shfl_down(v, 1, 64); }  // wave_shl:1
+inline float km_next64(float v) { return __shfl_down(v, 1, 64); }
+inline float km_prev64(float v) {  // wave_shr:1
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(float));
+    const int lane = emu::lane_id();
+    bool ok = false;
+    const uint64_t got = emu::wave_exchange(bits, lane ? lane - 1 : lane, &ok);
+    float r;
+    memcpy(&r, &got, sizeof(float));
+    return ok ? r : v;
+}
 inline int emu_readfirstlane(int v) {
     bool ok = false;
     return (int)(uint32_t)emu::wave_exchange((uint64_t)(uint32_t)v, -1, &ok);
