@@ -14,9 +14,9 @@ replayed graph runs them back to back.
         return g
     step = kornia_amd.graph.capture(train, x, H.requires_grad_(), target)
 
-Rules of capture (HIP's, not ours): tensor arguments must already live on the device, shapes are frozen, and the function must
-not synchronise (``.item()``, ``.tolist()`` on device data, host tensors turned into device tensors inside).  Non-tensor
-arguments are baked into the graph.  The returned tensors are the graph's own buffers: copy them if they must survive the
+Rules of capture (HIP's, not ours): the tensors that change between replays must already live on the device (host tensors and
+non-tensor arguments are baked into the graph), shapes are frozen, and the function must
+not synchronise (``.item()``, ``.tolist()`` on device data, host tensors turned into device tensors inside).  The returned tensors are the graph's own buffers: copy them if they must survive the
 next replay.
 """
 from __future__ import annotations
@@ -29,8 +29,9 @@ __all__ = ["GraphedStep", "capture"]
 
 
 def _tensors(tree: Any) -> list:
+    """The device tensors of a (nested) argument list; host tensors (e.g. ColorJitter's sampled ``order``) are constants of the graph."""
     if isinstance(tree, torch.Tensor):
-        return [tree]
+        return [tree] if tree.is_cuda else []
     if isinstance(tree, (list, tuple)):
         return [t for x in tree for t in _tensors(x)]
     if isinstance(tree, dict):
@@ -43,13 +44,15 @@ class GraphedStep:
 
     def __init__(self, fn: Callable, *args: Any, warmup: int = 2, no_grad: bool = False) -> None:
         tensors = _tensors(args)
-        if not tensors or not all(t.is_cuda for t in tensors):
-            raise ValueError("capture() needs every tensor argument on a HIP device")
+        if not tensors:
+            raise ValueError("capture() needs at least one tensor argument on a HIP device")
         self._device = tensors[0].device
         self._fn = fn
         self._no_grad = no_grad
 
         def clone(t):
+            if not t.is_cuda:
+                return t  # host tensors are baked into the graph as they are
             c = t.detach().clone()
             return c.requires_grad_(t.requires_grad)
 
