@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
     float acc = 0.0f;
     const int per_block = 256 * VEC * 4;  // 4 iterations per thread
     const int start = (int)chunk * per_block;
-#pragma unroll
+    // (not unrolled: four inlined copies of the stage machine - exact fmod paths included - are ~45 KB of code, more than the
+    // instruction cache of a CU pair holds)
+#pragma unroll 1
     for (int it = 0; it < 4; ++it) {
         const int p0 = start + (it * 256 + (int)threadIdx.x) * VEC;
         if (p0 >= HW) break;

@@ -1,0 +1,28 @@
+"""Times the three warp kernels of config 2 one by one through the C ABI (HIP events): fwd / gm / scatter.
+  python profiles/time_warp_kernels.py [iters] [which: fwd,gm,sc,blur]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from kornia_amd import _native as N
+lib = N.lib(); dev = torch.device('cuda')
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+which = (sys.argv[2] if len(sys.argv) > 2 else "fwd,gm,sc").split(",")
+B, C, S = int(os.environ.get("LAB_B", 256)), 3, 512
+g = torch.Generator().manual_seed(0); gg = torch.Generator(device=dev).manual_seed(0)
+x = torch.rand(B, C, S, S, device=dev, generator=gg); M = bench.flagship_homographies(B, S, S, g).to(dev)
+go = torch.rand(B, C, S, S, device=dev, generator=gg)
+stream = N.stream_ptr(dev)
+m = torch.empty(B, 9, device=dev); N.check(lib.km_homography_chain_fwd(M.data_ptr(), 3, None, m.data_ptr(), B, S, S, S, S, 0, stream), "c")
+out = torch.empty_like(x); gsrc = torch.empty_like(x); gm = torch.zeros(B, 9, device=dev, dtype=torch.float64)
+fns = {
+ "fwd": lambda: N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), out.data_ptr(), B, C, S, S, S, S, B, 0, 1, 1, 0, 1, None, 0, stream), "wf"),
+ "gm": lambda: N.check(lib.km_warp2d_bwd(go.data_ptr(), x.data_ptr(), m.data_ptr(), None, gm.data_ptr(), B, C, S, S, S, S, B, 0, 1, 1, 0, 1, None, 0, stream), "gm"),
+ "bwd": lambda: N.check(lib.km_warp2d_bwd(go.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, S, S, S, S, B, 0, 1, 1, 0, 1, None, 0, stream), "bwd"),
+ "sc": lambda: N.check(lib.km_warp2d_bwd(go.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), None, B, C, S, S, S, S, B, 0, 1, 1, 0, 1, None, 0, stream), "sc"),
+}
+if "copy" in which:
+    fns["copy"] = lambda: out.copy_(x)
+for k in which:
+    print(k, round(bench.event_time_ms(fns[k], iters), 4), "ms", flush=True)
