@@ -198,8 +198,16 @@ int km_transform_points_bwd(const void* gout, const void* T, const void* pts, vo
  * taps_x (B,kx) from sigma[:,1], taps_y (B,ky) from sigma[:,0], fp32, normalised to sum 1; 1 <= kx, ky <= 64.
  * km_select_samples_fwd replaces the per-sample probability blend of _AugmentationBase.transform_inputs
  * (kornia/augmentation/base.py:348-393, torch.where(to_apply, transformed, input)):
- * out[b] = apply[b] ? transformed[b] : original[b], apply (B) uint8 on the device, n_per_sample elements of dtype per sample. */
-int km_gaussian_taps_fwd(const void* sigma, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream);
+ * out[b] = apply[b] ? transformed[b] : original[b], apply (B) uint8 on the device, n_per_sample elements of dtype per sample.
+ * The same switch folded INTO the kernels, so that the blend costs no pass of its own: km_gaussian_taps_fwd's `apply` (nullable; a
+ * sample whose entry is 0 gets the identity kernel - odd sizes), km_warp2d_fwd_masked and km_color_jitter_fwd_masked (the arguments of
+ * km_warp2d_fwd / km_color_jitter_fwd plus `apply`; a sample whose entry is 0 is copied; the warp needs h == H, w == W). */
+int km_gaussian_taps_fwd(const void* sigma, const void* apply, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream);
+int km_warp2d_fwd_masked(const void* src, const void* mat, void* dst, const void* apply, int B, int C, int H, int W, int h,
+                         int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align, const void* fill,
+                         int dtype, void* stream);
+int km_color_jitter_fwd_masked(const void* x, void* y, const void* params, double* gray_sum, const void* enable,
+                               const void* apply, const int* stages, int n_stages, int B, int H, int W, int dtype, void* stream);
 int km_select_samples_fwd(const void* transformed, const void* original, const void* apply, void* out, int B,
                           long long n_per_sample, int dtype, void* stream);
 

@@ -51,7 +51,9 @@ _PROTOTYPES = {
     "km_resize_bilinear_fwd": [_P, _P] + [_I] * 8 + [_P],
     "km_resize_bilinear_bwd": [_P, _P] + [_I] * 8 + [_P],
     "km_warp_masked_loss": [_P, _P, _P, _P] + [_I] * 11 + [c_double, _I, _P],
-    "km_gaussian_taps_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "km_gaussian_taps_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "km_warp2d_fwd_masked": [_P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],
+    "km_color_jitter_fwd_masked": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "km_select_samples_fwd": [_P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P],
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
     "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
@@ -163,3 +165,14 @@ def device_guard(device: torch.device):
     if idx is None or idx == torch.cuda.current_device():
         return _NO_GUARD
     return torch.cuda.device(device)
+
+
+def flags(t, device, n=None):
+    """A per-sample / per-stage switch as the contiguous uint8 array the kernels read: a bool tensor is reinterpreted in place
+    (no launch), anything else goes through ``!= 0``."""
+    import torch
+    t = t.detach().to(device=device).reshape(-1)
+    if n is not None and t.numel() != n:
+        raise ValueError(f"expected {n} switch entries, got {t.numel()}")
+    t = t.contiguous()
+    return t.view(torch.uint8) if t.dtype == torch.bool else t.ne(0).view(torch.uint8)

@@ -10,8 +10,11 @@ parameter dictionaries the reference's generators produce (or a replay of them, 
   (``km_homography_chain_fwd``) -> sample;
 * :func:`color_jitter` - the four adjustments in the sampled order, one fused kernel (+ one reduction pass for the contrast mean);
 * :func:`random_gaussian_blur` - per-sample sigma -> taps (``km_gaussian_taps_fwd``, one launch) -> fused separable blur;
-* the per-sample apply probability (``batch_prob``) as :func:`select_samples` - one pass that reads only the kept side of each
-  sample (2e bytes per element against 3e for ``torch.where``), skipped entirely when the parameters carry no draw (p = 1);
+* the per-sample apply probability (``batch_prob``, base.py:348-393) rides INSIDE the three launches - the warp copies the samples
+  that are not transformed (``km_warp2d_fwd_masked``), the colour kernel passes them through (``km_color_jitter_fwd_masked``), the
+  blur gives them the identity kernel (``km_gaussian_taps_fwd``) - so ``torch.where``'s extra pass per stage does not exist;
+  :func:`select_samples` (one pass that reads only the kept side, 2e instead of 3e) serves every other augmentation through
+  ``patch()``; nothing of this runs when the parameters carry no draw (p = 1);
 * :func:`apply_sequence` - the three stages in the order of BASELINE config 3.  It captures into a HIP graph
   (``kornia_amd.graph.capture``) when the parameters are device tensors: nothing in it synchronises.
 
@@ -30,7 +33,7 @@ from .enhance.adjust import color_jitter as _color_jitter
 from .filters.filter import filter2d_separable
 from .filters.gaussian import gaussian_blur2d
 from .geometry.transform.builders import get_affine_matrix2d
-from .geometry.transform.imgwarp import warp_affine
+from .geometry.transform.imgwarp import COORD_AFFINE, _warp, warp_affine
 
 __all__ = ["affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "select_samples"]
 
@@ -64,16 +67,18 @@ def select_samples(transformed: torch.Tensor, original: torch.Tensor, apply: Opt
     return out
 
 
-def gaussian_taps(sigma: torch.Tensor, kernel_size) -> tuple:
+def gaussian_taps(sigma: torch.Tensor, kernel_size, apply: Optional[torch.Tensor] = None) -> tuple:
     """Per-sample 1-D Gaussian taps from ``sigma`` (B,2) = (sigma_y, sigma_x): ``(taps_x (B,kx), taps_y (B,ky))`` in float32, one
-    launch (``km_gaussian_taps_fwd``) for the ~16 elementwise launches of the reference's two ``get_gaussian_kernel1d`` calls."""
+    launch (``km_gaussian_taps_fwd``) for the ~16 elementwise launches of the reference's two ``get_gaussian_kernel1d`` calls.
+    ``apply`` (B,) bool: a sample whose entry is False gets the identity kernel (odd sizes), so the blur returns it unchanged."""
     ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
     s = sigma.detach().to(torch.float32).contiguous()
     B = s.shape[0]
     tx = torch.empty(B, kx, device=s.device, dtype=torch.float32)
     ty = torch.empty(B, ky, device=s.device, dtype=torch.float32)
+    flags = None if apply is None else N.flags(apply, s.device, B)
     with N.device_guard(s.device):
-        N.check(N.lib().km_gaussian_taps_fwd(s.data_ptr(), tx.data_ptr(), ty.data_ptr(), B, kx, ky, N.stream_ptr(s.device)), "km_gaussian_taps_fwd")
+        N.check(N.lib().km_gaussian_taps_fwd(s.data_ptr(), N.ptr(flags), tx.data_ptr(), ty.data_ptr(), B, kx, ky, N.stream_ptr(s.device)), "km_gaussian_taps_fwd")
     return tx, ty
 
 
@@ -91,7 +96,13 @@ def random_affine(input: torch.Tensor, params: Mapping[str, Any], resample: str 
     N.require_device(input, "input")
     M = affine_matrix(params, input.device)
     mask = _apply_mask(params, input.device)
-    out = warp_affine(input, M[:, :2, :], (input.shape[-2], input.shape[-1]), resample, padding_mode, align_corners, fill_value)
+    size = (input.shape[-2], input.shape[-1])
+    if mask is not None and not (torch.is_grad_enabled() and input.requires_grad):
+        # the switch rides in the warp's own launch: samples that are not transformed are copied by the workgroups that would have warped them
+        if padding_mode == "fill" and fill_value is None:
+            fill_value = torch.zeros(input.shape[1], device=input.device, dtype=input.dtype)
+        return _warp(input, M[:, :2, :], size, COORD_AFFINE, 1, resample, padding_mode, align_corners, fill_value, apply=mask)
+    out = warp_affine(input, M[:, :2, :], size, resample, padding_mode, align_corners, fill_value)
     return select_samples(out, input, mask)
 
 
@@ -104,8 +115,7 @@ def color_jitter(input: torch.Tensor, params: Mapping[str, Any], order: Optional
     if order is None:
         order = torch.as_tensor(params["order"]).tolist()  # sampled on the host by the reference's generator
     enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
-    out = _color_jitter(input, bf, cf, sf, hf, [int(i) for i in order], enable=enable)
-    return select_samples(out, input, _apply_mask(params, dev))
+    return _color_jitter(input, bf, cf, sf, hf, [int(i) for i in order], enable=enable, apply=_apply_mask(params, dev))
 
 
 def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_size=(5, 5), border_type: str = "reflect",
@@ -116,10 +126,15 @@ def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_
     if separable and input.dtype in (torch.float32, torch.bfloat16, torch.float16):
         # taps in float32 from the float32 sigma (the reference rounds sigma to the image dtype first), cast to the image dtype by
         # filter2d_separable exactly as it casts any kernel (kornia/filters/filter.py:126)
+        ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+        mask = _apply_mask(params, input.device)
+        if mask is None or (kx % 2 == 1 and ky % 2 == 1):
+            # the switch rides in the taps: a sample that is not blurred gets the identity kernel (1 * x + 0 * neighbours = x, bit for bit)
+            taps_x, taps_y = gaussian_taps(sigma, kernel_size, mask)
+            return filter2d_separable(input, taps_x, taps_y, border_type)
         taps_x, taps_y = gaussian_taps(sigma, kernel_size)
-        out = filter2d_separable(input, taps_x, taps_y, border_type)
-    else:
-        out = gaussian_blur2d(input, kernel_size, sigma.to(input.dtype), border_type, separable)
+        return select_samples(filter2d_separable(input, taps_x, taps_y, border_type), input, mask)
+    out = gaussian_blur2d(input, kernel_size, sigma.to(input.dtype), border_type, separable)
     return select_samples(out, input, _apply_mask(params, input.device))
 
 

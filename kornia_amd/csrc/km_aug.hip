@@ -12,14 +12,20 @@
 #include "km_regtile.h"
 
 template <int MAXK>
-__global__ __launch_bounds__(64) void km_gaussian_taps_kernel(const float* __restrict__ sigma, float* __restrict__ taps_x, float* __restrict__ taps_y, int B,
-                                                              int kx, int ky) {
+__global__ __launch_bounds__(64) void km_gaussian_taps_kernel(const float* __restrict__ sigma, const uint8_t* __restrict__ apply, float* __restrict__ taps_x,
+                                                              float* __restrict__ taps_y, int B, int kx, int ky) {
     const int t = blockIdx.x * 64 + threadIdx.x;  // one thread per (sample, axis)
     if (t >= 2 * B) return;
     const int b = t >> 1, axis = t & 1;           // axis 0: horizontal taps from sigma[:, 1]; axis 1: vertical from sigma[:, 0]
     const int k = axis ? ky : kx;
     const float s = sigma[(size_t)b * 2 + (axis ? 0 : 1)];
     float* out = (axis ? taps_y : taps_x) + (size_t)b * k;
+    if (apply && !apply[b]) {
+        // a sample that is not blurred gets the identity kernel: 1 * x + 0 * neighbours reproduces a finite image bit for bit, so the
+        // probability blend of the augmentation layer costs no pass of its own (odd kernel sizes; the caller blends otherwise)
+        for (int i = 0; i < k; ++i) out[i] = (i == k / 2) ? 1.0f : 0.0f;
+        return;
+    }
     const float mean = (float)(k / 2);
     const float den = 2.0f * (s * s);
     float g[MAXK];
@@ -74,16 +80,18 @@ static int km_select_run(const void* transformed, const void* original, const vo
 
 extern "C" {
 
-// sigma (B,2) fp32 on the device, (sigma_y, sigma_x) per sample like gaussian_blur2d's argument; taps_x (B,kx), taps_y (B,ky) fp32.
-int km_gaussian_taps_fwd(const void* sigma, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream) {
+// sigma (B,2) fp32 on the device, (sigma_y, sigma_x) per sample like gaussian_blur2d's argument; taps_x (B,kx), taps_y (B,ky) fp32;
+// apply (B) uint8 on the device, nullable: a sample whose entry is 0 gets the identity kernel (needs odd kx, ky).
+int km_gaussian_taps_fwd(const void* sigma, const void* apply, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream) {
     if (B == 0) return 0;
     KM_REQUIRE(sigma && taps_x && taps_y, "km_gaussian_taps_fwd: null pointer");
     KM_REQUIRE(B > 0 && kx > 0 && ky > 0 && kx <= 64 && ky <= 64, "km_gaussian_taps_fwd: bad sizes B=%d kx=%d ky=%d (1..64)", B, kx, ky);
+    KM_REQUIRE(!apply || ((kx & 1) && (ky & 1)), "km_gaussian_taps_fwd: the per-sample switch needs odd kernel sizes (%d, %d)", kx, ky);
     const dim3 grid((2 * B + 63) / 64);
     if (kx <= 8 && ky <= 8)
-        hipLaunchKernelGGL(km_gaussian_taps_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (float*)taps_x, (float*)taps_y, B, kx, ky);
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)apply, (float*)taps_x, (float*)taps_y, B, kx, ky);
     else
-        hipLaunchKernelGGL(km_gaussian_taps_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (float*)taps_x, (float*)taps_y, B, kx, ky);
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)apply, (float*)taps_x, (float*)taps_y, B, kx, ky);
     return km_check_launch("km_gaussian_taps_fwd");
 }
 

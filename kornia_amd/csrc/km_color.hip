@@ -21,6 +21,7 @@ struct KmColorArgs {
     const float* params;   // (B,4): brightness, contrast, saturation, hue shift in radians
     double* gray_sum;      // (B) fp64 accumulators for the contrast stage's mean, pre-zeroed (nullable if no contrast stage)
     const uint8_t* enable; // (4) per-stage-kind switches on the DEVICE (nullable = all on): the reference's `(factor != neutral).any()` guards
+    const uint8_t* apply;  // (B) per-sample switch of the augmentation layer (nullable = all on): a sample whose entry is 0 is copied
     int stages[KMC_MAX_STAGES];
     int n_stages;
     int HW;                // pixels per plane
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
     const int last = (MODE == 0) ? ci : a.n_stages;
     uint32_t enable_mask = 0xfu;
     if (a.enable) enable_mask = (a.enable[0] ? 1u : 0u) | (a.enable[1] ? 2u : 0u) | (a.enable[2] ? 4u : 0u) | (a.enable[3] ? 8u : 0u);
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not jittered - every stage off, the apply pass is a copy
+        if (MODE == 0) return;
+        enable_mask = 0u;
+    }
 
     float acc = 0.0f;
     const int per_block = 256 * VEC * 4;  // 4 iterations per thread
@@ -177,10 +182,11 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
 }
 
 template <typename T>
-static int kmc_run(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const int* stages, int n_stages, int B,
-                   int H, int W, hipStream_t s) {
+static int kmc_run(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const void* apply, const int* stages, int n_stages,
+                   int B, int H, int W, hipStream_t s) {
     KmColorArgs<T> a;
     a.x = (const T*)x; a.y = (T*)y; a.params = (const float*)params; a.gray_sum = gray_sum; a.enable = (const uint8_t*)enable;
+    a.apply = (const uint8_t*)apply;
     bool has_contrast = false;
     for (int k = 0; k < KMC_MAX_STAGES; ++k) {
         a.stages[k] = k < n_stages ? stages[k] : -1;
@@ -208,15 +214,8 @@ static int kmc_run(const void* x, void* y, const void* params, double* gray_sum,
     return km_check_launch("km_color_jitter_fwd");
 }
 
-extern "C" {
-
-// x, y: (B,3,H,W) RGB in `dtype` (f32 / bf16 / f16); params: (B,4) fp32 on the device - brightness factor, contrast
-// factor, saturation factor, hue shift in RADIANS; stages: HOST array of n_stages (<= 4) ids in application order
-// (0 brightness, 1 contrast, 2 saturation, 3 hue; at most one contrast stage); gray_sum: (B) fp64 device workspace,
-// zeroed by the caller, required iff a contrast stage is present; enable: (4) uint8 on the DEVICE indexed by stage id,
-// 0 = skip every stage of that kind (the reference's `(factor != neutral).any()` guards without a host sync), nullable.
-int km_color_jitter_fwd(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const int* stages,
-                        int n_stages, int B, int H, int W, int dtype, void* stream) {
+static int kmc_entry(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const void* apply, const int* stages,
+                     int n_stages, int B, int H, int W, int dtype, void* stream) {
     if (B == 0 || H == 0 || W == 0) return 0;
     KM_REQUIRE(x && y && params, "km_color_jitter_fwd: null pointer");
     KM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "km_color_jitter_fwd: bad shape B=%d H=%d W=%d", B, H, W);
@@ -229,11 +228,30 @@ int km_color_jitter_fwd(const void* x, void* y, const void* params, double* gray
     KM_REQUIRE(n_contrast <= 1, "km_color_jitter_fwd: at most one contrast stage");
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
-        case KM_F32: return kmc_run<float>(x, y, params, gray_sum, enable, stages, n_stages, B, H, W, s);
-        case KM_BF16: return kmc_run<km_bf16>(x, y, params, gray_sum, enable, stages, n_stages, B, H, W, s);
-        case KM_F16: return kmc_run<km_f16>(x, y, params, gray_sum, enable, stages, n_stages, B, H, W, s);
+        case KM_F32: return kmc_run<float>(x, y, params, gray_sum, enable, apply, stages, n_stages, B, H, W, s);
+        case KM_BF16: return kmc_run<km_bf16>(x, y, params, gray_sum, enable, apply, stages, n_stages, B, H, W, s);
+        case KM_F16: return kmc_run<km_f16>(x, y, params, gray_sum, enable, apply, stages, n_stages, B, H, W, s);
         default: km_set_error("km_color_jitter_fwd: dtype must be f32 / bf16 / f16"); return -1;
     }
+}
+
+extern "C" {
+
+// x, y: (B,3,H,W) RGB in `dtype` (f32 / bf16 / f16); params: (B,4) fp32 on the device - brightness factor, contrast
+// factor, saturation factor, hue shift in RADIANS; stages: HOST array of n_stages (<= 4) ids in application order
+// (0 brightness, 1 contrast, 2 saturation, 3 hue; at most one contrast stage); gray_sum: (B) fp64 device workspace,
+// zeroed by the caller, required iff a contrast stage is present; enable: (4) uint8 on the DEVICE indexed by stage id,
+// 0 = skip every stage of that kind (the reference's `(factor != neutral).any()` guards without a host sync), nullable.
+int km_color_jitter_fwd(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const int* stages,
+                        int n_stages, int B, int H, int W, int dtype, void* stream) {
+    return kmc_entry(x, y, params, gray_sum, enable, nullptr, stages, n_stages, B, H, W, dtype, stream);
+}
+
+// ... with the augmentation layer's per-sample switch (kornia/augmentation/base.py:348-393): apply (B) uint8 on the device, a sample
+// whose entry is 0 is copied unchanged (and does not enter the contrast mean pass)
+int km_color_jitter_fwd_masked(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const void* apply,
+                               const int* stages, int n_stages, int B, int H, int W, int dtype, void* stream) {
+    return kmc_entry(x, y, params, gray_sum, enable, apply, stages, n_stages, B, H, W, dtype, stream);
 }
 
 }  // extern "C"

@@ -40,9 +40,28 @@ struct KmWarpArgs {
     const R* fill;    // (C) compute dtype, pad == fill only
     const T* grid;    // KM_COORD_GRID: (B_M,h,w,2) normalised sampling grid in the image dtype
     R* ggrid;         // KM_COORD_GRID bwd: (B,h,w,2) gradient wrt the grid, written (nullable)
+    const uint8_t* apply;  // fwd, nullable: (B) per-sample switch of the augmentation layer - a sample whose entry is 0 is copied (h == H, w == W)
     KmWarpGeom<R> g;
     uint32_t tiles_x, tiles_y, nblocks;
 };
+
+// The per-sample probability blend of the augmentation layer (kornia/augmentation/base.py:348-393) folded into the forward: a
+// sample that is NOT transformed is copied by the workgroups that would have warped it (same mapping: this thread's column j, rows
+// i_base + r * row_step), so `torch.where(to_apply, transformed, input)` - a third full pass - disappears.
+template <typename T>
+__device__ __forceinline__ void km_fwd_copy_rows(const KmWarpArgs<T>& a, uint32_t b, int j, int i_base, int row_step, int n_rows) {
+    const auto& g = a.g;
+    if (j >= g.w) return;
+    const size_t plane = (size_t)g.h * g.w;  // == H * W (checked on the host)
+    for (int c = 0; c < g.C; ++c) {
+        const T* __restrict__ sp = a.src + ((size_t)b * g.C + c) * plane;
+        T* __restrict__ dp = a.dst + ((size_t)b * g.C + c) * plane;
+        for (int r = 0; r < n_rows; ++r) {
+            const int i = i_base + r * row_step;
+            if (i < g.h) dp[(size_t)i * g.w + j] = sp[(size_t)i * g.w + j];
+        }
+    }
+}
 
 template <typename T, int CM, int INTERP>
 __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a) {
@@ -60,6 +79,10 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
     const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
     const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // this thread's row r sits at tile row li_base + r * PH
     const int i_base = (int)ty * KM_TILE_H + li_base;
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
+        km_fwd_copy_rows<T>(a, b, j, i_base, PH, KM_ROWS);
+        return;
+    }
     __shared__ R s_v[KM_TILE_H];
     if (threadIdx.x < KM_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KM_TILE_H + (int)threadIdx.x);
     __syncthreads();
@@ -234,6 +257,10 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
     const int j = (int)tx * KM_TILE_W + (wave % WA) * PW + (lane % PW);
     const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;  // row inside the tile of this thread's row r: li_base + r * PH
     const int i_base = (int)ty * KM_TILE_H + li_base;
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
+        km_fwd_copy_rows<T>(a, b, j, i_base, PH, KM_ROWS);
+        return;
+    }
     __shared__ R s_v[KM_TILE_H];
     if (threadIdx.x < KM_TILE_H) s_v[threadIdx.x] = km_base_y<R, CM>(g, (int)ty * KM_TILE_H + (int)threadIdx.x);
     __syncthreads();
@@ -468,6 +495,10 @@ __global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<
     const int i_base = (int)ty * KML_TILE_H + li_base;
     __shared__ float4 s_rv[KML_TILE_H];
     __shared__ int s_fast;
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
+        for (int gr = 0; gr < KML_GROUPS; ++gr) km_fwd_copy_rows<T>(a, b, j, i_base + gr * KM_TILE_H, PH, KM_ROWS);
+        return;
+    }
 
     float m[9];
     {
@@ -712,6 +743,10 @@ __global__ __launch_bounds__(256) void km_warp_fwd_lds_kernel(const KmWarpArgs<T
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = mp[k];
     }
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
+        km_fwd_copy_rows<T>(a, b, j, i_base, KMF_RSTEP, KMF_RPT);
+        return;
+    }
     kmf_tile_setup<CM, ALIGN>(g, m, (int)tx * KMF_T, (int)ty * KMF_T, s_rv, s_info, false);
     __syncthreads();
     const KmfBox bx = kmf_read_box(s_info);
@@ -852,9 +887,11 @@ static int km_warp_dispatch_interp(bool bwd, const KmWarpArgs<T>& a, hipStream_t
 template <typename T>
 static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, const void* gout, void* gsrc, double* gmat,
                        int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp,
-                       int pad, int align, const void* fill, hipStream_t s, const void* grid = nullptr, void* ggrid = nullptr) {
+                       int pad, int align, const void* fill, hipStream_t s, const void* grid = nullptr, void* ggrid = nullptr,
+                       const void* apply = nullptr) {
     typedef typename KmTraits<T>::R R;
     KmWarpArgs<T> a;
+    a.apply = (const uint8_t*)apply;
     a.src = (const T*)src;
     a.mat = (const R*)mat;
     a.dst = (T*)dst;
@@ -923,6 +960,23 @@ int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int
         case KM_F64: return km_warp_run<double>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         case KM_BF16: return km_warp_run<km_bf16>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         default: return km_warp_run<km_f16>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
+    }
+}
+
+// km_warp2d_fwd with the augmentation layer's per-sample switch folded in (kornia/augmentation/base.py:348-393): apply (B) uint8 on
+// the device; a sample whose entry is 0 is copied instead of warped.  Needs h == H and w == W (what torch.where needs too).
+int km_warp2d_fwd_masked(const void* src, const void* mat, void* dst, const void* apply, int B, int C, int H, int W, int h, int w, int B_M,
+                         int coord_mode, int norm_coords, int interp, int pad, int align, const void* fill, int dtype, void* stream) {
+    if (B == 0 || C == 0 || h == 0 || w == 0) return 0;  // empty output
+    if (km_warp_validate("km_warp2d_fwd_masked", src, mat, B, C, H, W, h, w, B_M, coord_mode, interp, pad, fill, dtype)) return -1;
+    KM_REQUIRE(dst, "km_warp2d_fwd_masked: null dst");
+    KM_REQUIRE(!apply || (h == H && w == W), "km_warp2d_fwd_masked: a per-sample switch needs equal source and destination sizes (%dx%d -> %dx%d)", H, W, h, w);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return km_warp_run<float>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s, nullptr, nullptr, apply);
+        case KM_F64: return km_warp_run<double>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s, nullptr, nullptr, apply);
+        case KM_BF16: return km_warp_run<km_bf16>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s, nullptr, nullptr, apply);
+        default: return km_warp_run<km_f16>(false, src, mat, dst, nullptr, nullptr, nullptr, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s, nullptr, nullptr, apply);
     }
 }
 

@@ -49,7 +49,8 @@ def _factor_column(f: Factor, B: int, device, neutral: float) -> torch.Tensor:
     return f
 
 
-def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], enable: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], enable: Optional[torch.Tensor] = None,
+         apply: Optional[torch.Tensor] = None) -> torch.Tensor:
     N.require_device(image, "image")
     if not isinstance(image, torch.Tensor):
         raise TypeError(f"Input type is not a torch.Tensor. Got {type(image)}")
@@ -71,10 +72,16 @@ def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], 
     gray_sum = torch.zeros(B, device=dev, dtype=torch.float64) if CONTRAST in stages else None
     arr = (ctypes.c_int * max(len(stages), 1))(*stages)
     if enable is not None:
-        enable = enable.detach().to(device=dev).reshape(4).ne(0).to(torch.uint8).contiguous()
+        enable = N.flags(enable, dev, 4)
+    if apply is not None:  # the augmentation layer's per-sample switch: samples whose entry is 0 are copied by the same launch
+        apply = N.flags(apply, dev, B)
     with N.device_guard(dev):
-        N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
-                                            N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
+        if apply is None:
+            N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
+                                                N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
+        else:
+            N.check(N.lib().km_color_jitter_fwd_masked(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), apply.data_ptr(), arr,
+                                                       len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd_masked")
     return out.reshape(shape)
 
 
@@ -101,7 +108,8 @@ def adjust_hue(image: torch.Tensor, factor: Union[float, torch.Tensor]) -> torch
 
 
 def color_jitter(image: torch.Tensor, brightness_factor: Factor = None, contrast_factor: Factor = None, saturation_factor: Factor = None,
-                 hue_factor: Factor = None, order: Optional[Sequence[int]] = None, enable: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 hue_factor: Factor = None, order: Optional[Sequence[int]] = None, enable: Optional[torch.Tensor] = None,
+                 apply: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The ColorJitter sequence in one kernel.
 
     Factors follow ``ColorJitterGenerator`` (per-image tensors of shape (B,) or floats; ``None`` skips the stage):
@@ -110,6 +118,8 @@ def color_jitter(image: torch.Tensor, brightness_factor: Factor = None, contrast
     0 brightness, 1 contrast, 2 saturation, 3 hue (default 0,1,2,3); stages whose factor is ``None`` are dropped.
     ``enable``: optional (4,) device tensor indexed by stage id; a zero entry skips that stage - this is how the
     module's ``(factor != neutral).any()`` guards are honoured without a host synchronisation.
+    ``apply``: optional (B,) device tensor, the augmentation layer's per-sample switch - a sample whose entry is zero is returned
+    unchanged by the same launch (``_AugmentationBase._blend_by_prob``, kornia/augmentation/base.py:348-393, without its extra pass).
     """
     given = {BRIGHTNESS: brightness_factor, CONTRAST: contrast_factor, SATURATION: saturation_factor, HUE: hue_factor}
     order = [0, 1, 2, 3] if order is None else [int(i) for i in (order.tolist() if isinstance(order, torch.Tensor) else order)]
@@ -117,4 +127,4 @@ def color_jitter(image: torch.Tensor, brightness_factor: Factor = None, contrast
     hue = hue_factor
     if hue is not None:
         hue = hue * (2.0 * math.pi) if not isinstance(hue, torch.Tensor) else hue.float() * (2.0 * math.pi)
-    return _run(image, (brightness_factor, contrast_factor, saturation_factor, hue), stages, enable)
+    return _run(image, (brightness_factor, contrast_factor, saturation_factor, hue), stages, enable, apply)

@@ -53,7 +53,7 @@ class _Warp2dFunction(torch.autograd.Function):
     dst->src homography (B_M,3,3) [homography]; fill: (C,) compute-dtype tensor or None."""
 
     @staticmethod
-    def forward(ctx, src: torch.Tensor, mat: torch.Tensor, fill: Optional[torch.Tensor], cfg: _WarpCfg):
+    def forward(ctx, src: torch.Tensor, mat: torch.Tensor, fill: Optional[torch.Tensor], cfg: _WarpCfg, apply: Optional[torch.Tensor] = None):
         lib = N.lib()
         dev = src.device
         cdt = N.compute_dtype(src.dtype)
@@ -71,9 +71,14 @@ class _Warp2dFunction(torch.autograd.Function):
                 m = torch.empty(B_M, 9, device=dev, dtype=cdt)
                 N.check(lib.km_homography_chain_fwd(Mc.data_ptr(), Mc.shape[1], None, m.data_ptr(), B_M, H, W, h, w,
                                                     N.dtype_code(cdt), stream), "km_homography_chain_fwd")
-            N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), out.data_ptr(), B, C, H, W, h, w, B_M, cfg.coord_mode,
-                                      cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill), N.dtype_code(src.dtype),
-                                      stream), "km_warp2d_fwd")
+            if apply is None:
+                N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), out.data_ptr(), B, C, H, W, h, w, B_M, cfg.coord_mode,
+                                          cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill), N.dtype_code(src.dtype),
+                                          stream), "km_warp2d_fwd")
+            else:  # the augmentation layer's per-sample switch, folded into the launch (forward only: _warp refuses it under autograd)
+                N.check(lib.km_warp2d_fwd_masked(x.data_ptr(), m.data_ptr(), out.data_ptr(), apply.data_ptr(), B, C, H, W, h, w, B_M, cfg.coord_mode,
+                                                 cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill), N.dtype_code(src.dtype),
+                                                 stream), "km_warp2d_fwd_masked")
         ctx.save_for_backward(x, Mc, m, fill)
         ctx.cfg = cfg
         ctx.mat_dtype = mat.dtype
@@ -112,7 +117,7 @@ class _Warp2dFunction(torch.autograd.Function):
                     gmat = gM.to(ctx.mat_dtype)
         if gsrc is not None and gsrc.dtype != x.dtype:
             gsrc = gsrc.to(x.dtype)
-        return gsrc, gmat, None, None
+        return gsrc, gmat, None, None, None
 
 
 class _GridSampleFunction(torch.autograd.Function):
@@ -215,7 +220,7 @@ def _prepare_fill(fill_value: torch.Tensor, C: int, device, cdt) -> torch.Tensor
     return f.contiguous()
 
 
-def _warp(src, mat, dsize, coord_mode, norm_coords, mode, padding_mode, align_corners, fill_value):
+def _warp(src, mat, dsize, coord_mode, norm_coords, mode, padding_mode, align_corners, fill_value, apply=None):
     N.require_device(src, "src")
     interp, pad = _mode_codes(mode, padding_mode)
     B, C = src.shape[0], src.shape[1]
@@ -230,7 +235,13 @@ def _warp(src, mat, dsize, coord_mode, norm_coords, mode, padding_mode, align_co
     if pad == _PAD["fill"]:
         fill = _prepare_fill(fill_value, C, src.device, N.compute_dtype(src.dtype))
     cfg = _WarpCfg((int(dsize[0]), int(dsize[1])), coord_mode, int(bool(norm_coords)), interp, pad, int(bool(align_corners)))
-    return _Warp2dFunction.apply(src, mat, fill, cfg)
+    if apply is not None:
+        if torch.is_grad_enabled() and (src.requires_grad or mat.requires_grad):
+            raise RuntimeError("the per-sample switch of the warp is forward-only")
+        if tuple(cfg.dsize) != tuple(src.shape[-2:]) or apply.numel() != B:
+            raise ValueError("the per-sample switch needs dsize == the source size and one entry per sample")
+        apply = N.flags(apply, src.device, B)
+    return _Warp2dFunction.apply(src, mat, fill, cfg, apply)
 
 
 def warp_perspective(
