@@ -32,6 +32,10 @@ HIPCC_FLAGS = [
 ]
 
 
+# per-file additions to HIPCC_FLAGS (the reason is in the header of each file)
+FILE_FLAGS = {"km_warp_cubic.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -52,7 +56,7 @@ def _compile(src: str, force: bool, verbose: bool) -> tuple[str, bool]:
     newest = max(os.path.getmtime(src), _headers_mtime(), os.path.getmtime(__file__))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *HIPCC_FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

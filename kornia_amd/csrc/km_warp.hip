@@ -16,6 +16,7 @@
 // (read grad_out, read src, write grad_src) - see DESIGN.md.
 #include <stdlib.h>
 
+#include "km_warp_args.h"
 #include "km_warp_stage.h"
 
 #ifndef KM_ROWS
@@ -27,41 +28,6 @@
 #define KM_PATCH_W 32  // output columns covered by one wave instruction of the specialised forward (64, 32 or 16);
                        // measured at 256x3x512^2: 64 -> 0.434 ms (0.78 at 20 deg rotation), 32 -> 0.422 (0.67), 16 -> 0.492 (0.64)
 #endif
-
-template <typename T>
-struct KmWarpArgs {
-    typedef typename KmTraits<T>::R R;
-    const T* src;     // (B,C,H,W)
-    const R* mat;     // (B_M,9) row-major, compute dtype
-    T* dst;           // fwd: (B,C,h,w)
-    const T* gout;    // bwd: (B,C,h,w)
-    R* gsrc;          // bwd: (B,C,H,W) accumulators in compute dtype, pre-zeroed (nullable)
-    double* gmat;     // bwd: (B_M,9) fp64 accumulators, pre-zeroed (nullable)
-    const R* fill;    // (C) compute dtype, pad == fill only
-    const T* grid;    // KM_COORD_GRID: (B_M,h,w,2) normalised sampling grid in the image dtype
-    R* ggrid;         // KM_COORD_GRID bwd: (B,h,w,2) gradient wrt the grid, written (nullable)
-    const uint8_t* apply;  // fwd, nullable: (B) per-sample switch of the augmentation layer - a sample whose entry is 0 is copied (h == H, w == W)
-    KmWarpGeom<R> g;
-    uint32_t tiles_x, tiles_y, nblocks;
-};
-
-// The per-sample probability blend of the augmentation layer (kornia/augmentation/base.py:348-393) folded into the forward: a
-// sample that is NOT transformed is copied by the workgroups that would have warped it (same mapping: this thread's column j, rows
-// i_base + r * row_step), so `torch.where(to_apply, transformed, input)` - a third full pass - disappears.
-template <typename T>
-__device__ __forceinline__ void km_fwd_copy_rows(const KmWarpArgs<T>& a, uint32_t b, int j, int i_base, int row_step, int n_rows) {
-    const auto& g = a.g;
-    if (j >= g.w) return;
-    const size_t plane = (size_t)g.h * g.w;  // == H * W (checked on the host)
-    for (int c = 0; c < g.C; ++c) {
-        const T* __restrict__ sp = a.src + ((size_t)b * g.C + c) * plane;
-        T* __restrict__ dp = a.dst + ((size_t)b * g.C + c) * plane;
-        for (int r = 0; r < n_rows; ++r) {
-            const int i = i_base + r * row_step;
-            if (i < g.h) dp[(size_t)i * g.w + j] = sp[(size_t)i * g.w + j];
-        }
-    }
-}
 
 template <typename T, int CM, int INTERP>
 __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a) {
@@ -809,6 +775,9 @@ __global__ __launch_bounds__(256) void km_warp_fwd_lds_kernel(const KmWarpArgs<T
     }
 }
 
+// LDS-staged bicubic forward (km_warp_cubic.hip): launches and returns 1 when it takes the case, 0 otherwise
+int km_warp_fwd_cubic_try_any(int dtype, int coord_mode, const void* args, hipStream_t s);
+
 // the specialised forward: bilinear + zeros, fp32 compute, 32-bit byte offsets inside a plane, 24-bit row / column counts
 template <typename T, int CM>
 static bool km_fwd_lean_ok(const KmWarpArgs<T>& a) {
@@ -870,6 +839,7 @@ static int km_warp_launch(bool bwd, const KmWarpArgs<T>& a, hipStream_t s) {
             hipLaunchKernelGGL((km_warp_fwd_bz_kernel<T, CM, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((km_warp_fwd_bz_kernel<T, CM, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
+    } else if (INTERP == KM_INTERP_BICUBIC && !km_fwd_generic_forced() && km_warp_fwd_cubic_try_any(KmTraits<T>::code, CM, &a, s)) {
     } else
         hipLaunchKernelGGL((km_warp_fwd_kernel<T, CM, INTERP>), dim3(a.nblocks), dim3(256), 0, s, a);
     return km_check_launch(bwd ? "km_warp2d_bwd" : "km_warp2d_fwd");

@@ -36,15 +36,18 @@ struct KmfBox {
 };
 
 // wave 0: row table (m1 v, m4 v, m7 v, keep_v ? v : 0) + division guard; wave 1: the source box.  Needs a barrier before kmf_read_box.
-template <int CM, int ALIGN>
+// MARGIN: extra source pixels around the 2 x 2 footprint that the consumer reads (bicubic: 1 -> columns floor(x) - 1 .. floor(x) + 2)
+// TW x TH: the output tile; PITCH x ROWS: the capacity of the staged box (the defaults are the bilinear kernels' 32 x 32 / 56 x 56)
+template <int CM, int ALIGN, int MARGIN = 0, int TW = KMF_T, int TH = KMF_T, int PITCH = KMF_PITCH, int ROWS = KMF_ROWS>
 __device__ __forceinline__ void kmf_tile_setup(const KmWarpGeom<float>& g, const float (&m)[9], int j0, int i0, float4* s_rv, int* s_info, bool keep_v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int W = g.W, H = g.H;
     const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
-    const int j1 = min(j0 + KMF_T - 1, g.w - 1), i1 = min(i0 + KMF_T - 1, g.h - 1);
+    static_assert(TH <= 64, "one wave fills the row table");
+    const int j1 = min(j0 + TW - 1, g.w - 1), i1 = min(i0 + TH - 1, g.h - 1);
     if (wave == 0) {
         bool ok = true;
-        if (lane < KMF_T) {
+        if (lane < TH) {
             const float v = km_base_y<float, CM>(g, i0 + lane);
             const KmlHalf h = kml_row_half<CM>(m, v);
             s_rv[lane] = make_float4(h.a, h.b, h.c, keep_v ? v : 0.f);
@@ -72,12 +75,12 @@ __device__ __forceinline__ void kmf_tile_setup(const KmWarpGeom<float>& g, const
         if (lane == 0) {
             // taps of a pixel at (x, y): columns floor(x), floor(x) + 1; one more on each side for the rounding of positions
             // inside the quad relative to its corners (<< 1 px) - checked per pixel anyway
-            const int bx0 = (int)km_floor(xmin) - 1, bx1 = (int)km_floor(xmax) + 2;
-            const int by0 = (int)km_floor(ymin) - 1, by1 = (int)km_floor(ymax) + 2;
+            const int bx0 = (int)km_floor(xmin) - 1 - MARGIN, bx1 = (int)km_floor(xmax) + 2 + MARGIN;
+            const int by0 = (int)km_floor(ymin) - 1 - MARGIN, by1 = (int)km_floor(ymax) + 2 + MARGIN;
             const int xs = bx0 & ~3;  // 16-byte aligned start (two's complement: rounds toward -inf)
             const int wcols = bx1 - xs + 1, nrows = by1 - by0 + 1;
             const bool same_sign = (dmin > 0.f) || (dmax < 0.f);
-            const bool staged = finite4 && same_sign && wcols <= KMF_PITCH && nrows <= KMF_ROWS;
+            const bool staged = finite4 && same_sign && wcols <= PITCH && nrows <= ROWS;
             s_info[1] = staged ? 1 : 0;
             s_info[2] = xs;
             s_info[3] = by0;
@@ -137,9 +140,51 @@ __device__ __forceinline__ void kmf_stage_box(const T* __restrict__ src_b, size_
     }
 }
 
+// The same copy for any box capacity (PITCH floats per staged row): 16 or 32 lanes per source row, chosen per block from the
+// box width, four row loads of a thread in flight before their LDS stores.  Layout s_src[row][channel][PITCH].
+template <typename T, int NC, int PITCH>
+__device__ __forceinline__ void kmf_stage_box_dyn(const T* __restrict__ src_b, size_t src_plane, int W, int H, const KmfBox& bx, float* s_src,
+                                                  const float (&oob)[NC]) {
+    static_assert((PITCH % 4) == 0 && PITCH / 4 <= 32, "32 lanes x 16 bytes cover a staged row");
+    const int shift = bx.nch <= 16 ? 4 : 5;  // block-uniform
+    const int tid = threadIdx.x, ck = tid & ((1 << shift) - 1), r0 = tid >> shift, rpp = 256 >> shift;
+    const int x = bx.xs + 4 * ck;
+    const bool col_in = (ck < bx.nch) && (x >= 0) && (x + 3 < W);  // W % 4 == 0 and xs % 4 == 0: a chunk is inside or outside as a whole
+    for (int base = 0; base < bx.nrows; base += 4 * rpp) {
+        float v[4][NC][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = base + r0 + k * rpp, y = bx.ys + r;
+            const bool inb = col_in && (r < bx.nrows) && (y >= 0) && (y < H);
+            const uint32_t off = inb ? (uint32_t)y * (uint32_t)W + (uint32_t)x : 0u;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (inb) km_ld4(km_at(src_b + c * src_plane, off), v[k][c]);
+                else { v[k][c][0] = oob[c]; v[k][c][1] = oob[c]; v[k][c][2] = oob[c]; v[k][c][3] = oob[c]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = base + r0 + k * rpp;
+            if ((ck < bx.nch) && (r < bx.nrows)) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float* q = s_src + (r * NC + c) * PITCH + 4 * ck;
+                    KM_CHECK_ALIGNED(q, 16);
+                    *reinterpret_cast<float4*>(q) = make_float4(v[k][c][0], v[k][c][1], v[k][c][2], v[k][c][3]);
+                }
+            }
+        }
+    }
+}
+
 // the 2 x 2 footprint of a pixel lies in the staged box (NaN / inf positions do not)
 __device__ __forceinline__ bool kmf_in_box(const KmlTaps& t, const KmfBox& bx) {
     return (t.xf >= bx.bxlo) & (t.xf <= bx.bxhi) & (t.yf >= bx.bylo) & (t.yf <= bx.byhi);
+}
+// the 4 x 4 footprint of a bicubic sample at floor (xf, yf) lies in the staged box
+__device__ __forceinline__ bool kmf_in_box_cubic(float xf, float yf, const KmfBox& bx) {
+    return (xf >= bx.bxlo + 1.0f) & (xf <= bx.bxhi - 1.0f) & (yf >= bx.bylo + 1.0f) & (yf <= bx.byhi - 1.0f);
 }
 // LDS address of the north-west tap of channel 0 (channel c: + c * KMF_PITCH ; next row: + NC * KMF_PITCH); !valid: the box origin
 template <int NC>

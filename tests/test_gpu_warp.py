@@ -1,6 +1,8 @@
 """GPU parity of the warp path against the CPU oracle (called through the kornia-compatible API,
 i.e. through the C ABI).  fp32 forward results are required to be BIT-IDENTICAL to the oracle, which
 itself is bit-identical to the reference's CPU path (tests/golden, test_oracle_golden.py)."""
+import math
+
 import pytest
 import torch
 
@@ -335,3 +337,42 @@ def test_tiled_backward_nonfinite_gradients_propagate(oracle):
     assert torch.equal(torch.isnan(gs), torch.isnan(gs_o)) and torch.equal(torch.isinf(gs), torch.isinf(gs_o))
     fin = torch.isfinite(gs_o)
     assert torch.allclose(gs[fin], gs_o[fin], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [1, 3])
+def test_bicubic_lds_staged_kernel_is_bit_identical(oracle, C, dtype):
+    """The LDS-staged bicubic forward (km_warp_fwd_cubic_kernel: zeros padding, C in {1, 3}, W % 4 == 0, 16-byte aligned source)
+    against (a) the oracle, bit for bit in fp32, and (b) the per-pixel gather kernel, reached by handing the same image over at an
+    address that is not 16-byte aligned: small and large rotations, minification (source box larger than the LDS tile -> the
+    gather path inside the staged kernel), magnification, a projective map, a map that leaves the image."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(41)
+    B, H, W = 7, 72, 96
+    x = torch.rand(B, C, H, W, generator=g).to(dtype)
+    ang = torch.tensor([2.0, 31.0, -88.0, 5.0, 0.0, 170.0, 45.0]) * math.pi / 180
+    sc = torch.tensor([1.0, 1.0, 1.1, 0.35, 2.7, 1.0, 0.9])
+    a, b = sc * ang.cos(), sc * ang.sin()
+    cx, cy = (W - 1) / 2, (H - 1) / 2
+    A = torch.stack([torch.stack([a, b, (1 - a) * cx - b * cy + torch.tensor([0.3, -4.0, 2.0, 0.0, 1.5, 0.0, 40.0])], -1),
+                     torch.stack([-b, a, b * cx + (1 - a) * cy + torch.tensor([-0.7, 3.0, 0.0, 2.5, 0.0, -1.0, -25.0])], -1)], 1)
+    M = torch.cat([A, torch.tensor([[0.0, 0.0, 1.0]]).expand(B, 1, 3)], 1).clone()
+    M[:, 2, 0] = torch.tensor([0.0, 1e-3, -2e-3, 0.0, 5e-4, 0.0, 2e-3])
+    M[:, 2, 1] = torch.tensor([0.0, -1e-3, 1e-3, 2e-3, 0.0, 0.0, -1e-3])
+    xd = x.cuda()
+    off = torch.empty(x.numel() + 1, dtype=dtype, device="cuda")[1:].view_as(x)  # same values, 4- / 2-byte aligned only
+    off.copy_(xd)
+    assert off.data_ptr() % 16 != 0
+    for ds in ((H, W), (50, 64), (33, 130)):
+        for align in (True, False):
+            got = K.warp_affine(xd, A.cuda(), ds, "bicubic", "zeros", align)
+            assert torch.equal(got, K.warp_affine(off, A.cuda(), ds, "bicubic", "zeros", align)), (ds, align, "affine")
+            gotp = K.warp_perspective(xd, M.cuda(), ds, "bicubic", "zeros", align)
+            assert torch.equal(gotp, K.warp_perspective(off, M.cuda(), ds, "bicubic", "zeros", align)), (ds, align, "perspective")
+            if dtype == torch.float32:
+                assert torch.equal(got.cpu(), oracle.warp_affine(x, A, ds, "bicubic", "zeros", align, None)), (ds, align)
+                assert torch.equal(gotp.cpu(), oracle.warp_perspective(x, M, ds, "bicubic", "zeros", align, None)), (ds, align)
+    Hn = torch.eye(3)[None].repeat(B, 1, 1) + 0.05 * torch.randn(B, 3, 3, generator=g)
+    goth = K.homography_warp(xd, Hn.cuda(), (H, W), "bicubic", "zeros", True)
+    assert torch.equal(goth, K.homography_warp(off, Hn.cuda(), (H, W), "bicubic", "zeros", True))
