@@ -208,6 +208,14 @@ int km_warp2d_fwd_masked(const void* src, const void* mat, void* dst, const void
                          int dtype, void* stream);
 int km_color_jitter_fwd_masked(const void* x, void* y, const void* params, double* gray_sum, const void* enable,
                                const void* apply, const int* stages, int n_stages, int B, int H, int W, int dtype, void* stream);
+
+/* Backward of km_color_jitter_fwd(_masked) - the reference's adjustments are differentiable through autograd
+ * (kornia/enhance/adjust.py:80-593, kornia/color/hsv.py:27-131).  gx = d loss / d x given gy, same stage list / params / enable /
+ * apply as the forward.  gray_sum: (B) fp64, the forward's workspace as the forward left it; gsum: (B) fp64 workspace zeroed by
+ * the caller - both required iff a contrast stage is present.  gparams: (B,4) fp64 accumulators zeroed by the caller
+ * (d loss / d params, hue in radians), or NULL. */
+int km_color_jitter_bwd(const void* x, const void* gy, void* gx, const void* params, const double* gray_sum, double* gsum, double* gparams,
+                        const void* enable, const void* apply, const int* stages, int n_stages, int B, int H, int W, int dtype, void* stream);
 int km_select_samples_fwd(const void* transformed, const void* original, const void* apply, void* out, int B,
                           long long n_per_sample, int dtype, void* stream);
 

@@ -235,6 +235,261 @@ static int kmc_entry(const void* x, void* y, const void* params, double* gray_su
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward (the reference's ops are differentiable: kornia/enhance/adjust.py:80-593 through autograd).  One thread recomputes the
+// stage chain of its pixel, keeps every stage's input in registers and walks the stages in reverse with the transposed Jacobians
+// that autograd applies to the reference's op sequence:
+//   clamp            grad * (0 <= u <= 1)                                    (ATen clamp_backward: bounds inclusive)
+//   brightness       gx = f g m ;  df = sum g m x
+//   saturation       gx_k = (1 - f) w_k sum_c(g m)_c + f (g m)_k ;  df = sum (g m)_c (x_c - gray)
+//   contrast         gx_k = f (g m)_k + (1 - f) w_k S / HW,  S = sum over the IMAGE of (g m) - the mean couples every pixel, so a first
+//                    pass (MODE 0) back-propagates down to the contrast stage and accumulates S per image (fp64), the second pass
+//                    (MODE 1) uses it ;  df = sum (g m)_c (x_c - mean)
+//   hue              the 3 x 4 Jacobian d(r', g', b') / d(r, g, b, shift) by forward-mode differentiation of kmc_hue's own operation
+//                    sequence (KmcD: value + 4 tangents) with autograd's rules: amax / amin split the gradient evenly among ties,
+//                    where() passes it to the selected side, floor / remainder-by-constant / fmod have slope 0 / 1 / 1
+struct KmcD {
+    float v, d[4];
+};
+__device__ __forceinline__ KmcD kd_c(float v) { return {v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ KmcD kd_add(const KmcD& a, const KmcD& b) { return {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}}; }
+__device__ __forceinline__ KmcD kd_sub(const KmcD& a, const KmcD& b) { return {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}}; }
+__device__ __forceinline__ KmcD kd_scale(const KmcD& a, float c) { return {a.v * c, {a.d[0] * c, a.d[1] * c, a.d[2] * c, a.d[3] * c}}; }
+__device__ __forceinline__ KmcD kd_mul(const KmcD& a, const KmcD& b) {
+    return {a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2], a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ KmcD kd_div(const KmcD& a, const KmcD& b) {
+    const float q = a.v / b.v, ib = 1.0f / b.v;
+    return {q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib, (a.d[3] - q * b.d[3]) * ib}};
+}
+__device__ __forceinline__ KmcD kd_one_minus(const KmcD& a) { return {1.0f - a.v, {-a.d[0], -a.d[1], -a.d[2], -a.d[3]}}; }
+
+// J[c][k] = d out_c / d (r, g, b, shift)_k of kmc_hue at (r, g, b)
+__device__ __forceinline__ void kmc_hue_jacobian(float r, float g, float b, float shift, float (&J)[3][4]) {
+    const float two_pi = 6.283185307179586f;
+    const KmcD R = {r, {1.f, 0.f, 0.f, 0.f}}, G = {g, {0.f, 1.f, 0.f, 0.f}}, B = {b, {0.f, 0.f, 1.f, 0.f}};
+    const float mxv = fmaxf(r, fmaxf(g, b)), mnv = fminf(r, fminf(g, b));
+    const float xr = (r == mxv) ? 1.f : 0.f, xg = (g == mxv) ? 1.f : 0.f, xb = (b == mxv) ? 1.f : 0.f, xc = 1.0f / fmaxf(xr + xg + xb, 1.0f);
+    const float nr = (r == mnv) ? 1.f : 0.f, ng = (g == mnv) ? 1.f : 0.f, nb = (b == mnv) ? 1.f : 0.f, nc = 1.0f / fmaxf(nr + ng + nb, 1.0f);
+    const KmcD MX = {mxv, {xr * xc, xg * xc, xb * xc, 0.f}}, MN = {mnv, {nr * nc, ng * nc, nb * nc, 0.f}};
+    const KmcD delta = kd_sub(MX, MN);
+    const KmcD V = MX;
+    KmcD mxe = MX;
+    mxe.v = MX.v + 1e-8f;
+    const KmcD S = kd_div(delta, mxe);
+    const KmcD dc = (delta.v == 0.0f) ? kd_c(1.0f) : delta;
+    const KmcD rc = kd_sub(MX, R), gc = kd_sub(MX, G), bc = kd_sub(MX, B);
+    const KmcD h1 = kd_sub(bc, gc), h2 = kd_add(kd_sub(rc, bc), kd_scale(dc, 2.0f)), h3 = kd_add(kd_sub(gc, rc), kd_scale(dc, 4.0f));
+    KmcD h = ((r >= g) && (r >= b)) ? h1 : ((g >= b) ? h2 : h3);
+    h = kd_div(h, dc);
+    h = kd_scale(h, 1.0f / 6.0f);
+    h.v = kmc_pymod(h.v, 1.0f);
+    h = kd_scale(h, two_pi);
+    h.v = kmc_fmod_small(h.v + shift, two_pi);
+    h.d[3] = h.d[3] + 1.0f;
+    const KmcD h6 = kd_scale(kd_scale(h, 1.0f / two_pi), 6.0f);
+    const float hi = kmc_pymod(floorf(h6.v), 6.0f);
+    KmcD f = h6;
+    f.v = kmc_pymod(h6.v, 6.0f) - hi;
+    const KmcD p = kd_mul(V, kd_one_minus(S));
+    const KmcD q = kd_mul(V, kd_one_minus(kd_mul(f, S)));
+    const KmcD t = kd_mul(V, kd_one_minus(kd_mul(kd_one_minus(f), S)));
+    int k = (int)hi;
+    k = k < 0 ? 0 : (k > 5 ? 5 : k);
+    const KmcD& orr = (k == 0) ? V : (k == 1) ? q : (k == 2) ? p : (k == 3) ? p : (k == 4) ? t : V;
+    const KmcD& og = (k == 0) ? t : (k == 1) ? V : (k == 2) ? V : (k == 3) ? q : (k == 4) ? p : p;
+    const KmcD& ob = (k == 0) ? p : (k == 1) ? p : (k == 2) ? t : (k == 3) ? V : (k == 4) ? V : q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { J[0][j] = orr.d[j]; J[1][j] = og.d[j]; J[2][j] = ob.d[j]; }
+}
+
+template <typename T>
+struct KmColorBwdArgs {
+    const T* x;             // (B,3,H,W) forward input
+    const T* gy;            // (B,3,H,W) gradient wrt the output
+    T* gx;                  // (B,3,H,W) gradient wrt the input
+    const float* params;    // (B,4)
+    const double* gray_sum; // (B) the forward's gray sums (contrast stage only)
+    double* gsum;           // (B) fp64 workspace, pre-zeroed: S of the contrast stage
+    double* gparams;        // (B,4) fp64 accumulators, pre-zeroed: gradient wrt the parameters (nullable)
+    const uint8_t* enable;
+    const uint8_t* apply;
+    int stages[KMC_MAX_STAGES];
+    int n_stages;
+    int HW;
+    uint32_t blocks_per_image, nblocks;
+};
+
+__device__ __forceinline__ float kmc_pass01(float u) { return ((u >= 0.0f) && (u <= 1.0f)) ? 1.0f : 0.0f; }
+
+// MODE 0: S of the contrast stage;  MODE 1: the gradients
+template <typename T, int MODE, int VEC>
+__global__ __launch_bounds__(256) void km_color_jitter_bwd_kernel(const KmColorBwdArgs<T> a) {
+    const uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const uint32_t b = bid / a.blocks_per_image, chunk = bid % a.blocks_per_image;
+    const int HW = a.HW;
+    const size_t img = (size_t)b * 3 * HW;
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f[k] = a.params[(size_t)b * 4 + k];
+    uint32_t enable_mask = 0xfu;
+    if (a.enable) enable_mask = (a.enable[0] ? 1u : 0u) | (a.enable[1] ? 2u : 0u) | (a.enable[2] ? 4u : 0u) | (a.enable[3] ? 8u : 0u);
+    if (a.apply && !a.apply[b]) {  // block-uniform: the forward copied this sample
+        if (MODE == 0) return;
+        enable_mask = 0u;
+    }
+    int st[KMC_MAX_STAGES];  // stage kinds in application order, -1 = none / disabled
+    bool has_contrast = false;
+#pragma unroll
+    for (int s = 0; s < KMC_MAX_STAGES; ++s) {
+        const int k = (s < a.n_stages) ? a.stages[s] : -1;
+        st[s] = (k >= 0 && ((enable_mask >> k) & 1u)) ? k : -1;
+        has_contrast = has_contrast || (st[s] == KMC_CONTRAST);
+    }
+    if (MODE == 0 && !has_contrast) return;
+    float mean = 0.0f, s_over_hw = 0.0f;
+    if (has_contrast) {
+        mean = (float)(a.gray_sum[b] / (double)HW);
+        if (MODE == 1) s_over_hw = (float)(a.gsum[b] / (double)HW);
+    }
+    const float wgt[3] = {0.299f, 0.587f, 0.114f};
+    float acc_s = 0.0f, gf[4] = {0.f, 0.f, 0.f, 0.f};
+    const int per_block = 256 * VEC * 4;
+    const int start = (int)chunk * per_block;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int p0 = start + (it * 256 + (int)threadIdx.x) * VEC;
+        if (p0 >= HW) break;
+        float xin[3][VEC], g[3][VEC];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (VEC == 4) {
+                km_ld4(a.x + img + (size_t)c * HW + p0, xin[c]);
+                km_ld4(a.gy + img + (size_t)c * HW + p0, g[c]);
+            } else {
+                xin[c][0] = (float)km_ld(a.x + img + (size_t)c * HW + p0);
+                g[c][0] = (float)km_ld(a.gy + img + (size_t)c * HW + p0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            // forward: the input of every stage
+            float in[KMC_MAX_STAGES][3];
+            float r = xin[0][q], gg = xin[1][q], bb = xin[2][q];
+#pragma unroll
+            for (int s = 0; s < KMC_MAX_STAGES; ++s) {
+                in[s][0] = r; in[s][1] = gg; in[s][2] = bb;
+                if (st[s] == KMC_BRIGHTNESS) {
+                    r = kmc_clamp01(r * f[0]); gg = kmc_clamp01(gg * f[0]); bb = kmc_clamp01(bb * f[0]);
+                } else if (st[s] == KMC_CONTRAST) {
+                    const float off = mean * (1.0f - f[1]);
+                    r = kmc_clamp01(r * f[1] + off); gg = kmc_clamp01(gg * f[1] + off); bb = kmc_clamp01(bb * f[1] + off);
+                } else if (st[s] == KMC_SATURATION) {
+                    const float gr = kmc_gray(r, gg, bb), aa = (1.0f - f[2]) * gr;
+                    r = kmc_clamp01(aa + f[2] * r); gg = kmc_clamp01(aa + f[2] * gg); bb = kmc_clamp01(aa + f[2] * bb);
+                } else if (st[s] == KMC_HUE) {
+                    kmc_hue(r, gg, bb, f[3]);
+                }
+            }
+            // backward
+            float gr3[3] = {g[0][q], g[1][q], g[2][q]};
+            bool done = false;
+#pragma unroll
+            for (int s = KMC_MAX_STAGES - 1; s >= 0; --s) {
+                if (done) continue;
+                const float x0 = in[s][0], x1 = in[s][1], x2 = in[s][2];
+                if (st[s] == KMC_BRIGHTNESS) {
+                    const float m0 = gr3[0] * kmc_pass01(x0 * f[0]), m1 = gr3[1] * kmc_pass01(x1 * f[0]), m2 = gr3[2] * kmc_pass01(x2 * f[0]);
+                    gf[0] += (m0 * x0 + m1 * x1) + m2 * x2;
+                    gr3[0] = m0 * f[0]; gr3[1] = m1 * f[0]; gr3[2] = m2 * f[0];
+                } else if (st[s] == KMC_CONTRAST) {
+                    const float off = mean * (1.0f - f[1]);
+                    const float m0 = gr3[0] * kmc_pass01(x0 * f[1] + off), m1 = gr3[1] * kmc_pass01(x1 * f[1] + off), m2 = gr3[2] * kmc_pass01(x2 * f[1] + off);
+                    if (MODE == 0) {
+                        acc_s += (m0 + m1) + m2;
+                        done = true;
+                    } else {
+                        gf[1] += (m0 * (x0 - mean) + m1 * (x1 - mean)) + m2 * (x2 - mean);
+                        const float spread = (1.0f - f[1]) * s_over_hw;
+                        gr3[0] = f[1] * m0 + wgt[0] * spread; gr3[1] = f[1] * m1 + wgt[1] * spread; gr3[2] = f[1] * m2 + wgt[2] * spread;
+                    }
+                } else if (st[s] == KMC_SATURATION) {
+                    const float gray = kmc_gray(x0, x1, x2), aa = (1.0f - f[2]) * gray;
+                    const float m0 = gr3[0] * kmc_pass01(aa + f[2] * x0), m1 = gr3[1] * kmc_pass01(aa + f[2] * x1), m2 = gr3[2] * kmc_pass01(aa + f[2] * x2);
+                    gf[2] += (m0 * (x0 - gray) + m1 * (x1 - gray)) + m2 * (x2 - gray);
+                    const float sm = (1.0f - f[2]) * ((m0 + m1) + m2);
+                    gr3[0] = wgt[0] * sm + f[2] * m0; gr3[1] = wgt[1] * sm + f[2] * m1; gr3[2] = wgt[2] * sm + f[2] * m2;
+                } else if (st[s] == KMC_HUE) {
+                    float J[3][4];
+                    kmc_hue_jacobian(x0, x1, x2, f[3], J);
+                    const float o0 = (gr3[0] * J[0][0] + gr3[1] * J[1][0]) + gr3[2] * J[2][0];
+                    const float o1 = (gr3[0] * J[0][1] + gr3[1] * J[1][1]) + gr3[2] * J[2][1];
+                    const float o2 = (gr3[0] * J[0][2] + gr3[1] * J[1][2]) + gr3[2] * J[2][2];
+                    gf[3] += (gr3[0] * J[0][3] + gr3[1] * J[1][3]) + gr3[2] * J[2][3];
+                    gr3[0] = o0; gr3[1] = o1; gr3[2] = o2;
+                }
+            }
+            g[0][q] = gr3[0]; g[1][q] = gr3[1]; g[2][q] = gr3[2];
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if constexpr (VEC == 4) km_st4(a.gx + img + (size_t)c * HW + p0, g[c]);
+                else km_st(a.gx + img + (size_t)c * HW + p0, g[c][0]);
+            }
+        }
+    }
+    __shared__ double red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (MODE == 0) {
+        const double sw = km_wave_sum((double)acc_s);
+        if (lane == 0) red[0][wave] = sw;
+        __syncthreads();
+        if (threadIdx.x == 0) km_atomic_add(a.gsum + b, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    } else if (a.gparams) {  // kernel-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double sw = km_wave_sum((double)gf[k]);
+            if (lane == 0) red[k][wave] = sw;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) km_atomic_add(a.gparams + (size_t)b * 4 + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+    }
+}
+
+template <typename T>
+static int kmc_bwd_run(const void* x, const void* gy, void* gx, const void* params, const double* gray_sum, double* gsum, double* gparams, const void* enable,
+                       const void* apply, const int* stages, int n_stages, int B, int H, int W, hipStream_t s) {
+    KmColorBwdArgs<T> a;
+    a.x = (const T*)x; a.gy = (const T*)gy; a.gx = (T*)gx; a.params = (const float*)params; a.gray_sum = gray_sum; a.gsum = gsum; a.gparams = gparams;
+    a.enable = (const uint8_t*)enable; a.apply = (const uint8_t*)apply;
+    bool has_contrast = false;
+    for (int k = 0; k < KMC_MAX_STAGES; ++k) {
+        a.stages[k] = k < n_stages ? stages[k] : -1;
+        if (k < n_stages && stages[k] == KMC_CONTRAST) has_contrast = true;
+    }
+    a.n_stages = n_stages;
+    a.HW = H * W;
+    const size_t esz = sizeof(T);
+    const bool vec = (a.HW % 4 == 0) && ((uintptr_t)x % (4 * esz) == 0) && ((uintptr_t)gy % (4 * esz) == 0) && ((uintptr_t)gx % (4 * esz) == 0);
+    const int per_block = 256 * (vec ? 4 : 1) * 4;
+    a.blocks_per_image = (uint32_t)((a.HW + per_block - 1) / per_block);
+    const uint64_t nb = (uint64_t)a.blocks_per_image * (uint64_t)B;
+    KM_REQUIRE(nb < (1ull << 31), "km_color_jitter_bwd: grid too large");
+    a.nblocks = (uint32_t)nb;
+    if (nb == 0) return 0;
+    if (has_contrast) {
+        KM_REQUIRE(gray_sum && gsum, "km_color_jitter_bwd: a contrast stage needs the forward's gray sums and the gsum workspace");
+        if (vec) hipLaunchKernelGGL((km_color_jitter_bwd_kernel<T, 0, 4>), dim3(a.nblocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((km_color_jitter_bwd_kernel<T, 0, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
+        const int rc = km_check_launch("km_color_jitter_bwd(contrast sum)");
+        if (rc) return rc;
+    }
+    if (vec) hipLaunchKernelGGL((km_color_jitter_bwd_kernel<T, 1, 4>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((km_color_jitter_bwd_kernel<T, 1, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
+    return km_check_launch("km_color_jitter_bwd");
+}
+
 extern "C" {
 
 // x, y: (B,3,H,W) RGB in `dtype` (f32 / bf16 / f16); params: (B,4) fp32 on the device - brightness factor, contrast
@@ -252,6 +507,31 @@ int km_color_jitter_fwd(const void* x, void* y, const void* params, double* gray
 int km_color_jitter_fwd_masked(const void* x, void* y, const void* params, double* gray_sum, const void* enable, const void* apply,
                                const int* stages, int n_stages, int B, int H, int W, int dtype, void* stream) {
     return kmc_entry(x, y, params, gray_sum, enable, apply, stages, n_stages, B, H, W, dtype, stream);
+}
+
+// Backward of km_color_jitter_fwd(_masked): gx = d loss / d x given gy = d loss / d y, same stage list / params / enable / apply as the
+// forward.  gray_sum: (B) fp64, the forward's workspace AFTER the forward ran (the per-image gray sums) - required iff a contrast
+// stage is present, as is gsum: (B) fp64 workspace zeroed by the caller.  gparams: (B,4) fp64 accumulators zeroed by the caller,
+// receives d loss / d params (hue in radians), or NULL.  Reference: autograd through kornia/enhance/adjust.py:80-593.
+int km_color_jitter_bwd(const void* x, const void* gy, void* gx, const void* params, const double* gray_sum, double* gsum, double* gparams,
+                        const void* enable, const void* apply, const int* stages, int n_stages, int B, int H, int W, int dtype, void* stream) {
+    if (B == 0 || H == 0 || W == 0) return 0;
+    KM_REQUIRE(x && gy && gx && params, "km_color_jitter_bwd: null pointer");
+    KM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "km_color_jitter_bwd: bad shape B=%d H=%d W=%d", B, H, W);
+    KM_REQUIRE(n_stages >= 0 && n_stages <= KMC_MAX_STAGES && (n_stages == 0 || stages), "km_color_jitter_bwd: bad stage list");
+    int n_contrast = 0;
+    for (int k = 0; k < n_stages; ++k) {
+        KM_REQUIRE(stages[k] >= 0 && stages[k] <= 3, "km_color_jitter_bwd: stage id %d out of range", stages[k]);
+        n_contrast += stages[k] == KMC_CONTRAST;
+    }
+    KM_REQUIRE(n_contrast <= 1, "km_color_jitter_bwd: at most one contrast stage");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case KM_F32: return kmc_bwd_run<float>(x, gy, gx, params, gray_sum, gsum, gparams, enable, apply, stages, n_stages, B, H, W, s);
+        case KM_BF16: return kmc_bwd_run<km_bf16>(x, gy, gx, params, gray_sum, gsum, gparams, enable, apply, stages, n_stages, B, H, W, s);
+        case KM_F16: return kmc_bwd_run<km_f16>(x, gy, gx, params, gray_sum, gsum, gparams, enable, apply, stages, n_stages, B, H, W, s);
+        default: km_set_error("km_color_jitter_bwd: dtype must be f32 / bf16 / f16"); return -1;
+    }
 }
 
 }  // extern "C"

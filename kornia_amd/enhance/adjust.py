@@ -8,7 +8,8 @@ Reference functions mirrored (names, argument meaning, output range):
 and ``color_jitter`` = the sequence ColorJitter.apply_transform runs
 (kornia/augmentation/_2d/intensity/color_jitter.py:126-159) in ONE pass over the image.
 
-Forward only (augmentation): tensors that require grad are refused rather than silently detached.
+Differentiable like the reference's op sequences: ``km_color_jitter_bwd`` gives the gradients wrt the image and wrt per-image
+factor tensors (contrast couples every pixel of an image through the mean: one extra reduction pass).
 RGB ``(B,3,H,W)`` / ``(3,H,W)`` inputs on a HIP device; there is no PyTorch/CPU fallback.
 """
 from __future__ import annotations
@@ -41,12 +42,53 @@ def _factor_column(f: Factor, B: int, device, neutral: float) -> torch.Tensor:
         return torch.full((B,), float(f), device=device, dtype=torch.float32)
     if not isinstance(f, torch.Tensor):
         raise TypeError(f"Factor should be float or torch.Tensor. Got {type(f)}")
-    f = f.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    f = f.to(device=device, dtype=torch.float32).reshape(-1)
     if f.numel() == 1:
         return f.expand(B)
     if f.numel() != B:
         raise ValueError(f"factor has {f.numel()} elements, expected 1 or the batch size {B}")
     return f
+
+
+class _ColorJitterFunction(torch.autograd.Function):
+    """``km_color_jitter_fwd(_masked)`` / ``km_color_jitter_bwd``: gradients wrt the image and the (B,4) parameter table."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor], stages: tuple):
+        B, _, H, W = x.shape
+        dev = x.device
+        x = x.contiguous()
+        params = params.contiguous()
+        out = torch.empty_like(x)
+        gray_sum = torch.zeros(B, device=dev, dtype=torch.float64) if CONTRAST in stages else None
+        arr = (ctypes.c_int * max(len(stages), 1))(*stages)
+        with N.device_guard(dev):
+            if apply is None:
+                N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
+                                                    N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
+            else:
+                N.check(N.lib().km_color_jitter_fwd_masked(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), apply.data_ptr(), arr,
+                                                           len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd_masked")
+        ctx.stages = stages
+        ctx.save_for_backward(x, params, gray_sum, enable, apply)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy: torch.Tensor):
+        x, params, gray_sum, enable, apply = ctx.saved_tensors
+        stages = ctx.stages
+        B, _, H, W = x.shape
+        dev = x.device
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        gsum = torch.zeros(B, device=dev, dtype=torch.float64) if CONTRAST in stages else None
+        gparams = torch.zeros(B, 4, device=dev, dtype=torch.float64) if ctx.needs_input_grad[1] else None
+        arr = (ctypes.c_int * max(len(stages), 1))(*stages)
+        with N.device_guard(dev):
+            N.check(N.lib().km_color_jitter_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(gsum), N.ptr(gparams),
+                                                N.ptr(enable), N.ptr(apply), arr, len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_bwd")
+        return (gx if ctx.needs_input_grad[0] else None), (gparams.to(params.dtype) if gparams is not None else None), None, None, None
 
 
 def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], enable: Optional[torch.Tensor] = None,
@@ -58,31 +100,19 @@ def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], 
         raise ValueError(f"Input size must have a shape of (*, 3, H, W). Got {image.shape}")
     if image.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         raise TypeError(f"color adjustments run in float32 / bfloat16 / float16 on the native path. Got {image.dtype}")
-    if image.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError("kornia_amd.enhance: the fused colour kernels are forward-only (augmentation); detach the input")
     stages = [int(s) for s in stages]
     if len(stages) > 4 or any(s not in (0, 1, 2, 3) for s in stages) or stages.count(CONTRAST) > 1:
         raise ValueError(f"`order` entries must be in 0..3 (brightness, contrast, saturation, hue), contrast at most once. Got {stages}")
     shape = image.shape
-    x = image.detach().reshape(-1, 3, shape[-2], shape[-1]).contiguous()
-    B, _, H, W = x.shape
+    x = image.reshape(-1, 3, shape[-2], shape[-1])
+    B = x.shape[0]
     dev = x.device
-    params = torch.stack([_factor_column(f, B, dev, n) for f, n in zip(factors, _NEUTRAL)], dim=1).contiguous()
-    out = torch.empty_like(x)
-    gray_sum = torch.zeros(B, device=dev, dtype=torch.float64) if CONTRAST in stages else None
-    arr = (ctypes.c_int * max(len(stages), 1))(*stages)
+    params = torch.stack([_factor_column(f, B, dev, n) for f, n in zip(factors, _NEUTRAL)], dim=1)
     if enable is not None:
         enable = N.flags(enable, dev, 4)
     if apply is not None:  # the augmentation layer's per-sample switch: samples whose entry is 0 are copied by the same launch
         apply = N.flags(apply, dev, B)
-    with N.device_guard(dev):
-        if apply is None:
-            N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
-                                                N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
-        else:
-            N.check(N.lib().km_color_jitter_fwd_masked(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), apply.data_ptr(), arr,
-                                                       len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd_masked")
-    return out.reshape(shape)
+    return _ColorJitterFunction.apply(x, params, enable, apply, tuple(stages)).reshape(shape)
 
 
 def adjust_brightness_accumulative(image: torch.Tensor, factor: Union[float, torch.Tensor], clip_output: bool = True) -> torch.Tensor:

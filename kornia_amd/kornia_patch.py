@@ -39,7 +39,7 @@ _NATIVE = {
     "kornia.filters.filter": {"filter2d": _f.filter2d, "filter2d_separable": _f.filter2d_separable},
     "kornia.filters.gaussian": {"gaussian_blur2d": _f.gaussian_blur2d},
     "kornia.filters.sobel": {"spatial_gradient": _f.spatial_gradient, "sobel": _f.sobel},
-    # forward-only fused colour kernels (the ColorJitter leg)
+    # fused colour kernels (the ColorJitter leg)
     "kornia.enhance.adjust": {
         "adjust_brightness_accumulative": _e.adjust_brightness_accumulative,
         "adjust_contrast_with_mean_subtraction": _e.adjust_contrast_with_mean_subtraction,
@@ -47,7 +47,7 @@ _NATIVE = {
         "adjust_hue": _e.adjust_hue,
     },
 }
-_FORWARD_ONLY = {id(f) for f in _NATIVE["kornia.enhance.adjust"].values()}
+_COLOR_OPS = {id(f) for f in _NATIVE["kornia.enhance.adjust"].values()}
 _COLOR_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 _SUPPORTED = (torch.float32, torch.float64, torch.bfloat16, torch.float16)
 _patched: dict = {}  # id(original) -> (original, dispatcher)
@@ -64,18 +64,17 @@ def _use_native(args, kwargs) -> bool:
 
 
 def _use_native_color(args, kwargs) -> bool:
-    """The fused colour kernels: RGB float32/bfloat16/float16 images that do not need gradients, default options."""
+    """The fused colour kernels: RGB float32/bfloat16/float16 images, default options (differentiable: km_color_jitter_bwd)."""
     if not _use_native(args, kwargs) or kwargs.get("clip_output", True) is not True:
         return False
     image = args[0] if args else kwargs.get("image")
     if not isinstance(image, torch.Tensor) or image.dim() < 3 or image.shape[-3] != 3 or image.dtype not in _COLOR_DTYPES:
         return False
-    tensors = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor)]
-    return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+    return True
 
 
 def _dispatcher(original: Callable, native: Callable) -> Callable:
-    accept = _use_native_color if id(native) in _FORWARD_ONLY else _use_native
+    accept = _use_native_color if id(native) in _COLOR_OPS else _use_native
 
     @functools.wraps(original)
     def wrapper(*args, **kwargs):
@@ -99,7 +98,7 @@ def _color_jitter_apply(original: Callable) -> Callable:
         keys = ("brightness_factor", "contrast_factor", "saturation_factor", "hue_factor")
         ok = (
             isinstance(input, torch.Tensor) and _N.on_device(input) and input.dim() == 4 and input.shape[1] == 3
-            and input.dtype in _COLOR_DTYPES and not (torch.is_grad_enabled() and input.requires_grad)
+            and input.dtype in _COLOR_DTYPES
             and all(isinstance(params.get(k), torch.Tensor) for k in keys)
             and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
         )
