@@ -89,6 +89,23 @@ int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype);
 int km_affine_matrix2d_fwd(const void* translations, const void* center, const void* scale, const void* angle, const void* sx,
                            const void* sy, void* out, int B, int dtype, void* stream);
 
+/* RandomAffine.compute_transformation + the normalise / invert chain of warp_affine in one launch (float32):
+ * kornia/augmentation/_2d/geometric/affine.py:125-141 (-> imgwarp.py:746-787), then imgwarp.py:271-284.
+ * translations / center / scale (B,2), angle (B) degrees, shear_x / shear_y (B) DEGREES or NULL ->
+ * M_out (B,9) pixel src->dst matrix (nullable), m_out (B,9) the normalised dst->src matrix km_warp2d_fwd reads with
+ * coord_mode = affine for a (Hs,Ws) source and (hd,wd) destination.  batch_prob (B) fp32 or NULL -> apply (B) uint8 =
+ * batch_prob > 0.5 (kornia/augmentation/base.py:380), the per-sample switch km_warp2d_fwd_masked takes. */
+int km_affine_params_chain_fwd(const void* translations, const void* center, const void* scale, const void* angle, const void* shear_x,
+                               const void* shear_y, const void* batch_prob, void* M_out, void* m_out, void* apply, int B, int Hs, int Ws, int hd,
+                               int wd, void* stream);
+
+/* ColorJitter's sampled factors -> the inputs of km_color_jitter_fwd(_masked) in one launch
+ * (kornia/augmentation/_2d/intensity/color_jitter.py:137-148, base.py:380): brightness / contrast / saturation / hue (B) fp32
+ * (hue in turns), batch_prob (B) fp32 or NULL -> params (B,4) fp32 (hue in radians), enable (4) uint8 = the module's
+ * `(factor != neutral).any()` guards, apply (B) uint8 = batch_prob > 0.5 (iff batch_prob is given). */
+int km_color_params_fwd(const void* brightness, const void* contrast, const void* saturation, const void* hue, const void* batch_prob, void* params,
+                        void* enable, void* apply, int B, void* stream);
+
 /* Replaces get_perspective_transform (kornia/geometry/transform/imgwarp.py:397-525, Heckbert closed form) as called by
  * RandomPerspective.compute_transformation (kornia/augmentation/_2d/geometric/perspective.py): one launch instead of ~40.
  *   points_src, points_dst (B,4,2) -> out (B,3,3) with out[2][2] == 1; dtype KM_F32 or KM_F64. */

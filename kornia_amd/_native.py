@@ -54,6 +54,8 @@ _PROTOTYPES = {
     "km_gaussian_taps_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "km_warp2d_fwd_masked": [_P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],
     "km_color_jitter_fwd_masked": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "km_affine_params_chain_fwd": [_P] * 10 + [_I] * 5 + [_P],
+    "km_color_params_fwd": [_P] * 8 + [_I, _P],
     "km_color_jitter_bwd": [_P] * 10 + [_I] * 5 + [_P],
     "km_select_samples_fwd": [_P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P],
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],

@@ -6,8 +6,8 @@ _2d/intensity/color_jitter.py:126-159, _2d/intensity/gaussian_blur.py:95-114) sp
 blend of ``_AugmentationBase.transform_inputs``, augmentation/base.py:348-393).  This module is the second half, taking the
 parameter dictionaries the reference's generators produce (or a replay of them, ``AugmentationSequential(x, params=...)``):
 
-* :func:`random_affine` - parameters (B,...) -> pixel matrix (``km_affine_matrix2d_fwd``, one launch) -> normalise / invert
-  (``km_homography_chain_fwd``) -> sample;
+* :func:`random_affine` - parameters (B,...) -> pixel matrix -> normalise / invert in ONE launch (``km_affine_params_chain_fwd``:
+  the prologue of the warp) -> sample; under autograd the same through ``km_affine_matrix2d_fwd`` + ``warp_affine``;
 * :func:`color_jitter` - the four adjustments in the sampled order, one fused kernel (+ one reduction pass for the contrast mean);
 * :func:`random_gaussian_blur` - per-sample sigma -> taps (``km_gaussian_taps_fwd``, one launch) -> fused separable blur;
 * the per-sample apply probability (``batch_prob``, base.py:348-393) rides INSIDE the three launches - the warp copies the samples
@@ -29,13 +29,13 @@ from typing import Any, Mapping, Optional, Sequence
 import torch
 
 from . import _native as N
-from .enhance.adjust import color_jitter as _color_jitter
+from .enhance.adjust import color_jitter as _color_jitter, color_jitter_from_table
 from .filters.filter import filter2d_separable
 from .filters.gaussian import gaussian_blur2d
 from .geometry.transform.builders import get_affine_matrix2d
-from .geometry.transform.imgwarp import COORD_AFFINE, _warp, warp_affine
+from .geometry.transform.imgwarp import _warp_affine_from_chain, warp_affine
 
-__all__ = ["affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "select_samples"]
+__all__ = ["affine_chain", "affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "select_samples"]
 
 
 def _p(params: Mapping[str, Any], key: str, device) -> torch.Tensor:
@@ -47,6 +47,16 @@ def _apply_mask(params: Mapping[str, Any], device) -> Optional[torch.Tensor]:
     if "batch_prob" not in params or params["batch_prob"] is None:
         return None
     return torch.atleast_1d(torch.as_tensor(params["batch_prob"]).to(device) > 0.5)
+
+
+def _prob(params: Mapping[str, Any], device, B: int) -> Optional[torch.Tensor]:
+    """``batch_prob`` as a contiguous (B,) float32 device tensor for the parameter kernels (which threshold it), or None."""
+    if "batch_prob" not in params or params["batch_prob"] is None:
+        return None
+    p = torch.as_tensor(params["batch_prob"]).to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    if p.numel() != B:
+        raise ValueError(f"batch_prob has {p.numel()} entries, expected the batch size {B}")
+    return p
 
 
 def select_samples(transformed: torch.Tensor, original: torch.Tensor, apply: Optional[torch.Tensor]) -> torch.Tensor:
@@ -90,18 +100,40 @@ def affine_matrix(params: Mapping[str, Any], device) -> torch.Tensor:
                                _p(params, "angle", device), _p(params, "shear_x", device) * d2r, _p(params, "shear_y", device) * d2r)
 
 
+def affine_chain(params: Mapping[str, Any], device, height: int, width: int, with_matrix: bool = False):
+    """The sampled parameters -> ``(m, M, apply)`` in ONE launch (``km_affine_params_chain_fwd`` = compute_transformation +
+    warp_affine's normalise / invert chain + the ``batch_prob > 0.5`` switch): m (B,9) float32, the normalised dst->src matrix the
+    warp kernel reads for a same-size warp of a (height, width) image; M (B,3,3) the pixel matrix (the module's
+    ``transform_matrix``) when ``with_matrix``, else None; apply (B) uint8 when the parameters carry a probability draw, else None."""
+    device = torch.device(device)
+    t, c, sc, ang, sx, sy = (_p(params, k, device).contiguous() for k in ("translations", "center", "scale", "angle", "shear_x", "shear_y"))
+    B = ang.numel()
+    if t.shape != (B, 2) or c.shape != (B, 2) or sc.shape != (B, 2) or sx.numel() != B or sy.numel() != B:
+        raise ValueError("translations / center / scale must be (B,2) and angle / shear_x / shear_y (B,)")
+    prob = _prob(params, device, B)
+    m = torch.empty(B, 9, device=device, dtype=torch.float32)
+    M = torch.empty(B, 3, 3, device=device, dtype=torch.float32) if with_matrix else None
+    apply = torch.empty(B, device=device, dtype=torch.uint8) if prob is not None else None
+    with N.device_guard(device):
+        N.check(N.lib().km_affine_params_chain_fwd(t.data_ptr(), c.data_ptr(), sc.data_ptr(), ang.data_ptr(), sx.data_ptr(), sy.data_ptr(), N.ptr(prob),
+                                                   N.ptr(M), m.data_ptr(), N.ptr(apply), B, int(height), int(width), int(height), int(width),
+                                                   N.stream_ptr(device)), "km_affine_params_chain_fwd")
+    return m, M, apply
+
+
 def random_affine(input: torch.Tensor, params: Mapping[str, Any], resample: str = "bilinear", align_corners: bool = False,
                   padding_mode: str = "zeros", fill_value: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RandomAffine.apply_transform + the batch_prob blend (affine.py:143-162, base.py:380-393)."""
     N.require_device(input, "input")
-    M = affine_matrix(params, input.device)
-    mask = _apply_mask(params, input.device)
-    size = (input.shape[-2], input.shape[-1])
-    if mask is not None and not (torch.is_grad_enabled() and input.requires_grad):
-        # the switch rides in the warp's own launch: samples that are not transformed are copied by the workgroups that would have warped them
+    if input.dim() == 4 and input.dtype in (torch.float32, torch.bfloat16, torch.float16) and not (torch.is_grad_enabled() and input.requires_grad):
+        # parameters -> normalised inverse matrix (+ the per-sample switch) in one launch, the switch applied inside the warp's own launch
         if padding_mode == "fill" and fill_value is None:
             fill_value = torch.zeros(input.shape[1], device=input.device, dtype=input.dtype)
-        return _warp(input, M[:, :2, :], size, COORD_AFFINE, 1, resample, padding_mode, align_corners, fill_value, apply=mask)
+        m, _, apply = affine_chain(params, input.device, input.shape[-2], input.shape[-1])
+        return _warp_affine_from_chain(input, m, resample, padding_mode, align_corners, fill_value, apply)
+    mask = _apply_mask(params, input.device)
+    M = affine_matrix(params, input.device)
+    size = (input.shape[-2], input.shape[-1])
     out = warp_affine(input, M[:, :2, :], size, resample, padding_mode, align_corners, fill_value)
     return select_samples(out, input, mask)
 
@@ -114,8 +146,22 @@ def color_jitter(input: torch.Tensor, params: Mapping[str, Any], order: Optional
     bf, cf, sf, hf = (_p(params, k, dev) for k in ("brightness_factor", "contrast_factor", "saturation_factor", "hue_factor"))
     if order is None:
         order = torch.as_tensor(params["order"]).tolist()  # sampled on the host by the reference's generator
+    order = [int(i) for i in order]
+    B = input.shape[0] if input.dim() == 4 else -1
+    if (input.dim() == 4 and input.shape[1] == 3 and all(f.dim() == 1 and f.numel() == B for f in (bf, cf, sf, hf))
+            and not (torch.is_grad_enabled() and any(f.requires_grad for f in (bf, cf, sf, hf)))):
+        # factor table, stage switches and the per-sample switch in one launch (km_color_params_fwd), then the fused kernel
+        prob = _prob(params, dev, B)
+        table = torch.empty(B, 4, device=dev, dtype=torch.float32)
+        enable = torch.empty(4, device=dev, dtype=torch.uint8)
+        apply = torch.empty(B, device=dev, dtype=torch.uint8) if prob is not None else None
+        bf, cf, sf, hf = (f.contiguous() for f in (bf, cf, sf, hf))
+        with N.device_guard(dev):
+            N.check(N.lib().km_color_params_fwd(bf.data_ptr(), cf.data_ptr(), sf.data_ptr(), hf.data_ptr(), N.ptr(prob), table.data_ptr(), enable.data_ptr(),
+                                                N.ptr(apply), B, N.stream_ptr(dev)), "km_color_params_fwd")
+        return color_jitter_from_table(input, table, enable, apply, order)
     enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
-    return _color_jitter(input, bf, cf, sf, hf, [int(i) for i in order], enable=enable, apply=_apply_mask(params, dev))
+    return _color_jitter(input, bf, cf, sf, hf, order, enable=enable, apply=_apply_mask(params, dev))
 
 
 def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_size=(5, 5), border_type: str = "reflect",

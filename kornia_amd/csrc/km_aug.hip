@@ -78,6 +78,23 @@ static int km_select_run(const void* transformed, const void* original, const vo
     return km_check_launch("km_select_samples_fwd");
 }
 
+// ColorJitter's sampled factors -> what km_color_jitter_fwd reads, in one launch (one block): the (B,4) parameter table with the
+// hue factor turned from turns into radians (x float(2 pi), color_jitter.py:147), the four stage switches of the module's
+// `(factor != neutral).any()` guards (color_jitter.py:137-148: brightness != 0, contrast != 1, saturation != 1, hue != 0) and,
+// when the parameters carry a probability draw, the per-sample switch `batch_prob > 0.5` (augmentation/base.py:380).
+__global__ __launch_bounds__(256) void km_color_params_kernel(const float* bf, const float* cf, const float* sf, const float* hf, const float* prob,
+                                                              float* params, uint8_t* enable, uint8_t* apply, int B) {
+    int any_b = 0, any_c = 0, any_s = 0, any_h = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float vb = bf[b], vc = cf[b], vs = sf[b], vh = hf[b];
+        params[4 * b + 0] = vb; params[4 * b + 1] = vc; params[4 * b + 2] = vs; params[4 * b + 3] = vh * 6.283185307179586f;
+        any_b |= (vb != 0.0f); any_c |= (vc != 1.0f); any_s |= (vs != 1.0f); any_h |= (vh != 0.0f);
+        if (apply) apply[b] = (prob[b] > 0.5f) ? 1 : 0;
+    }
+    any_b = __syncthreads_or(any_b); any_c = __syncthreads_or(any_c); any_s = __syncthreads_or(any_s); any_h = __syncthreads_or(any_h);
+    if (threadIdx.x == 0) { enable[0] = any_b ? 1 : 0; enable[1] = any_c ? 1 : 0; enable[2] = any_s ? 1 : 0; enable[3] = any_h ? 1 : 0; }
+}
+
 extern "C" {
 
 // sigma (B,2) fp32 on the device, (sigma_y, sigma_x) per sample like gaussian_blur2d's argument; taps_x (B,kx), taps_y (B,ky) fp32;
@@ -108,6 +125,17 @@ int km_select_samples_fwd(const void* transformed, const void* original, const v
         case KM_F16: return km_select_run<km_f16>(transformed, original, apply, out, B, (size_t)n_per_sample, s);
         default: km_set_error("km_select_samples_fwd: dtype must be f32 / bf16 / f16"); return -1;
     }
+}
+
+// brightness / contrast / saturation / hue factors (B) fp32 on the device as ColorJitter's generator samples them (hue in turns),
+// batch_prob (B) fp32 or NULL -> params (B,4) fp32 (hue in radians), enable (4) uint8, apply (B) uint8 (iff batch_prob is given).
+int km_color_params_fwd(const void* brightness, const void* contrast, const void* saturation, const void* hue, const void* batch_prob, void* params,
+                        void* enable, void* apply, int B, void* stream) {
+    KM_REQUIRE(B >= 0 && enable && (B == 0 || (brightness && contrast && saturation && hue && params)), "km_color_params_fwd: null pointer");
+    KM_REQUIRE((batch_prob == nullptr) == (apply == nullptr) || B == 0, "km_color_params_fwd: batch_prob and apply go together");
+    hipLaunchKernelGGL(km_color_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)brightness, (const float*)contrast,
+                       (const float*)saturation, (const float*)hue, (const float*)batch_prob, (float*)params, (uint8_t*)enable, (uint8_t*)apply, B);
+    return km_check_launch("km_color_params_fwd");
 }
 
 }  // extern "C"

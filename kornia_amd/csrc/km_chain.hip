@@ -194,10 +194,10 @@ __device__ __forceinline__ double km_cos(double x) { return cos(x); }
 __device__ __forceinline__ float km_tan(float x) { return tanf(x); }
 __device__ __forceinline__ double km_tan(double x) { return tan(x); }
 
-template <typename R>
-__global__ __launch_bounds__(64) void km_affine_matrix2d_kernel(const KmAffineArgs<R> a) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.B) return;
+// the matrix of sample b; SHEAR_DEG: sx / sy are in degrees and converted as RandomAffine.compute_transformation does
+// (x * float(pi / 180), kornia/augmentation/_2d/geometric/affine.py:131-133), else radians
+template <typename R, bool SHEAR_DEG>
+__device__ __forceinline__ void km_affine_matrix_of(const KmAffineArgs<R>& a, int b, R (&m)[9]) {
     const R cx = a.center[2 * b], cy = a.center[2 * b + 1];
     // deg2rad(-angle): tensor * pi.type(dtype) / 180 with pi a float32 constant (conversions.py:148, constants.py:25)
     const R pi32 = (R)3.14159265358979323846f;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void km_affine_matrix2d_kernel(const KmAffineAr
     const R shift_inv[9] = {1, 0, -cx, 0, 1, -cy, 0, 0, 1};
     const R rot[9] = {c, s, 0, -s, c, 0, 0, 0, 1};
     const R scl[9] = {a.scale[2 * b], 0, 0, 0, a.scale[2 * b + 1], 0, 0, 0, 1};
-    R t0[9], t1[9], m[9];
+    R t0[9], t1[9];
     km_mm3(shift, rot, t0);
     km_mm3(t0, scl, t1);
     km_mm3(t1, shift_inv, m);
@@ -215,15 +215,49 @@ __global__ __launch_bounds__(64) void km_affine_matrix2d_kernel(const KmAffineAr
     m[5] = m[5] + a.trans[2 * b + 1];
     m[6] = 0; m[7] = 0; m[8] = 1;  // convert_affinematrix_to_homography of the (2,3) block
     if (a.sx || a.sy) {
-        const R tx = a.sx ? km_tan(a.sx[b]) : km_tan((R)0), ty = a.sy ? km_tan(a.sy[b]) : km_tan((R)0);
+        const R d2r = (R)(3.14159265358979323846 / 180.0);
+        const R ax = a.sx ? (SHEAR_DEG ? a.sx[b] * d2r : a.sx[b]) : (R)0, ay = a.sy ? (SHEAR_DEG ? a.sy[b] * d2r : a.sy[b]) : (R)0;
+        const R tx = km_tan(ax), ty = km_tan(ay);
         const R sh[9] = {1, -tx, tx * cy, -ty, (R)1 + tx * ty, ty * (cx - tx * cy), 0, 0, 1};
         R o[9];
         km_mm3(m, sh, o);
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = o[k];
     }
+}
+
+template <typename R>
+__global__ __launch_bounds__(64) void km_affine_matrix2d_kernel(const KmAffineArgs<R> a) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    R m[9];
+    km_affine_matrix_of<R, false>(a, b, m);
 #pragma unroll
     for (int k = 0; k < 9; ++k) a.out[(size_t)b * 9 + k] = m[k];
+}
+
+// RandomAffine's sampled parameters -> what the warp kernel reads, in ONE launch: the pixel matrix as above (shears in degrees),
+// then normalise and invert exactly as km_chain_fwd_kernel does for warp_affine (imgwarp.py:271-284):  m = inv(Nd M inv(Ns)).
+__global__ __launch_bounds__(64) void km_affine_params_chain_kernel(const KmAffineArgs<float> a, const KmChainArgs<float> ch, float* M_out,
+                                                                    const float* prob, uint8_t* apply) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    if (apply) apply[b] = (prob[b] > 0.5f) ? 1 : 0;  // the per-sample switch of the augmentation layer (base.py:380)
+    float M[9];
+    km_affine_matrix_of<float, true>(a, b, M);
+    if (M_out) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M_out[(size_t)b * 9 + k] = M[k];
+    }
+    const float Ns[9] = {ch.sx_s, 0, -1, 0, ch.sy_s, -1, 0, 0, 1};
+    const float Nd[9] = {ch.sx_d, 0, -1, 0, ch.sy_d, -1, 0, 0, 1};
+    float Nsi[9], t[9], A[9], mi[9];
+    km_inv3(Ns, Nsi);
+    km_mm3(M, Nsi, t);
+    km_mm3(Nd, t, A);
+    km_inv3(A, mi);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ch.m[(size_t)b * 9 + k] = mi[k];
 }
 
 template <typename R>
@@ -308,6 +342,29 @@ int km_affine_matrix2d_fwd(const void* translations, const void* center, const v
     KM_REQUIRE(dtype == KM_F32 || dtype == KM_F64, "km_affine_matrix2d_fwd: dtype must be f32/f64");
     if (dtype == KM_F32) return km_affine_run<float>(translations, center, scale, angle, sx, sy, out, B, (hipStream_t)stream);
     return km_affine_run<double>(translations, center, scale, angle, sx, sy, out, B, (hipStream_t)stream);
+}
+
+// RandomAffine.compute_transformation + the normalise / invert chain of warp_affine in one launch (float32):
+// translations / center / scale (B,2), angle (B) degrees, shear_x / shear_y (B) DEGREES or null ->
+// M_out (B,9) pixel src->dst matrix (nullable) and m_out (B,9), the normalised dst->src matrix km_warp2d_fwd reads
+// (coord_mode = affine) for a (Hs,Ws) source and a (hd,wd) destination; batch_prob (B) fp32 or null -> apply (B) uint8 = batch_prob > 0.5.
+// Reference: kornia/augmentation/_2d/geometric/affine.py:125-141 -> imgwarp.py:746-787, then imgwarp.py:271-284; base.py:380.
+int km_affine_params_chain_fwd(const void* translations, const void* center, const void* scale, const void* angle, const void* shear_x,
+                               const void* shear_y, const void* batch_prob, void* M_out, void* m_out, void* apply, int B, int Hs, int Ws, int hd, int wd,
+                               void* stream) {
+    if (B == 0) return 0;
+    KM_REQUIRE(translations && center && scale && angle && m_out, "km_affine_params_chain_fwd: null pointer");
+    KM_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && hd > 0 && wd > 0, "km_affine_params_chain_fwd: bad sizes");
+    KM_REQUIRE((batch_prob == nullptr) == (apply == nullptr), "km_affine_params_chain_fwd: batch_prob and apply go together");
+    KmAffineArgs<float> a;
+    a.trans = (const float*)translations; a.center = (const float*)center; a.scale = (const float*)scale; a.angle = (const float*)angle;
+    a.sx = (const float*)shear_x; a.sy = (const float*)shear_y; a.out = nullptr; a.B = B;
+    KmChainArgs<float> ch;
+    ch.M = nullptr; ch.A = nullptr; ch.m = (float*)m_out; ch.gm = nullptr; ch.gM = nullptr; ch.B = B; ch.rows = 3;
+    ch.sx_s = km_norm_scale(Ws); ch.sy_s = km_norm_scale(Hs); ch.sx_d = km_norm_scale(wd); ch.sy_d = km_norm_scale(hd);
+    hipLaunchKernelGGL(km_affine_params_chain_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, ch, (float*)M_out, (const float*)batch_prob,
+                       (uint8_t*)apply);
+    return km_check_launch("km_affine_params_chain_fwd");
 }
 
 // points_src / points_dst (B,4,2) -> out (B,3,3), H[2][2] == 1; dtype f32 / f64.

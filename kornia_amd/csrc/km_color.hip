@@ -101,29 +101,48 @@ __device__ __forceinline__ void kmc_apply(float& r, float& g, float& b, const in
 }
 
 
-// MODE 0: reduction pass (gray mean in front of the contrast stage);  MODE 1: apply pass.  VEC = 4 needs HW % 4 == 0
-// and 4-element aligned planes; VEC = 1 otherwise.
+template <typename T>
+__device__ __forceinline__ float kmc_storage_round(float v) {  // v as it reads back from the storage dtype
+    T t;
+    km_st(&t, v);
+    return (float)km_ld(&t);
+}
+
+// MODE 0: the pass in front of a contrast stage - applies the stages that precede it, accumulates the per-image gray sum and, when
+// there are such stages, stores the intermediate image in y (storage dtype);  MODE 1: the apply pass - without a contrast stage
+// the whole chain from x; with one, the contrast stage and what follows it, from the intermediate in y (in place: a thread reads
+// and writes the same pixels), so that every stage is evaluated once (the hue round trip through HSV is ~200 VALU instructions
+// per pixel: evaluating it in both passes made the 224 x 224 bf16 pass ALU-bound at 0.45 TB/s).
+// VEC = 4 needs HW % 4 == 0 and 4-element aligned planes; VEC = 1 otherwise.
 template <typename T, int MODE, int VEC>
 __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<T> a) {
     const uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
     const uint32_t b = bid / a.blocks_per_image, chunk = bid % a.blocks_per_image;
     const int HW = a.HW;
     const T* xr = a.x + (size_t)b * 3 * HW;
+    T* yr = a.y + (size_t)b * 3 * HW;
     float f[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) f[k] = a.params[(size_t)b * 4 + k];
     int ci = a.n_stages;  // index of the contrast stage
     for (int s = 0; s < a.n_stages; ++s)
         if (a.stages[s] == KMC_CONTRAST) { ci = s; break; }
+    const bool has_contrast = ci < a.n_stages;
     float mean = 0.0f;
-    if (MODE == 1 && ci < a.n_stages) mean = (float)(a.gray_sum[b] / (double)HW);
-    const int last = (MODE == 0) ? ci : a.n_stages;
+    if (MODE == 1 && has_contrast) mean = (float)(a.gray_sum[b] / (double)HW);
     uint32_t enable_mask = 0xfu;
     if (a.enable) enable_mask = (a.enable[0] ? 1u : 0u) | (a.enable[1] ? 2u : 0u) | (a.enable[2] ? 4u : 0u) | (a.enable[3] ? 8u : 0u);
-    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not jittered - every stage off, the apply pass is a copy
+    bool skipped = false;
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not jittered - every stage off, the apply pass is a copy of x
         if (MODE == 0) return;
         enable_mask = 0u;
+        skipped = true;
     }
+    // MODE 0 applies [0, ci) ; MODE 1 applies [ci, n) of the intermediate when MODE 0 stored one, else [0, n) of x
+    const bool staged = has_contrast && ci > 0 && !skipped;
+    const int first = (MODE == 1 && staged) ? ci : 0;
+    const int last = (MODE == 0) ? ci : a.n_stages;
+    const T* in = (MODE == 1 && staged) ? (const T*)yr : xr;
 
     float acc = 0.0f;
     const int per_block = 256 * VEC * 4;  // 4 iterations per thread
@@ -135,38 +154,28 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
         const int p0 = start + (it * 256 + (int)threadIdx.x) * VEC;
         if (p0 >= HW) break;
         float r[VEC], g[VEC], bl[VEC];
-        if (VEC == 4) {
-            float t4[4];
-            km_ld4(xr + p0, t4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = t4[q];
-            km_ld4(xr + HW + p0, t4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = t4[q];
-            km_ld4(xr + 2 * (size_t)HW + p0, t4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bl[q] = t4[q];
+        if constexpr (VEC == 4) {
+            km_ld4(in + p0, r);
+            km_ld4(in + HW + p0, g);
+            km_ld4(in + 2 * (size_t)HW + p0, bl);
         } else {
-            r[0] = (float)km_ld(xr + p0); g[0] = (float)km_ld(xr + HW + p0); bl[0] = (float)km_ld(xr + 2 * (size_t)HW + p0);
+            r[0] = (float)km_ld(in + p0); g[0] = (float)km_ld(in + HW + p0); bl[0] = (float)km_ld(in + 2 * (size_t)HW + p0);
         }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            kmc_apply(r[q], g[q], bl[q], a.stages, 0, last, f, mean, enable_mask);
-            if (MODE == 0) acc += kmc_gray(r[q], g[q], bl[q]);
+            kmc_apply(r[q], g[q], bl[q], a.stages, first, last, f, mean, enable_mask);
+            if (MODE == 0) {
+                if (ci > 0) {  // the gray sum is taken of the values the apply pass will read back: the stored ones
+                    r[q] = kmc_storage_round<T>(r[q]); g[q] = kmc_storage_round<T>(g[q]); bl[q] = kmc_storage_round<T>(bl[q]);
+                }
+                acc += kmc_gray(r[q], g[q], bl[q]);
+            }
         }
-        if (MODE == 1) {
-            T* yr = a.y + (size_t)b * 3 * HW;
-            if (VEC == 4) {
-                float t4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t4[q] = r[q];
-                km_st4(yr + p0, t4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t4[q] = g[q];
-                km_st4(yr + HW + p0, t4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t4[q] = bl[q];
-                km_st4(yr + 2 * (size_t)HW + p0, t4);
+        if (MODE == 1 || ci > 0) {
+            if constexpr (VEC == 4) {
+                km_st4(yr + p0, r);
+                km_st4(yr + HW + p0, g);
+                km_st4(yr + 2 * (size_t)HW + p0, bl);
             } else {
                 km_st(yr + p0, r[0]); km_st(yr + HW + p0, g[0]); km_st(yr + 2 * (size_t)HW + p0, bl[0]);
             }

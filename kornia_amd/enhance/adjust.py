@@ -28,6 +28,7 @@ __all__ = [
     "adjust_hue",
     "adjust_saturation_with_gray_subtraction",
     "color_jitter",
+    "color_jitter_from_table",
 ]
 
 BRIGHTNESS, CONTRAST, SATURATION, HUE = 0, 1, 2, 3
@@ -113,6 +114,21 @@ def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], 
     if apply is not None:  # the augmentation layer's per-sample switch: samples whose entry is 0 are copied by the same launch
         apply = N.flags(apply, dev, B)
     return _ColorJitterFunction.apply(x, params, enable, apply, tuple(stages)).reshape(shape)
+
+
+def color_jitter_from_table(image: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor],
+                            stages: Sequence[int]) -> torch.Tensor:
+    """The fused kernel on an already assembled parameter table (``km_color_params_fwd``): params (B,4) float32 - brightness,
+    contrast, saturation factors and the hue shift in RADIANS; enable (4) / apply (B) uint8 device tensors or None."""
+    N.require_device(image, "image")
+    if image.dim() != 4 or image.shape[1] != 3 or image.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError(f"expected a (B,3,H,W) float32 / bfloat16 / float16 image. Got {tuple(image.shape)} {image.dtype}")
+    stages = tuple(int(s) for s in stages)
+    if len(stages) > 4 or any(s not in (0, 1, 2, 3) for s in stages) or stages.count(CONTRAST) > 1:
+        raise ValueError(f"`order` entries must be in 0..3 (brightness, contrast, saturation, hue), contrast at most once. Got {list(stages)}")
+    if params.dtype != torch.float32 or tuple(params.shape) != (image.shape[0], 4):
+        raise ValueError("params must be (B,4) float32")
+    return _ColorJitterFunction.apply(image, params, enable, apply, stages)
 
 
 def adjust_brightness_accumulative(image: torch.Tensor, factor: Union[float, torch.Tensor], clip_output: bool = True) -> torch.Tensor:

@@ -244,6 +244,30 @@ def _warp(src, mat, dsize, coord_mode, norm_coords, mode, padding_mode, align_co
     return _Warp2dFunction.apply(src, mat, fill, cfg, apply)
 
 
+def _warp_affine_from_chain(src: torch.Tensor, m: torch.Tensor, mode: str, padding_mode: str, align_corners: bool, fill_value, apply) -> torch.Tensor:
+    """Forward-only ``warp_affine`` to the source's own size from an already normalised and inverted (B,9) float32 matrix
+    (``km_affine_params_chain_fwd``): the augmentation layer's apply step, no autograd node, one launch."""
+    N.require_device(src, "src")
+    interp, pad = _mode_codes(mode, padding_mode)
+    B, C, H, W = src.shape
+    dev = src.device
+    if src.dtype not in (torch.float32, torch.bfloat16, torch.float16) or m.dtype != torch.float32 or tuple(m.shape) != (B, 9):
+        raise TypeError("the chained warp takes float32 / bfloat16 / float16 images and a (B,9) float32 matrix")
+    fill = _prepare_fill(fill_value, C, dev, torch.float32) if pad == _PAD["fill"] else None
+    x = src.detach().contiguous()
+    out = torch.empty_like(x)
+    if apply is not None:
+        apply = N.flags(apply, dev, B)
+    with N.device_guard(dev):
+        if apply is None:
+            N.check(N.lib().km_warp2d_fwd(x.data_ptr(), m.data_ptr(), out.data_ptr(), B, C, H, W, H, W, B, COORD_AFFINE, 1, interp, pad,
+                                          int(bool(align_corners)), N.ptr(fill), N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_warp2d_fwd")
+        else:
+            N.check(N.lib().km_warp2d_fwd_masked(x.data_ptr(), m.data_ptr(), out.data_ptr(), apply.data_ptr(), B, C, H, W, H, W, B, COORD_AFFINE, 1, interp,
+                                                 pad, int(bool(align_corners)), N.ptr(fill), N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_warp2d_fwd_masked")
+    return out
+
+
 def warp_perspective(
     src: torch.Tensor,
     M: torch.Tensor,

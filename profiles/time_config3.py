@@ -37,6 +37,11 @@ t("affine_matrix (params->M)", lambda: A.affine_matrix(dPa, dev))
 t("warp_affine bf16 256x3x224^2", lambda: K.warp_affine(x, M[:, :2], (224, 224), align_corners=False))
 t("random_affine (matrix+warp+mask)", lambda: A.random_affine(x, dPa))
 t("color_jitter", lambda: A.color_jitter(w, dPj))
+def cj_fwd_bwd():
+    with torch.enable_grad():
+        wr = w.detach().requires_grad_()
+        A.color_jitter(wr, dPj).backward(c)
+t("color_jitter fwd + bwd (image gradient)", cj_fwd_bwd)
 t("gaussian_blur2d tensor sigma (B,2)", lambda: K.gaussian_blur2d(c, (5, 5), sig))
 t("gaussian_blur2d tuple sigma", lambda: K.gaussian_blur2d(c, (5, 5), (1.5, 1.5)))
 t("random_gaussian_blur", lambda: A.random_gaussian_blur(c, dPb))

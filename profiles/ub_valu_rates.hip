@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void k_rate(float* out, float seed, unsigned l
     const float2 pb = make_float2(b, b), pc = make_float2(c, c);
     const int laddr = (int)(threadIdx.x * 4 + 4 * (int)seed) * 4;  // byte address, 16-B multiples of lane
     const int laddr_u = (int)(threadIdx.x * 3 + (int)seed) * 4;    // 12-byte stride: only 4-byte aligned
+    const int laddr4 = (int)((threadIdx.x & 63) + 4 * (int)seed) * 4;   // 4-byte lane stride (waves of a block share the words)
+    const int laddr8 = (int)((threadIdx.x & 63) + 4 * (int)seed) * 8;   // 8-byte lane stride
     unsigned long long t0 = 0, t1 = 0, w0 = 0, w1 = 0;
     if (threadIdx.x == 0 && blockIdx.x == 0) { t0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
     for (int it = 0; it < ITER; ++it) {
@@ -114,6 +116,21 @@ __global__ __launch_bounds__(256) void k_rate(float* out, float seed, unsigned l
             REP16(S)
 #undef S
             asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == 24) {  // ds_add_u32, lane stride 4 bytes: conflict-free (OP 18's 16-byte lane stride is a 4-way bank conflict)
+#define S(k) asm volatile("ds_add_u32 %0, %1 offset:" #k "*256" : : "v"(laddr4), "v"(ia[k]));
+            REP16(S)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == 25) {  // ds_read_b32, lane stride 4 bytes: conflict-free
+#define S(k) asm volatile("ds_read_b32 %0, %1 offset:" #k "*256" : "=v"(a[k]) : "v"(laddr4));
+            REP16(S)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == 26) {  // ds_add_u64, lane stride 8 bytes
+#define S(k) asm volatile("ds_add_u64 %0, %1 offset:" #k "*512" : : "v"(laddr8), "v"(p[k]));
+            REP16(S)
+#undef S
+            asm volatile("s_waitcnt lgkmcnt(0)");
         } else if (OP == 19) {  // v_cvt_rpi_i32_f32
 #define S(k) asm volatile("v_cvt_rpi_i32_f32 %0, %1" : "=v"(ia[k]) : "v"(a[k]));
             REP16(S)
@@ -193,11 +210,14 @@ int main(int argc, char** argv) {
         run<12>("v_div_fixup_f32", W, out, clk);
         run<13>("v_med3_f32", W, out, clk);
         run<23>("v_fma_f32 dependent", W, out, clk);
-        run<14>("ds_read_b32", W, out, clk);
+        run<14>("ds_read_b32 (16B lane stride)", W, out, clk);
         run<15>("ds_read2_b32 (12B stride)", W, out, clk);
         run<16>("ds_read_b64 unaligned", W, out, clk);
         run<17>("ds_read_b64 aligned", W, out, clk);
-        run<18>("ds_add_u32", W, out, clk);
+        run<18>("ds_add_u32 (16B lane stride)", W, out, clk);
+        run<24>("ds_add_u32 conflict-free", W, out, clk);
+        run<25>("ds_read_b32 conflict-free", W, out, clk);
+        run<26>("ds_add_u64 (8B lane stride)", W, out, clk);
     }
     return 0;
 }

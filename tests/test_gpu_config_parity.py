@@ -255,3 +255,34 @@ def test_per_sample_switch_inside_the_launches():
         _warp(x.float().requires_grad_(), M, (H, W), COORD_AFFINE, 1, "bilinear", "zeros", True, None, apply=mask.cuda())
     with pytest.raises(ValueError):
         _warp(x, M, (H + 1, W), COORD_AFFINE, 1, "bilinear", "zeros", True, None, apply=mask.cuda())
+
+
+def test_affine_parameters_to_chain_in_one_launch():
+    """km_affine_params_chain_fwd = RandomAffine.compute_transformation (affine.py:125-141) + warp_affine's normalise / invert chain
+    (imgwarp.py:271-284): bit-identical to the two-step native path (km_affine_matrix2d_fwd with the shears converted by torch, then
+    km_homography_chain_fwd inside warp_affine), for the matrices and for the warped image, with and without the per-sample switch."""
+    import kornia_amd as K
+    import kornia_amd.augmentation as A
+
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 9, 48, 64
+    P = {"translations": (torch.rand(B, 2, generator=g) - 0.5) * 12, "center": torch.tensor([[(W - 1) / 2, (H - 1) / 2]]).repeat(B, 1),
+         "scale": 0.7 + 0.6 * torch.rand(B, 2, generator=g), "angle": (torch.rand(B, generator=g) - 0.5) * 90,
+         "shear_x": (torch.rand(B, generator=g) - 0.5) * 30, "shear_y": (torch.rand(B, generator=g) - 0.5) * 30}
+    dP = {k: v.cuda() for k, v in P.items()}
+    m, M, no_switch = A.affine_chain(dP, torch.device("cuda"), H, W, with_matrix=True)
+    assert no_switch is None
+    M2 = A.affine_matrix(dP, torch.device("cuda"))
+    assert torch.equal(M, M2)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.rand(B, 3, H, W, generator=g).to(dt).cuda()
+        for mode, pad, align in (("bilinear", "zeros", False), ("nearest", "border", True), ("bicubic", "reflection", False), ("bilinear", "fill", True)):
+            fill = torch.tensor([0.1, 0.5, 0.9]).cuda() if pad == "fill" else None
+            ref = K.warp_affine(x, M2[:, :2], (H, W), mode, pad, align, fill)
+            assert torch.equal(A.random_affine(x, dP, mode, align, pad, fill), ref), (dt, mode, pad)
+            mask = torch.rand(B, generator=g) > 0.4
+            got = A.random_affine(x, dict(dP, batch_prob=mask.float().cuda()), mode, align, pad, fill)
+            assert torch.equal(got, torch.where(mask.view(-1, 1, 1, 1).cuda(), ref, x)), (dt, mode, pad, "masked")
+    xg = torch.rand(B, 3, H, W, generator=g).cuda().requires_grad_()  # under autograd: the differentiable two-step path
+    A.random_affine(xg, dP).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
