@@ -130,7 +130,12 @@ def kernel_roofline(x, M, go, size, iters):
 
     # per LAUNCH: the bytes that launch itself must move (every tensor it reads once + every tensor it writes once); the two
     # backward launches both read grad_out, so their sum (4e) exceeds the op's algorithmic 3e - which is why the op line exists
+    # Single-kernel loops run with the batch traversal FIXED (km_set_traversal(1)): with the product's alternating direction,
+    # launch k+1 of a loop over ONE input would start on the ~256 MB that launch k just left in the Infinity Cache - a hit rate
+    # no kernel of the real step sees on its own input.  The op loop of km_warp2d_bwd keeps the product's policy (its second
+    # launch reads grad_out where the first one ended, as in the step); the fixed-direction figure is reported beside it.
     kernels = {}
+    prev_mode = lib.km_set_traversal(1)
     for name, fn, nbytes, what in (
         ("km_warp_fwd_lean_kernel", warp_fwd, 2 * e * n_el, "read src, write out"),
         ("km_blur_reg_kernel<fwd>", blur_fwd, 2 * e * n_el, "read x, write y"),
@@ -141,6 +146,8 @@ def kernel_roofline(x, M, go, size, iters):
         ms = event_time_ms(fn, iters)
         kernels[name] = {"ms": round(ms, 4), "launch_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "moves": what}
     # per PUBLIC OP: SURVEY 8(d)'s algorithmic bytes (compulsory traffic at the API boundary)
+    bwd_fixed_ms = event_time_ms(warp_bwd, iters)
+    lib.km_set_traversal(prev_mode)
     ops = {}
     for name, fn, mult in (("km_warp2d_fwd", warp_fwd, 2), ("km_filter2d_sep_fwd", blur_fwd, 2), ("km_filter2d_sep_bwd_input", blur_bwd, 2),
                            ("km_warp2d_bwd", warp_bwd, 3)):
@@ -149,6 +156,7 @@ def kernel_roofline(x, M, go, size, iters):
                 kernels["km_blur_reg_kernel<bwd>"]["ms"] if name == "km_filter2d_sep_bwd_input" else event_time_ms(fn, iters)))
         nbytes = mult * e * n_el
         ops[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    ops["km_warp2d_bwd"]["ms_fixed_traversal"] = round(bwd_fixed_ms, 4)
     return kernels, ops
 
 

@@ -38,6 +38,11 @@ int km_abi_version(void);
 const char* km_last_error(void);
 /* gcnArchName of the current device into name[n]; returns the CU count or < 0 */
 int km_device_info(char* name, int n);
+/* Batch traversal of the streaming kernels (warp forward / backward, separable blur): mode 0 (default) alternates the direction
+ * from one launch to the next, so that a consumer starts on what its producer left in the 256 MB Infinity Cache; mode 1 keeps
+ * every launch forward (what a per-kernel timing loop over one input needs: otherwise launch k+1 re-reads the tail launch k just
+ * read).  Results do not depend on it.  Returns the previous mode.  (No reference counterpart: the reference has no launch policy.) */
+int km_set_traversal(int mode);
 
 /* ---- batched 3x3 homography chain -----------------------------------------------------------
  * Replaces normalize_homography (kornia/geometry/conversions.py:1691-1726),

@@ -100,12 +100,14 @@ def lib() -> ctypes.CDLL:
         fn.restype = c_int
     handle.km_device_info.argtypes = [c_char_p, c_int]
     handle.km_device_info.restype = c_int
+    handle.km_set_traversal.argtypes = [c_int]
+    handle.km_set_traversal.restype = c_int
     _lib = handle
     return handle
 
 
 def exported_symbols() -> list[str]:
-    return ["km_abi_version", "km_last_error", "km_device_info", *_PROTOTYPES.keys()]
+    return ["km_abi_version", "km_last_error", "km_device_info", "km_set_traversal", *_PROTOTYPES.keys()]
 
 
 def check(rc: int, what: str) -> None:

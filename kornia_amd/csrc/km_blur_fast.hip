@@ -56,6 +56,7 @@ struct KmBlurArgs {
     uint32_t groups_x;   // W / 4
     uint32_t bx, by;     // blocks per plane in x / y
     uint32_t nblocks;
+    uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
 };
 
 // Adjoint taps along one axis for output position p:  w[d] multiplies the (zero-extended) gradient at
@@ -84,7 +85,7 @@ __device__ __forceinline__ void kmb_adjoint_taps(const float (&k)[K], int p, int
 template <typename T, int K, bool BWD>
 __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a) {
     constexpr int L = (K - 1) / 2, R = K - 1 - L;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tbx = bid % a.bx;
     bid /= a.bx;
     const uint32_t tby = bid % a.by;
@@ -242,6 +243,7 @@ static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, 
     KM_REQUIRE(nb < (1ull << 31), "km_blur: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
+    a.reverse = km_traversal_next();
     switch (K) {
         case 3: return km_blur_launch<T, 3>(bwd, a, s);
         case 5: return km_blur_launch<T, 5>(bwd, a, s);

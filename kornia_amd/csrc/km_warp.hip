@@ -19,6 +19,9 @@
 #include "km_warp_args.h"
 #include "km_warp_stage.h"
 
+#ifndef KML_EXP
+#define KML_EXP 0   // timing experiments only (wrong results): 1 = no fallback loads for lanes without a right neighbour, 2 = one source row
+#endif
 #ifndef KM_ROWS
 #define KM_ROWS 4   // output rows per thread
 #endif
@@ -379,11 +382,19 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
                 v[r][c][0] = (float)km_ld(km_at(sp[c], off));
+#if KML_EXP == 2
+                v[r][c][2] = v[r][c][0];
+#else
                 v[r][c][2] = (float)km_ld(km_at(sp[c], off + (uint32_t)W));
+#endif
+#if KML_EXP >= 1
+                v[r][c][1] = v[r][c][0]; v[r][c][3] = v[r][c][2];
+#else
                 if (!nb[r]) {
                     v[r][c][1] = (float)km_ld(km_at(sp[c], off + 1u));
                     v[r][c][3] = (float)km_ld(km_at(sp[c], off + (uint32_t)W + 1u));
                 }
+#endif
             }
         }
 #pragma unroll
@@ -445,11 +456,14 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
 #define KML_GROUPS 2   // measured on one box, 256x3x512^2: 1 -> 0.49 ms, 2 -> 0.41, 4 -> 0.42 (round-1 kernel there: 0.44)
 #endif
 #define KML_TILE_H (KM_TILE_H * KML_GROUPS)
+#ifndef KML_BOUNDS
+#define KML_BOUNDS __launch_bounds__(256)
+#endif
 template <typename T, int CM, int NC, int ALIGN>  // NC = 3 / 1: RGB / grey unrolled ; NC = 0: runtime channel loop
-__global__ __launch_bounds__(256) void km_warp_fwd_lean_kernel(const KmWarpArgs<T> a) {
+__global__ KML_BOUNDS void km_warp_fwd_lean_kernel(const KmWarpArgs<T> a) {
     static_assert(KML_TILE_H <= 64, "the row table is filled by one wave");
     const KmWarpGeom<float>& g = a.g;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
@@ -790,6 +804,7 @@ static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
     KmWarpArgs<T> a = a0;
     a.tiles_y = (uint32_t)((a.g.h + KML_TILE_H - 1) / KML_TILE_H);
     a.nblocks = a.tiles_x * a.tiles_y * (uint32_t)a.g.B;  // (<= the 64 x 16 grid the caller checked)
+    a.reverse = km_traversal_next();
     if (a.g.align)
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
@@ -878,6 +893,7 @@ static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, co
     const uint64_t nb = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
     KM_REQUIRE(nb < (1ull << 31), "km_warp2d: grid too large (%llu blocks)", (unsigned long long)nb);
     a.nblocks = (uint32_t)nb;
+    a.reverse = 0;
     if (nb == 0) return 0;
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return km_warp_dispatch_interp<T, KM_COORD_PERSPECTIVE>(bwd, a, s);
@@ -967,6 +983,8 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
         if (km_warp_bwd_tiled_dims_ok(h, w)) {
             // both gradients in one pass over grad_out when the tile-owner kernel can gather the source taps itself
             const bool fuse = gmat && gm_fast && km_warp_bwd_tiled_fuses_gm(H, W);
+            // scatter first, matrix gradient second: with the alternating batch traversal (km_traversal_next) the second launch starts on the
+            // part of grad_out the first one read last.  (The other order measured 1.868 against 1.845 ms per step - no better than a fixed direction.)
             const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, src, fuse ? gmat : nullptr, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad,
                                                  align, dtype, s);
             if (rc != 0 || !gmat || fuse) return rc;

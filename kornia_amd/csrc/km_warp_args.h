@@ -18,6 +18,7 @@ struct KmWarpArgs {
     const uint8_t* apply;  // fwd, nullable: (B) per-sample switch of the augmentation layer - a sample whose entry is 0 is copied (h == H, w == W)
     KmWarpGeom<R> g;
     uint32_t tiles_x, tiles_y, nblocks;
+    uint32_t reverse;  // lean forward only: the XCDs walk their block ranges backwards (km_traversal_next)
 };
 
 // The per-sample probability blend of the augmentation layer (kornia/augmentation/base.py:348-393) folded into the forward: a

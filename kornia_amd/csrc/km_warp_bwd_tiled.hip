@@ -41,6 +41,9 @@
 #ifndef KMT_UNROLL
 #define KMT_UNROLL 2       // pixels in flight per thread in the scatter loop
 #endif
+#ifndef KMT_UNROLL_GM
+#define KMT_UNROLL_GM 2    // the same in the fused form (both gradients): grad_out and the source taps of each pixel in flight
+#endif
 #define KMT_CC 3            // channels per pass
 #define KMT_BAND_W 128      // output columns per band = capacity of the column table (float4 entries)
 #define KMT_TAB 128         // output rows per band = capacity of the row table (float4 entries)
@@ -57,6 +60,7 @@ struct KmWarpTiledArgs {
     const float* fill;   // (C), pad == fill only (the matrix gradient sees (v - fill))
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, nblocks;
+    uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
 };
 
 // [host-testable begin: tile_box]  (tests/test_tile_box_spec.py compiles this span for the host with g++)
@@ -256,25 +260,33 @@ __device__ __forceinline__ void kmt_load_go(const T* const (&gout_c)[CC], uint32
     for (int c = 0; c < CC; ++c) go[c] = (float)km_ld(km_at(gout_c[c], off));
 }
 
-// One output pixel of the scatter pass: position (the forward's own instruction sequence, km_lean.h), footprint, and the
-// four contributions w * grad_out[q, c] to the taps that fall inside the tile.  FIXED: int32 fixed-point LDS accumulators;
-// otherwise IEEE float LDS atomics (slow; non-finite gradients, vanishing-line tiles, extreme magnification).
-// matrix-gradient side of a pixel (GM): the pixel is counted by the ONE tile that owns its north-west tap (clamped into the image),
-// with the source taps gathered from global memory - grad_out is then read once for both gradients (3e bytes per element for the
-// backward instead of 4e with a separate matrix-gradient launch).
-template <typename T, int CC>
-struct KmtGm {
-    const T* src_c[CC];   // channel planes of the source image
-    float fill[CC];       // pad == fill: subtracted from every in-bounds tap
-    int W, H;
-    float mx, my;         // d (pixel) / d (normalised)
-    bool enabled;         // false while a tile is being redone with the exact scale (its matrix-gradient sums are already complete)
+// A visited output pixel: position (the forward's own instruction sequence, km_lean.h), footprint, tile-relative north-west tap.
+struct KmtPix {
+    KmlPos p;
+    KmlTaps t;
+    float x, y;       // sampling position in source pixels
+    uint32_t ux, uy;  // (floor(x), floor(y)) relative to the tile, unsigned
 };
 
-template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED, bool GM>
-__device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, float ub, float vb, bool valid, const float (&go)[CC],
-                                          int* s_acc, float scale, float Wm1, float hW, float Hm1, float hH, uint32_t X0, uint32_t TWc, uint32_t Y0,
-                                          uint32_t THc, uint32_t& seen_bits, const KmtGm<T, CC>& gm, float (&gacc)[9]) {
+template <int CM, int ALIGN, bool FAST>
+__device__ __forceinline__ void kmt_pix_position(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, bool valid, float Wm1, float hW, float Hm1, float hH,
+                                                 uint32_t X0, uint32_t Y0, KmtPix& q) {
+    kml_position<CM, FAST>(m, cu, rv, q.p);
+    q.x = kml_unnormalize<ALIGN>(q.p.gx, Wm1, hW);
+    q.y = kml_unnormalize<ALIGN>(q.p.gy, Hm1, hH);
+    // weights: the forward's own expressions ((x0 + 1) - x, x - x0), so grad_src = W^T grad_out for the very W it applied
+    kml_taps(q.x, q.y, q.t);
+    // Tile-relative tap position in unsigned arithmetic.  A tap inside the tile is inside the image, so the in-tile test is
+    // the whole predicate: positions far outside saturate in the conversion and wrap to values >= 2^30, a NaN position
+    // converts to 0 - its weights are NaN, which the quantisation turns into 0 (FIXED) or which is excluded below (float path).
+    q.ux = (uint32_t)KM_F2I(q.t.xf) - X0;
+    q.uy = valid ? (uint32_t)KM_F2I(q.t.yf) - Y0 : 0x40000000u;
+}
+
+// The four contributions w * grad_out[q, c] of a visited pixel to the taps that fall inside the tile.  FIXED: int32 fixed-point LDS
+// accumulators; otherwise IEEE float LDS atomics (slow; non-finite gradients, vanishing-line tiles, extreme magnification).
+template <int CC, bool FIXED>
+__device__ __forceinline__ void kmt_pix_scatter(const KmtPix& q, const float (&go)[CC], int* s_acc, float scale, uint32_t TWc, uint32_t THc, uint32_t& seen_bits) {
     // the fixed-point scale was chosen for |grad_out| <= bound: remember the largest magnitude seen, as an integer
     // (sign cleared, IEEE bit patterns order like unsigned integers and NaN / inf sort above every finite value)
     if (FIXED) {
@@ -283,18 +295,8 @@ __device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu
         for (int c = 1; c < CC; ++c) mb = max(mb, __float_as_uint(go[c]) & 0x7fffffffu);
         seen_bits = max(seen_bits, mb);
     }
-    KmlPos p;
-    kml_position<CM, FAST>(m, cu, rv, p);
-    const float x = kml_unnormalize<ALIGN>(p.gx, Wm1, hW);
-    const float y = kml_unnormalize<ALIGN>(p.gy, Hm1, hH);
-    // weights: the forward's own expressions ((x0 + 1) - x, x - x0), so grad_src = W^T grad_out for the very W it applied
-    KmlTaps t;
-    kml_taps(x, y, t);
-    // Tile-relative tap position in unsigned arithmetic.  A tap inside the tile is inside the image, so the in-tile test is
-    // the whole predicate: positions far outside saturate in the conversion and wrap to values >= 2^30, a NaN position
-    // converts to 0 - its weights are NaN, which the quantisation turns into 0 (FIXED) or which is excluded below (float path).
-    const uint32_t ux = (uint32_t)KM_F2I(t.xf) - X0;
-    const uint32_t uy = valid ? (uint32_t)KM_F2I(t.yf) - Y0 : 0x40000000u;
+    const KmlTaps& t = q.t;
+    const uint32_t ux = q.ux, uy = q.uy;
     const bool in_x0 = ux < TWc, in_x1 = (ux + 1u) < TWc;
     const bool in_y0 = uy < THc, in_y1 = (uy + 1u) < THc;
     bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;  // (lane masks: s_and_b64)
@@ -321,7 +323,7 @@ __device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu
             for (int c = 0; c < CC; ++c) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, kmt_quant(w11 * go[c]));
         }
     } else {
-        const bool num = (x == x) & (y == y);  // a NaN position touches nothing (ATen: the converted index is out of bounds)
+        const bool num = (q.x == q.x) & (q.y == q.y);  // a NaN position touches nothing (ATen: the converted index is out of bounds)
         t00 = t00 && num; t01 = t01 && num; t10 = t10 && num; t11 = t11 && num;
         const float w00 = t.wx1 * t.wy1, w01 = t.wx0 * t.wy1, w10 = t.wx1 * t.wy0, w11 = t.wx0 * t.wy0;
         float* accp = (float*)s_acc + l00;
@@ -333,61 +335,91 @@ __device__ __forceinline__ void kmt_pixel(const float (&m)[9], const KmlHalf& cu
             if (t11) atomicAdd(accp + c * KMT_PLANE + KMT_TW + 1, w11 * go[c]);
         }
     }
-    if (GM) {
-        // owner = the tile holding (max(x0, 0), max(y0, 0)); a pixel with no tap inside the image contributes nothing anywhere
-        const bool ox = in_x0 || ((X0 == 0u) && (ux == 0xffffffffu));
-        const bool oy = in_y0 || ((Y0 == 0u) && (uy == 0xffffffffu));
-        const bool own = ox && oy && (x == x) && (y == y) && gm.enabled;
-        if (__any(own)) {
-            float gix = 0.f, giy = 0.f;
-            const bool interior = kml_inside(t, (float)(gm.W - 2), (float)(gm.H - 2));
-            if (__all(!own || interior)) {
-                const uint32_t off = own ? (uint32_t)__mul24(KM_F2I(t.yf), gm.W) + (uint32_t)KM_F2I(t.xf) : 0u;
-                float sv[CC][4];
+}
+
+// ---- matrix-gradient side of a visited pixel (fused form: grad_out is read once for both gradients, 3e bytes per element for the
+// backward instead of 4e with a separate matrix-gradient launch).  A pixel is counted by the ONE tile that owns its north-west tap
+// (clamped into the image).  Its source taps are gathered from global memory as two (xa, xa + 1) pairs on rows ya0 / ya1, clamped so
+// that every address is valid whatever the position; the loads are ISSUED TOGETHER WITH the pixel's grad_out loads - the addresses
+// depend on the position only - so an iteration of the tile-owner loop waits for memory once.  (The first fused form gathered the
+// taps after the scatter of each pixel: two dependent memory latencies per iteration and one pixel in flight, 1.32 ms; this form
+// 0.92 ms; the two launches 0.77 ms at 256x3x512^2 - km_warp_bwd_tiled_fuses_gm.)
+template <typename T, int CC>
+struct KmtGm {
+    const T* src_c[CC];   // channel planes of the source image
+    float fill[CC];       // pad == fill: subtracted from every in-bounds tap
+    int W, H;
+    float mx, my;         // d (pixel) / d (normalised)
+    bool enabled;         // false while a tile is being redone with the exact scale (its matrix-gradient sums are already complete)
+};
+
+template <typename T, int CC>
+__device__ __forceinline__ void kmt_pix_load_src(const KmtGm<T, CC>& gm, const KmtPix& q, float (&sv)[CC][4]) {
+    const int x0 = KM_F2I(q.t.xf), y0 = KM_F2I(q.t.yf);  // saturating; NaN -> 0
+    const int xa = min(max(x0, 0), gm.W - 2);             // pair base column: x0 unless x0 = -1 (-> 0) or x0 = W - 1 (-> W - 2)
+    const int yc = min(max(y0, -1), gm.H - 1);
+    const int ya0 = max(yc, 0), ya1 = min(yc + 1, gm.H - 1);
+    const uint32_t o0 = (uint32_t)__mul24(ya0, gm.W) + (uint32_t)xa, o1 = (uint32_t)__mul24(ya1, gm.W) + (uint32_t)xa;
 #pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    km_ld2(km_at(gm.src_c[c], off), sv[c][0], sv[c][1]);
-                    km_ld2(km_at(gm.src_c[c], off + (uint32_t)gm.W), sv[c][2], sv[c][3]);
-                }
+    for (int c = 0; c < CC; ++c) {
+        km_ld2(km_at(gm.src_c[c], o0), sv[c][0], sv[c][1]);
+        km_ld2(km_at(gm.src_c[c], o1), sv[c][2], sv[c][3]);
+    }
+}
+
+template <typename T, int CM, int CC, bool FAST>
+__device__ __forceinline__ void kmt_pix_gm(const KmtGm<T, CC>& gm, const KmtPix& q, float ub, float vb, const float (&go)[CC], const float (&sv)[CC][4], uint32_t X0,
+                                           uint32_t TWc, uint32_t Y0, uint32_t THc, float (&gacc)[9]) {
+    // owner = the tile holding (max(x0, 0), max(y0, 0)); a pixel with no tap inside the image contributes nothing anywhere
+    const bool ox = (q.ux < TWc) || ((X0 == 0u) && (q.ux == 0xffffffffu));
+    const bool oy = (q.uy < THc) || ((Y0 == 0u) && (q.uy == 0xffffffffu));
+    const bool own = ox && oy && (q.x == q.x) && (q.y == q.y) && gm.enabled;
+    if (!__any(own)) return;
+    const KmlTaps& t = q.t;
+    float gix = 0.f, giy = 0.f;
+    const bool interior = kml_inside(t, (float)(gm.W - 2), (float)(gm.H - 2));
+    if (__all(!own || interior)) {
 #pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    const float f = gm.fill[c];  // 0 unless pad == fill (same rounding sequence as the oracle: (v - fill) first)
-                    const float s00 = sv[c][0] - f, s01 = sv[c][1] - f, s10 = sv[c][2] - f, s11 = sv[c][3] - f;
-                    gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-                    giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
-                }
-            } else {
-                KmBilin<float> tb;
-                km_bilinear_setup(x, y, gm.W, gm.H, tb);  // clamped indices (always valid addresses) + per-tap bounds
+        for (int c = 0; c < CC; ++c) {
+            const float f = gm.fill[c];  // 0 unless pad == fill (same rounding sequence as the oracle: (v - fill) first)
+            const float s00 = sv[c][0] - f, s01 = sv[c][1] - f, s10 = sv[c][2] - f, s11 = sv[c][3] - f;
+            gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
+            giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
+        }
+    } else {
+        // per-tap bounds as km_bilinear_setup decides them (in floating point: NaN / huge positions are out of bounds); a column
+        // that is inside while its neighbour is not sits at the other end of the clamped pair
+        const float xf = t.xf, yf = t.yf;
+        const bool bx0 = (xf >= 0.0f) && (xf <= (float)(gm.W - 1)), bx1 = (xf >= -1.0f) && (xf <= (float)(gm.W - 2));
+        const bool by0 = (yf >= 0.0f) && (yf <= (float)(gm.H - 1)), by1 = (yf >= -1.0f) && (yf <= (float)(gm.H - 2));
 #pragma unroll
-                for (int c = 0; c < CC; ++c) {
-                    const float f = gm.fill[c];
-                    const float v00 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i00)), v01 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i01));
-                    const float v10 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i10)), v11 = (float)km_ld(km_at(gm.src_c[c], (uint32_t)tb.i11));
-                    const float s00 = tb.b00 ? v00 - f : 0.0f, s01 = tb.b01 ? v01 - f : 0.0f;
-                    const float s10 = tb.b10 ? v10 - f : 0.0f, s11 = tb.b11 ? v11 - f : 0.0f;
-                    gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-                    giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
-                }
-            }
-            const float gx_ = own ? gix * gm.mx : 0.0f, gy_ = own ? giy * gm.my : 0.0f;
-            float ax, ay, az;
-            if (CM == KM_COORD_PERSPECTIVE) {
-                const float inv = FAST ? p.rinv : __frcp_rn(p.den);
-                ax = gx_ * inv; ay = gy_ * inv;
-                az = -km_fma(gx_, p.gx, gy_ * p.gy) * inv;
-            } else if (CM == KM_COORD_AFFINE) {
-                ax = gx_; ay = gy_; az = 0.f;
-            } else {
-                const float sc = p.den;
-                ax = gx_ * sc; ay = gy_ * sc;
-                az = p.live ? -km_fma(gx_, p.X, gy_ * p.Y) * sc * sc : 0.0f;
-            }
-            gacc[0] = km_fma(ax, ub, gacc[0]); gacc[1] = km_fma(ax, vb, gacc[1]); gacc[2] += ax;
-            gacc[3] = km_fma(ay, ub, gacc[3]); gacc[4] = km_fma(ay, vb, gacc[4]); gacc[5] += ay;
-            gacc[6] = km_fma(az, ub, gacc[6]); gacc[7] = km_fma(az, vb, gacc[7]); gacc[8] += az;
+        for (int c = 0; c < CC; ++c) {
+            const float f = gm.fill[c];
+            const float v00 = bx1 ? sv[c][0] : sv[c][1], v01 = bx0 ? sv[c][1] : sv[c][0];
+            const float v10 = bx1 ? sv[c][2] : sv[c][3], v11 = bx0 ? sv[c][3] : sv[c][2];
+            const float s00 = (bx0 && by0) ? v00 - f : 0.0f, s01 = (bx1 && by0) ? v01 - f : 0.0f;
+            const float s10 = (bx0 && by1) ? v10 - f : 0.0f, s11 = (bx1 && by1) ? v11 - f : 0.0f;
+            gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
+            giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
         }
     }
+    const KmlPos& p = q.p;
+    const float gx_ = own ? gix * gm.mx : 0.0f, gy_ = own ? giy * gm.my : 0.0f;
+    float ax, ay, az;
+    if (CM == KM_COORD_PERSPECTIVE) {
+        const float inv = FAST ? p.rinv : __frcp_rn(p.den);
+        ax = gx_ * inv; ay = gy_ * inv;
+        az = -km_fma(gx_, p.gx, gy_ * p.gy) * inv;
+    } else if (CM == KM_COORD_AFFINE) {
+        ax = gx_; ay = gy_; az = 0.f;
+    } else {
+        const float sc = p.den;
+        ax = gx_ * sc; ay = gy_ * sc;
+        az = p.live ? -km_fma(gx_, p.X, gy_ * p.Y) * sc * sc : 0.0f;
+    }
+    gacc[0] = km_fma(ax, ub, gacc[0]); gacc[1] = km_fma(ax, vb, gacc[1]); gacc[2] += ax;
+    gacc[3] = km_fma(ay, ub, gacc[3]); gacc[4] = km_fma(ay, vb, gacc[4]); gacc[5] += ay;
+    gacc[6] = km_fma(az, ub, gacc[6]); gacc[7] = km_fma(az, vb, gacc[7]); gacc[8] += az;
 }
 
 struct KmtBand {
@@ -413,7 +445,7 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
     if (qj >= bwb) { qi += 1; qj -= bwb; }
     const uint32_t row0 = (uint32_t)bd.ib * (uint32_t)g.w + (uint32_t)bd.jb;  // the host guarantees 4 * h * w < 2^32
     int base = 0;
-    if (FIXED && !GM) {  // (the fused form keeps one pixel in flight: its matrix-gradient side needs the registers)
+    if (FIXED && !GM) {
         // KMT_UNROLL pixels per thread and iteration, all their grad_out loads issued first: a tile's time is (iterations) x (memory
         // latency + the pixels' arithmetic), so fewer, fatter iterations shorten it.  (A software-pipelined form - the loads of
         // iteration k + 1 issued before the pixels of iteration k - measured slower: 0.48 vs 0.45 ms on the same box.)
@@ -428,9 +460,33 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
             }
 #pragma unroll
             for (int s4 = 0; s4 < KMT_UNROLL; ++s4) {
-                const float4 c0 = s_u4[pqj[s4]], r0 = s_v4[pqi[s4]];  // (.w: the base coordinate itself)
-                kmt_pixel<T, CM, ALIGN, CC, FAST, FIXED, GM>(m, kmt_half(c0), kmt_half(r0), c0.w, r0.w, true, go[s4], s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0,
-                                                             THc, seen_bits, gm, gacc);
+                const float4 c0 = s_u4[pqj[s4]], r0 = s_v4[pqi[s4]];
+                KmtPix q;
+                kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), true, Wm1, hW, Hm1, hH, X0, Y0, q);
+                kmt_pix_scatter<CC, FIXED>(q, go[s4], s_acc, scale, TWc, THc, seen_bits);
+            }
+        }
+    }
+    if (FIXED && GM) {
+        // fused form: the position comes first (it addresses the source taps), then grad_out and the taps of KMT_UNROLL_GM pixels are
+        // requested back to back, then the pixels are scattered and their matrix-gradient terms formed
+        for (; base + KMT_UNROLL_GM * KMT_NT <= nq; base += KMT_UNROLL_GM * KMT_NT) {
+            KmtPix q[KMT_UNROLL_GM];
+            float ub[KMT_UNROLL_GM], vb[KMT_UNROLL_GM];  // (.w of the table entries: the base coordinate itself)
+            float go[KMT_UNROLL_GM][CC], sv[KMT_UNROLL_GM][CC][4];
+#pragma unroll
+            for (int s4 = 0; s4 < KMT_UNROLL_GM; ++s4) {
+                const float4 c0 = s_u4[qj], r0 = s_v4[qi];
+                ub[s4] = c0.w; vb[s4] = r0.w;
+                kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi * (uint32_t)g.w + (uint32_t)qj, go[s4]);
+                kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), true, Wm1, hW, Hm1, hH, X0, Y0, q[s4]);
+                kmt_pix_load_src<T, CC>(gm, q[s4], sv[s4]);
+                kmt_advance(qi, qj, di, dj, bwb);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < KMT_UNROLL_GM; ++s4) {
+                kmt_pix_scatter<CC, FIXED>(q[s4], go[s4], s_acc, scale, TWc, THc, seen_bits);
+                kmt_pix_gm<T, CM, CC, FAST>(gm, q[s4], ub[s4], vb[s4], go[s4], sv[s4], X0, TWc, Y0, THc, gacc);
             }
         }
     }
@@ -440,8 +496,12 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
         float go[CC];
         kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)vqi * (uint32_t)g.w + (uint32_t)vqj, go);
         const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
-        kmt_pixel<T, CM, ALIGN, CC, FAST, FIXED, GM>(m, kmt_half(c0), kmt_half(r0), c0.w, r0.w, valid, go, s_acc, scale, Wm1, hW, Hm1, hH, X0, TWc, Y0, THc,
-                                                     seen_bits, gm, gacc);
+        KmtPix q;
+        kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), valid, Wm1, hW, Hm1, hH, X0, Y0, q);
+        float sv[CC][4];
+        if (GM) kmt_pix_load_src<T, CC>(gm, q, sv);
+        kmt_pix_scatter<CC, FIXED>(q, go, s_acc, scale, TWc, THc, seen_bits);
+        if (GM) kmt_pix_gm<T, CM, CC, FAST>(gm, q, c0.w, r0.w, go, sv, X0, TWc, Y0, THc, gacc);
         kmt_advance(qi, qj, di, dj, bwb);
     }
 }
@@ -678,9 +738,12 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
 #ifndef KMT_MIN_WAVES
 #define KMT_MIN_WAVES 6
 #endif
+#ifndef KMT_MIN_WAVES_GM
+#define KMT_MIN_WAVES_GM 4  // fused form: 128 registers (80 spill ~190 of them to scratch: the taps and grad_out of the pixels in flight)
+#endif
 
 template <typename T, int CM, int ALIGN, bool GM>
-__global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
+__global__ __launch_bounds__(KMT_NT, GM ? KMT_MIN_WAVES_GM : KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ float red_max[KMT_NW];
     __shared__ int s_box[8];
@@ -688,7 +751,7 @@ __global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kerne
     static_assert(KMT_BAND_W + KMT_TAB <= KMT_NT || KMT_NT >= 2 * KMT_TAB, "the column and row tables are filled by disjoint threads");
 
     const KmWarpGeom<float>& g = a.g;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
@@ -779,6 +842,7 @@ static int kmt_run(const void* gout, const void* mat, void* gsrc, const void* sr
     KM_REQUIRE(nb < (1ull << 31), "km_warp2d_bwd: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
+    a.reverse = km_traversal_next();
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmt_launch<T, KM_COORD_PERSPECTIVE>(a, s);
         case KM_COORD_AFFINE: return kmt_launch<T, KM_COORD_AFFINE>(a, s);
@@ -802,9 +866,10 @@ int km_warp_bwd_tiled_dims_ok(int h, int w) { return ((uint64_t)h * (uint64_t)w 
 
 // 1 if the tile-owner kernel should also form the matrix gradient (one read of grad_out for both gradients)
 int km_warp_bwd_tiled_fuses_gm(int H, int W) {
-    // Measured on MI355X (256x3x512^2): fused 1.32 ms against 0.79 ms for the two launches - the gathers of the source taps
-    // serialise behind each pixel's grad_out load in the tile-owner loop, and their registers take away the second pixel in
-    // flight.  Kept for A/B timing: KM_WARP_BWD_FUSE=1.
+    // Measured on MI355X (256x3x512^2): 0.92 ms fused (128 registers, 2 workgroups per CU, grad_out and the source taps of two pixels
+    // in flight) against 0.77 ms for the two launches.  (The first fused form - taps gathered after each pixel's scatter, under the
+    // scatter's 80-register bound, i.e. ~190 registers spilled to scratch - took 1.32 ms.)  The tile-owner loop is VALU / latency bound
+    // and the matrix-gradient kernel is bound by its tap gathers; one loop that does both pays both.  Kept for A/B timing: KM_WARP_BWD_FUSE=1.
     static int off = -1;
     if (off < 0) {
         const char* e = getenv("KM_WARP_BWD_FUSE");
@@ -819,7 +884,11 @@ int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, const v
                           int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, int dtype, hipStream_t s) {
     switch (dtype) {
         case KM_F32: return kmt_run<float>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+#ifndef KMT_DEV_F32_ONLY  // (development builds: one storage type compiles in a third of the time)
         case KM_BF16: return kmt_run<km_bf16>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
         default: return kmt_run<km_f16>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+#else
+        default: return -1;
+#endif
     }
 }

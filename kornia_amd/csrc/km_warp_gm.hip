@@ -29,6 +29,9 @@
 #define KMG_PATCH_W 32  // measured at 256x3x512^2: 64 -> 0.375 ms (0.83 at 20 deg, 1.32 at 45 deg), 32 -> 0.368 (0.60, 0.84), 16 -> 0.412 (0.57, 0.68)
 #endif
 #define KMG_TILE_H (4 * KMG_ROWS)
+#ifndef KMG_BOUNDS
+#define KMG_BOUNDS __launch_bounds__(256)
+#endif
 
 template <typename T>
 struct KmWarpGmArgs {
@@ -39,6 +42,7 @@ struct KmWarpGmArgs {
     const float* fill;  // (C), pad == fill only
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, nblocks;
+    uint32_t reverse;   // the XCDs walk their block ranges backwards (km_traversal_next)
 };
 
 // matrix-gradient terms of one output pixel from the lean position record (km_gm_terms on KmlPos)
@@ -204,12 +208,12 @@ __device__ __forceinline__ void kmg_block_reduce(const float (&S)[3], const floa
 }
 
 template <typename T, int CM, int NC, int ALIGN>  // NC = 3 / 1: RGB / grey unrolled ; NC = 0: runtime channel loop
-__global__ __launch_bounds__(256) void km_warp_gm_kernel(const KmWarpGmArgs<T> a) {
+__global__ KMG_BOUNDS void km_warp_gm_kernel(const KmWarpGmArgs<T> a) {
     const KmWarpGeom<float>& g = a.g;
     __shared__ double red[4][9];
     __shared__ float4 s_rv[KMG_TILE_H];  // per row of the tile: (m1 v, m4 v, m7 v, v)
     __shared__ int s_fast;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
@@ -408,6 +412,7 @@ static int kmg_run(const void* gout, const void* src, const void* mat, double* g
     KM_REQUIRE(nb < (1ull << 31), "km_warp2d_bwd: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
+    a.reverse = km_traversal_next();
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmg_launch<T, KM_COORD_PERSPECTIVE>(a, s);
         case KM_COORD_AFFINE: return kmg_launch<T, KM_COORD_AFFINE>(a, s);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds the library of a git revision into gpurun_out/lib_<tag>.so (A/B timing on one box): build_revision.sh <rev> <tag>
+# builds the library of a git revision into kornia_amd/lib/var/lib_<tag>.so (A/B timing on one box): build_revision.sh <rev> <tag>
 set -e
 rev=$1; tag=$2
 cd /root/repo
@@ -12,6 +12,6 @@ for f in $tmp/kornia_amd/csrc/*.hip; do
   objs="$objs $o"
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_out/lib_${tag}.so $objs
+hipcc --offload-arch=gfx950 -shared -fPIC -o kornia_amd/lib/var/lib_${tag}.so $objs
 rm -rf $tmp
-echo built gpurun_out/lib_${tag}.so
+echo built kornia_amd/lib/var/lib_${tag}.so

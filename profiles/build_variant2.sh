@@ -1,13 +1,16 @@
 #!/bin/bash
-# build_variant.sh <tag> <flags...> : rebuilds the three warp sources with extra -D flags, links with the current objects
-# -> kornia_amd/lib/var/lib_<tag>.so (travels to the GPU box; select with KORNIA_AMD_LIB)
+# build_variant2.sh <tag> <file>:<flags,comma-separated> ... : per-file -D flags, links with the current objects -> kornia_amd/lib/var/lib_<tag>.so
 set -e
 tag=$1; shift
 cd /root/repo
 mkdir -p kornia_amd/lib/var
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt"
 d=$(mktemp -d)
-for f in ${KM_VARIANT_FILES:-km_warp km_warp_gm km_warp_bwd_tiled}; do hipcc $F "$@" -c kornia_amd/csrc/$f.hip -o $d/$f.o & done
+for spec in "$@"; do
+  f=${spec%%:*}; fl=${spec#*:}
+  IFS='|' read -ra FL <<< "$fl"
+  hipcc $F "${FL[@]}" -c kornia_amd/csrc/$f.hip -o $d/$f.o &
+done
 wait
 objs=""
 for o in kornia_amd/lib/obj/*.o; do b=$(basename $o); if [ -f $d/$b ]; then objs="$objs $d/$b"; else objs="$objs $o"; fi; done
