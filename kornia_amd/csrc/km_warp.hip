@@ -920,9 +920,8 @@ static int km_warp_validate(const char* fn, const void* src, const void* mat, in
 // owner-computes grad_src for bilinear + zeros/fill (km_warp_bwd_tiled.hip)
 int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc);
 int km_warp_bwd_tiled_dims_ok(int h, int w);
-int km_warp_bwd_tiled_fuses_gm(int H, int W);
-int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, const void* src, double* gmat, const void* fill, int B, int C, int H, int W,
-                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, int dtype, hipStream_t s);
+int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords,
+                          int pad, int align, int dtype, hipStream_t s);
 
 // matrix gradient of the bilinear warps (km_warp_gm.hip)
 int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, int w);
@@ -982,12 +981,10 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
     if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc)) {
         if (km_warp_bwd_tiled_dims_ok(h, w)) {
             // both gradients in one pass over grad_out when the tile-owner kernel can gather the source taps itself
-            const bool fuse = gmat && gm_fast && km_warp_bwd_tiled_fuses_gm(H, W);
             // scatter first, matrix gradient second: with the alternating batch traversal (km_traversal_next) the second launch starts on the
             // part of grad_out the first one read last.  (The other order measured 1.868 against 1.845 ms per step - no better than a fixed direction.)
-            const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, src, fuse ? gmat : nullptr, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad,
-                                                 align, dtype, s);
-            if (rc != 0 || !gmat || fuse) return rc;
+            const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, dtype, s);
+            if (rc != 0 || !gmat) return rc;
             if (gm_fast) return km_warp_gm_run(gout, src, mat, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
             gsrc = nullptr;  // matrix gradient by the generic kernel below (W < 2)
         } else {

@@ -1,6 +1,13 @@
 // kornia_amd - "owner-computes" gradient of the bilinear warps (zeros / fill padding) with respect to the
 // IMAGE, for gfx950.  (The gradient with respect to the matrix is km_warp_gm.hip.)
 //
+// Two ways of producing both gradients from ONE read of grad_out were built and measured on MI355X (256x3x512^2) and are not in the
+// tree: the matrix-gradient terms inside the tile-owner loop (source taps gathered with each pixel's grad_out: 1.32 ms under the
+// scatter's 80-register bound, 0.92 ms with 128 registers and 2 workgroups per CU), and the two kernels' workgroups interleaved in one
+// launch (tile-owner and matrix-gradient workgroups of the same image as neighbours on a CU, grad_out shared through L2: 0.845 ms) -
+// against 0.77 - 0.79 ms for the two launches.  Both kernels are limited by the latency their own resident waves can hide, so taking
+// registers, LDS or workgroup slots from one to host the other costs more than the second read of grad_out.
+//
 // The generic backward (km_warp.hip) scatters 4*C fp32 atomics per output pixel into HBM - what ATen's
 // grid_sampler_2d_backward does - and needs grad_src zeroed first: ~5e bytes of HBM traffic per element
 // against 2e algorithmic, serialised by the L2 atomic units (4.2 ms at 256x3x512^2).  Here:
@@ -41,9 +48,6 @@
 #ifndef KMT_UNROLL
 #define KMT_UNROLL 2       // pixels in flight per thread in the scatter loop
 #endif
-#ifndef KMT_UNROLL_GM
-#define KMT_UNROLL_GM 2    // the same in the fused form (both gradients): grad_out and the source taps of each pixel in flight
-#endif
 #define KMT_CC 3            // channels per pass
 #define KMT_BAND_W 128      // output columns per band = capacity of the column table (float4 entries)
 #define KMT_TAB 128         // output rows per band = capacity of the row table (float4 entries)
@@ -55,9 +59,6 @@ struct KmWarpTiledArgs {
     const T* gout;       // (B,C,h,w)
     const float* mat;    // (B_M,9)
     float* gsrc;         // (B,C,H,W) fp32, written completely (no pre-zeroing needed)
-    const T* src;        // (B,C,H,W): only read when gmat != nullptr
-    double* gmat;        // (B_M,9) fp64 accumulators, pre-zeroed; nullptr: image gradient only
-    const float* fill;   // (C), pad == fill only (the matrix gradient sees (v - fill))
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, nblocks;
     uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
@@ -337,91 +338,6 @@ __device__ __forceinline__ void kmt_pix_scatter(const KmtPix& q, const float (&g
     }
 }
 
-// ---- matrix-gradient side of a visited pixel (fused form: grad_out is read once for both gradients, 3e bytes per element for the
-// backward instead of 4e with a separate matrix-gradient launch).  A pixel is counted by the ONE tile that owns its north-west tap
-// (clamped into the image).  Its source taps are gathered from global memory as two (xa, xa + 1) pairs on rows ya0 / ya1, clamped so
-// that every address is valid whatever the position; the loads are ISSUED TOGETHER WITH the pixel's grad_out loads - the addresses
-// depend on the position only - so an iteration of the tile-owner loop waits for memory once.  (The first fused form gathered the
-// taps after the scatter of each pixel: two dependent memory latencies per iteration and one pixel in flight, 1.32 ms; this form
-// 0.92 ms; the two launches 0.77 ms at 256x3x512^2 - km_warp_bwd_tiled_fuses_gm.)
-template <typename T, int CC>
-struct KmtGm {
-    const T* src_c[CC];   // channel planes of the source image
-    float fill[CC];       // pad == fill: subtracted from every in-bounds tap
-    int W, H;
-    float mx, my;         // d (pixel) / d (normalised)
-    bool enabled;         // false while a tile is being redone with the exact scale (its matrix-gradient sums are already complete)
-};
-
-template <typename T, int CC>
-__device__ __forceinline__ void kmt_pix_load_src(const KmtGm<T, CC>& gm, const KmtPix& q, float (&sv)[CC][4]) {
-    const int x0 = KM_F2I(q.t.xf), y0 = KM_F2I(q.t.yf);  // saturating; NaN -> 0
-    const int xa = min(max(x0, 0), gm.W - 2);             // pair base column: x0 unless x0 = -1 (-> 0) or x0 = W - 1 (-> W - 2)
-    const int yc = min(max(y0, -1), gm.H - 1);
-    const int ya0 = max(yc, 0), ya1 = min(yc + 1, gm.H - 1);
-    const uint32_t o0 = (uint32_t)__mul24(ya0, gm.W) + (uint32_t)xa, o1 = (uint32_t)__mul24(ya1, gm.W) + (uint32_t)xa;
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-        km_ld2(km_at(gm.src_c[c], o0), sv[c][0], sv[c][1]);
-        km_ld2(km_at(gm.src_c[c], o1), sv[c][2], sv[c][3]);
-    }
-}
-
-template <typename T, int CM, int CC, bool FAST>
-__device__ __forceinline__ void kmt_pix_gm(const KmtGm<T, CC>& gm, const KmtPix& q, float ub, float vb, const float (&go)[CC], const float (&sv)[CC][4], uint32_t X0,
-                                           uint32_t TWc, uint32_t Y0, uint32_t THc, float (&gacc)[9]) {
-    // owner = the tile holding (max(x0, 0), max(y0, 0)); a pixel with no tap inside the image contributes nothing anywhere
-    const bool ox = (q.ux < TWc) || ((X0 == 0u) && (q.ux == 0xffffffffu));
-    const bool oy = (q.uy < THc) || ((Y0 == 0u) && (q.uy == 0xffffffffu));
-    const bool own = ox && oy && (q.x == q.x) && (q.y == q.y) && gm.enabled;
-    if (!__any(own)) return;
-    const KmlTaps& t = q.t;
-    float gix = 0.f, giy = 0.f;
-    const bool interior = kml_inside(t, (float)(gm.W - 2), (float)(gm.H - 2));
-    if (__all(!own || interior)) {
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            const float f = gm.fill[c];  // 0 unless pad == fill (same rounding sequence as the oracle: (v - fill) first)
-            const float s00 = sv[c][0] - f, s01 = sv[c][1] - f, s10 = sv[c][2] - f, s11 = sv[c][3] - f;
-            gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-            giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
-        }
-    } else {
-        // per-tap bounds as km_bilinear_setup decides them (in floating point: NaN / huge positions are out of bounds); a column
-        // that is inside while its neighbour is not sits at the other end of the clamped pair
-        const float xf = t.xf, yf = t.yf;
-        const bool bx0 = (xf >= 0.0f) && (xf <= (float)(gm.W - 1)), bx1 = (xf >= -1.0f) && (xf <= (float)(gm.W - 2));
-        const bool by0 = (yf >= 0.0f) && (yf <= (float)(gm.H - 1)), by1 = (yf >= -1.0f) && (yf <= (float)(gm.H - 2));
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            const float f = gm.fill[c];
-            const float v00 = bx1 ? sv[c][0] : sv[c][1], v01 = bx0 ? sv[c][1] : sv[c][0];
-            const float v10 = bx1 ? sv[c][2] : sv[c][3], v11 = bx0 ? sv[c][3] : sv[c][2];
-            const float s00 = (bx0 && by0) ? v00 - f : 0.0f, s01 = (bx1 && by0) ? v01 - f : 0.0f;
-            const float s10 = (bx0 && by1) ? v10 - f : 0.0f, s11 = (bx1 && by1) ? v11 - f : 0.0f;
-            gix = km_fma(go[c], km_fma(s01 - s00, t.wy1, (s11 - s10) * t.wy0), gix);
-            giy = km_fma(go[c], km_fma(s10 - s00, t.wx1, (s11 - s01) * t.wx0), giy);
-        }
-    }
-    const KmlPos& p = q.p;
-    const float gx_ = own ? gix * gm.mx : 0.0f, gy_ = own ? giy * gm.my : 0.0f;
-    float ax, ay, az;
-    if (CM == KM_COORD_PERSPECTIVE) {
-        const float inv = FAST ? p.rinv : __frcp_rn(p.den);
-        ax = gx_ * inv; ay = gy_ * inv;
-        az = -km_fma(gx_, p.gx, gy_ * p.gy) * inv;
-    } else if (CM == KM_COORD_AFFINE) {
-        ax = gx_; ay = gy_; az = 0.f;
-    } else {
-        const float sc = p.den;
-        ax = gx_ * sc; ay = gy_ * sc;
-        az = p.live ? -km_fma(gx_, p.X, gy_ * p.Y) * sc * sc : 0.0f;
-    }
-    gacc[0] = km_fma(ax, ub, gacc[0]); gacc[1] = km_fma(ax, vb, gacc[1]); gacc[2] += ax;
-    gacc[3] = km_fma(ay, ub, gacc[3]); gacc[4] = km_fma(ay, vb, gacc[4]); gacc[5] += ay;
-    gacc[6] = km_fma(az, ub, gacc[6]); gacc[7] = km_fma(az, vb, gacc[7]); gacc[8] += az;
-}
-
 struct KmtBand {
     int jb, bwb;   // first output column of the band, its width (<= KMT_BAND_W)
     int ib, nrows; // first output row of the band, its height (<= KMT_TAB)
@@ -430,10 +346,10 @@ struct KmtBand {
 // One band of the box, walked as a linear list of pixels: element e = base + tid, (row, column) = (e / bwb, e % bwb).  Lane
 // utilisation is bwb * nrows / (a multiple of KMT_NT) whatever the shape of the box, consecutive lanes read consecutive
 // grad_out pixels.  Two pixels in flight per thread (FIXED: the IEEE float path is not worth unrolling).
-template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED, bool GM>
+template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED>
 __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, const float (&m)[9], const KmtBand& bd, const T* const (&gout_c)[CC],
                                                  const float4* s_u4, const float4* s_v4, int* s_acc, float scale, uint32_t X0, uint32_t TWc,
-                                                 uint32_t Y0, uint32_t THc, uint32_t& seen_bits, const KmtGm<T, CC>& gm, float (&gacc)[9]) {
+                                                 uint32_t Y0, uint32_t THc, uint32_t& seen_bits) {
     const int tid = threadIdx.x;
     const float Wm1 = (float)(g.W - 1), Hm1 = (float)(g.H - 1), hW = (float)g.W / 2, hH = (float)g.H / 2;
     const int bwb = bd.bwb;
@@ -445,7 +361,7 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
     if (qj >= bwb) { qi += 1; qj -= bwb; }
     const uint32_t row0 = (uint32_t)bd.ib * (uint32_t)g.w + (uint32_t)bd.jb;  // the host guarantees 4 * h * w < 2^32
     int base = 0;
-    if (FIXED && !GM) {
+    if (FIXED) {
         // KMT_UNROLL pixels per thread and iteration, all their grad_out loads issued first: a tile's time is (iterations) x (memory
         // latency + the pixels' arithmetic), so fewer, fatter iterations shorten it.  (A software-pipelined form - the loads of
         // iteration k + 1 issued before the pixels of iteration k - measured slower: 0.48 vs 0.45 ms on the same box.)
@@ -467,29 +383,6 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
             }
         }
     }
-    if (FIXED && GM) {
-        // fused form: the position comes first (it addresses the source taps), then grad_out and the taps of KMT_UNROLL_GM pixels are
-        // requested back to back, then the pixels are scattered and their matrix-gradient terms formed
-        for (; base + KMT_UNROLL_GM * KMT_NT <= nq; base += KMT_UNROLL_GM * KMT_NT) {
-            KmtPix q[KMT_UNROLL_GM];
-            float ub[KMT_UNROLL_GM], vb[KMT_UNROLL_GM];  // (.w of the table entries: the base coordinate itself)
-            float go[KMT_UNROLL_GM][CC], sv[KMT_UNROLL_GM][CC][4];
-#pragma unroll
-            for (int s4 = 0; s4 < KMT_UNROLL_GM; ++s4) {
-                const float4 c0 = s_u4[qj], r0 = s_v4[qi];
-                ub[s4] = c0.w; vb[s4] = r0.w;
-                kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi * (uint32_t)g.w + (uint32_t)qj, go[s4]);
-                kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), true, Wm1, hW, Hm1, hH, X0, Y0, q[s4]);
-                kmt_pix_load_src<T, CC>(gm, q[s4], sv[s4]);
-                kmt_advance(qi, qj, di, dj, bwb);
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < KMT_UNROLL_GM; ++s4) {
-                kmt_pix_scatter<CC, FIXED>(q[s4], go[s4], s_acc, scale, TWc, THc, seen_bits);
-                kmt_pix_gm<T, CM, CC, FAST>(gm, q[s4], ub[s4], vb[s4], go[s4], sv[s4], X0, TWc, Y0, THc, gacc);
-            }
-        }
-    }
     for (; base < nq; base += KMT_NT) {
         const bool valid = base + tid < nq;
         const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
@@ -498,10 +391,7 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
         const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
         KmtPix q;
         kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), valid, Wm1, hW, Hm1, hH, X0, Y0, q);
-        float sv[CC][4];
-        if (GM) kmt_pix_load_src<T, CC>(gm, q, sv);
         kmt_pix_scatter<CC, FIXED>(q, go, s_acc, scale, TWc, THc, seen_bits);
-        if (GM) kmt_pix_gm<T, CM, CC, FAST>(gm, q, c0.w, r0.w, go, sv, X0, TWc, Y0, THc, gacc);
         kmt_advance(qi, qj, di, dj, bwb);
     }
 }
@@ -527,10 +417,9 @@ __device__ __forceinline__ void kmt_scatter_band(const KmWarpGeom<float>& g, con
 //     the exact maximum over its box (attempt 1).  The factor 8 costs 3 bits of the fixed-point resolution;
 //   * three block barriers per tile (accumulators zeroed + box + sample | coordinate tables | scatter done) when the box
 //     fits one band of the tables - any warp that does not shrink the image by more than 2x.
-template <typename T, int CM, int ALIGN, int CC, bool GM>
+template <typename T, int CM, int ALIGN, int CC>
 __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, const float (&m)[9], uint32_t b, int cbase, int X0, int Y0, int TWc, int THc,
-                                               bool box_pending, const int* s_box, float4* s_u4, float4* s_v4, int* s_acc, float* red_max,
-                                               float (&gm_total)[9]) {
+                                               bool box_pending, const int* s_box, float4* s_u4, float4* s_v4, int* s_acc, float* red_max) {
     const KmWarpGeom<float>& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t src_plane = (size_t)g.H * g.W, dst_plane = (size_t)g.h * g.w;
@@ -538,17 +427,6 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
     const T* gout_c[CC];
 #pragma unroll
     for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)b * g.C + (size_t)(cbase + c)) * dst_plane;
-    KmtGm<T, CC> gm;
-    gm.W = g.W; gm.H = g.H;
-    gm.mx = ALIGN ? (float)(g.W - 1) / 2 : (float)g.W / 2;
-    gm.my = ALIGN ? (float)(g.H - 1) / 2 : (float)g.H / 2;
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-        gm.src_c[c] = GM ? a.src + ((size_t)b * g.C + (size_t)(cbase + c)) * src_plane : nullptr;
-        gm.fill[c] = (GM && g.pad == KM_PAD_FILL) ? a.fill[cbase + c] : 0.0f;
-    }
-    gm.enabled = true;
-
     // ---- speculative bound: one pixel per thread on a KMT_NT-point lattice over the tile's own location in the output ----
     float vsample = 0.f;
     if (g.h > 0 && g.w > 0) {
@@ -672,9 +550,9 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
                     }
                     const bool fast = __syncthreads_and((int)okr) != 0;  // every row of the band has safe division operands
                     const uint32_t uX0 = (uint32_t)X0, uY0 = (uint32_t)Y0, uTW = (uint32_t)TWc, uTH = (uint32_t)THc;
-                    if (!finite) kmt_scatter_band<T, CM, ALIGN, CC, false, false, GM>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits, gm, gm_total);
-                    else if (fast) kmt_scatter_band<T, CM, ALIGN, CC, true, true, GM>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits, gm, gm_total);
-                    else kmt_scatter_band<T, CM, ALIGN, CC, false, true, GM>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits, gm, gm_total);
+                    if (!finite) kmt_scatter_band<T, CM, ALIGN, CC, false, false>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
+                    else if (fast) kmt_scatter_band<T, CM, ALIGN, CC, true, true>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
+                    else kmt_scatter_band<T, CM, ALIGN, CC, false, true>(g, m, bd, gout_c, s_u4, s_v4, s_acc, scale, uX0, uTW, uY0, uTH, seen_bits);
                 }
             }
         }
@@ -683,7 +561,6 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
         const int redo = __syncthreads_or((int)exceeded);
         if (attempt == 0 && redo) {
             for (int e = tid; e < CC * KMT_PLANE / 4; e += KMT_NT) ((int4*)s_acc)[e] = make_int4(0, 0, 0, 0);  // discard the attempt
-            gm.enabled = false;  // the matrix-gradient sums do not depend on the scale: attempt 0 has formed them
             continue;  // the barriers at the top of attempt 1 order these stores before the next atomics
         }
         break;
@@ -738,24 +615,11 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
 #ifndef KMT_MIN_WAVES
 #define KMT_MIN_WAVES 6
 #endif
-#ifndef KMT_MIN_WAVES_GM
-#define KMT_MIN_WAVES_GM 4  // fused form: 128 registers (80 spill ~190 of them to scratch: the taps and grad_out of the pixels in flight)
-#endif
 
-template <typename T, int CM, int ALIGN, bool GM>
-__global__ __launch_bounds__(KMT_NT, GM ? KMT_MIN_WAVES_GM : KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ float red_max[KMT_NW];
-    __shared__ int s_box[8];
-    __shared__ double red_gm[GM ? KMT_NW : 1][9];
-    static_assert(KMT_BAND_W + KMT_TAB <= KMT_NT || KMT_NT >= 2 * KMT_TAB, "the column and row tables are filled by disjoint threads");
-
+// one tile (tx, ty) of image b, all channels: the body of a workgroup
+template <typename T, int CM, int ALIGN>
+__device__ __forceinline__ void kmt_tile_block(const KmWarpTiledArgs<T>& a, uint32_t tx, uint32_t ty, uint32_t b, char* smem_raw, float* red_max, int* s_box) {
     const KmWarpGeom<float>& g = a.g;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
-    const uint32_t tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const uint32_t ty = bid % a.tiles_y;
-    const uint32_t b = bid / a.tiles_y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int X0 = (int)tx * KMT_TW, Y0 = (int)ty * KMT_TH;
     const int X1 = min(X0 + KMT_TW, g.W), Y1 = min(Y0 + KMT_TH, g.H);  // tile = [X0,X1) x [Y0,Y1)
@@ -785,55 +649,45 @@ __global__ __launch_bounds__(KMT_NT, GM ? KMT_MIN_WAVES_GM : KMT_MIN_WAVES) void
     int* s_acc = (int*)(s_v4 + KMT_TAB);
 
     // channels in chunks of 3 (RGB: one pass); a remainder of 1 or 2 channels goes one channel at a time
-    float gm_total[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) gm_total[k] = 0.f;
     int cbase = 0;
     for (; cbase + KMT_CC <= g.C; cbase += KMT_CC) {
         if (cbase) __syncthreads();  // the previous chunk's flush is done with the accumulators
-        kmt_tile_chunk<T, CM, ALIGN, KMT_CC, GM>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max, gm_total);
+        kmt_tile_chunk<T, CM, ALIGN, KMT_CC>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max);
     }
     for (; cbase < g.C; ++cbase) {
         if (cbase) __syncthreads();
-        kmt_tile_chunk<T, CM, ALIGN, 1, GM>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max, gm_total);
-    }
-    if (GM) {  // per-thread fp32 partial sums -> fp64 wave / block reduction -> 9 fp64 atomics per block
-        if (CM == KM_COORD_AFFINE) gm_total[6] = gm_total[7] = gm_total[8] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const double sum = km_wave_sum((double)gm_total[k]);
-            if (lane == 0) red_gm[wave][k] = sum;
-        }
-        __syncthreads();
-        if (threadIdx.x < 9) {
-            double sum = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < KMT_NW; ++wv) sum += red_gm[wv][threadIdx.x];
-            if (sum != 0.0) km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0 : b) * 9 + threadIdx.x, sum);
-        }
+        kmt_tile_chunk<T, CM, ALIGN, 1>(a, m, b, cbase, X0, Y0, TWc, THc, cbase == 0, s_box, s_u4, s_v4, s_acc, red_max);
     }
 }
 
-template <typename T, int CM, bool GM>
-static void kmt_launch_gm(const KmWarpTiledArgs<T>& a, hipStream_t s) {
-    if (a.g.align)
-        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 1, GM>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
-    else
-        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 0, GM>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+template <typename T, int CM, int ALIGN>
+__global__ __launch_bounds__(KMT_NT, KMT_MIN_WAVES) void km_warp_bwd_tiled_kernel(const KmWarpTiledArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ float red_max[KMT_NW];
+    __shared__ int s_box[8];
+    static_assert(KMT_BAND_W + KMT_TAB <= KMT_NT || KMT_NT >= 2 * KMT_TAB, "the column and row tables are filled by disjoint threads");
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+    kmt_tile_block<T, CM, ALIGN>(a, tx, ty, b, smem_raw, red_max, s_box);
 }
+
 template <typename T, int CM>
 static int kmt_launch(const KmWarpTiledArgs<T>& a, hipStream_t s) {
-    if (a.gmat) kmt_launch_gm<T, CM, true>(a, s);
-    else kmt_launch_gm<T, CM, false>(a, s);
+    if (a.g.align)
+        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 1>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
+    else
+        hipLaunchKernelGGL((km_warp_bwd_tiled_kernel<T, CM, 0>), dim3(a.nblocks), dim3(KMT_NT), (size_t)KMT_LDS_BYTES, s, a);
     return km_check_launch("km_warp2d_bwd(tiled)");
 }
 
 template <typename T>
-static int kmt_run(const void* gout, const void* mat, void* gsrc, const void* src, double* gmat, const void* fill, int B, int C, int H, int W, int h, int w,
-                   int B_M, int coord_mode, int norm_coords, int pad, int align, hipStream_t s) {
+static int kmt_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords, int pad,
+                   int align, hipStream_t s) {
     KmWarpTiledArgs<T> a;
     a.gout = (const T*)gout; a.mat = (const float*)mat; a.gsrc = (float*)gsrc;
-    a.src = (const T*)src; a.gmat = gmat; a.fill = (const float*)fill;
     KmWarpGeom<float>& g = a.g;
     km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, KM_INTERP_BILINEAR, pad, align);
     a.tiles_x = (uint32_t)((W + KMT_TW - 1) / KMT_TW);
@@ -864,29 +718,14 @@ int km_warp_bwd_tiled_supported(int interp, int pad, int dtype, const void* gsrc
 // 32-bit byte offsets inside a grad_out plane (the caller falls back to the generic kernel otherwise)
 int km_warp_bwd_tiled_dims_ok(int h, int w) { return ((uint64_t)h * (uint64_t)w * 4 < (1ull << 32)) ? 1 : 0; }
 
-// 1 if the tile-owner kernel should also form the matrix gradient (one read of grad_out for both gradients)
-int km_warp_bwd_tiled_fuses_gm(int H, int W) {
-    // Measured on MI355X (256x3x512^2): 0.92 ms fused (128 registers, 2 workgroups per CU, grad_out and the source taps of two pixels
-    // in flight) against 0.77 ms for the two launches.  (The first fused form - taps gathered after each pixel's scatter, under the
-    // scatter's 80-register bound, i.e. ~190 registers spilled to scratch - took 1.32 ms.)  The tile-owner loop is VALU / latency bound
-    // and the matrix-gradient kernel is bound by its tap gathers; one loop that does both pays both.  Kept for A/B timing: KM_WARP_BWD_FUSE=1.
-    static int off = -1;
-    if (off < 0) {
-        const char* e = getenv("KM_WARP_BWD_FUSE");
-        off = (e && e[0] == '1') ? 0 : 1;
-    }
-    // 32-bit byte offsets inside a source plane, 24-bit row / column counts, pair loads need two columns
-    return (!off && W >= 2 && (uint64_t)H * W * 4 < (1ull << 32) && W < (1 << 23) && H < (1 << 23)) ? 1 : 0;
-}
-
-// grad_src (pad zeros / fill does not change it) and, when gmat != nullptr, the matrix gradient (src and, for pad == fill, fill are read then)
-int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, const void* src, double* gmat, const void* fill, int B, int C, int H, int W,
-                          int h, int w, int B_M, int coord_mode, int norm_coords, int pad, int align, int dtype, hipStream_t s) {
+// grad_src (pad zeros / fill does not change it)
+int km_warp_bwd_tiled_run(const void* gout, const void* mat, void* gsrc, int B, int C, int H, int W, int h, int w, int B_M, int coord_mode, int norm_coords,
+                          int pad, int align, int dtype, hipStream_t s) {
     switch (dtype) {
-        case KM_F32: return kmt_run<float>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        case KM_F32: return kmt_run<float>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
 #ifndef KMT_DEV_F32_ONLY  // (development builds: one storage type compiles in a third of the time)
-        case KM_BF16: return kmt_run<km_bf16>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
-        default: return kmt_run<km_f16>(gout, mat, gsrc, src, gmat, fill, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        case KM_BF16: return kmt_run<km_bf16>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
+        default: return kmt_run<km_f16>(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, s);
 #else
         default: return -1;
 #endif
