@@ -19,9 +19,6 @@
 #include "km_warp_args.h"
 #include "km_warp_stage.h"
 
-#ifndef KML_EXP
-#define KML_EXP 0   // timing experiments only (wrong results): 1 = no fallback loads for lanes without a right neighbour, 2 = one source row
-#endif
 #ifndef KM_ROWS
 #define KM_ROWS 4   // output rows per thread
 #endif
@@ -372,7 +369,10 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
         // the next lane when that lane's footprint starts exactly one pixel to the right - which it does for most lanes of any
         // warp of scale ~1; the others (and the last lane of each output row of the patch) load it themselves.  Same values either way.
         // (Fetching the edge lanes' columns with ONE helper load - lane k loads item k - and handing them over through ds_bpermute
-        // measured slower: 0.425 vs 0.378 ms.)
+        // measured slower: 0.425 vs 0.378 ms.  Ablations on one box, wrong results, timing only: 0.39 ms as is; without the fallback
+        // loads of the lanes that have no right neighbour 0.362; with one source row on top of that - 3 loads + 3 stores per 64 pixels, the
+        // shape of a copy - 0.324; identity / pure translation matrices 0.355 - 0.366: the floor of a lane-per-pixel tile copy is ~0.32.
+        // Rows per thread 2 / 3 / 4 (62 / 80 / 94 registers, 8 / 6 / 5 waves per SIMD): 0.381 / 0.389 / 0.389 - occupancy is not it.)
         float v[KM_ROWS][NCC][4];
         bool nb[KM_ROWS];
 #pragma unroll
@@ -382,19 +382,11 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
                 v[r][c][0] = (float)km_ld(km_at(sp[c], off));
-#if KML_EXP == 2
-                v[r][c][2] = v[r][c][0];
-#else
                 v[r][c][2] = (float)km_ld(km_at(sp[c], off + (uint32_t)W));
-#endif
-#if KML_EXP >= 1
-                v[r][c][1] = v[r][c][0]; v[r][c][3] = v[r][c][2];
-#else
                 if (!nb[r]) {
                     v[r][c][1] = (float)km_ld(km_at(sp[c], off + 1u));
                     v[r][c][3] = (float)km_ld(km_at(sp[c], off + (uint32_t)W + 1u));
                 }
-#endif
             }
         }
 #pragma unroll

@@ -98,7 +98,10 @@ __device__ __forceinline__ void km_warp_gm_rows(const KmWarpGmArgs<T>& a, const 
             const T* __restrict__ gp[NCC];
 #pragma unroll
             for (int c = 0; c < NCC; ++c) { sp[c] = src_b + c * src_plane; gp[c] = gout_b + c * dst_plane; }  // wave-uniform plane bases
-            // (taking the x0 + 1 column from the next lane, as the forward does, measured slower here: 0.40 vs 0.38 ms)
+            // (taking the x0 + 1 column from the next lane, as the forward does, measured slower here: 0.40 vs 0.38 ms.  Ablations on one
+            // box, wrong results, timing only: 0.397 ms as is; 4-byte instead of 8-byte tap loads 0.345; one source row 0.349; no source
+            // taps at all - grad_out, the position arithmetic and the reductions only - 0.266: two thirds of the kernel's time is not its
+            // tap gathers but the dependent chain position -> address -> load -> terms of each group of rows.)
             float go[GROUP][NCC], v[GROUP][NCC][4];
 #pragma unroll
             for (int q = 0; q < GROUP; ++q) {
