@@ -41,21 +41,37 @@ __device__ __forceinline__ void km_ld4(const km_f16* p, float (&o)[4]) {
 }
 __device__ __forceinline__ void km_st4(float* p, const float (&o)[4]) {
     KM_CHECK_ALIGNED(p, 16);
+#ifdef KM_NT_ST
+    typedef float km_f4v __attribute__((ext_vector_type(4)));
+    km_f4v v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+    __builtin_nontemporal_store(v, reinterpret_cast<km_f4v*>(p));
+#else
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+#endif
 }
 __device__ __forceinline__ void km_st4(km_bf16* p, const float (&o)[4]) {
     uint2 v;
     v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
     v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
     KM_CHECK_ALIGNED(p, 8);
+#ifdef KM_NT_ST
+    typedef uint32_t km_u2v __attribute__((ext_vector_type(2)));
+    km_u2v vv; vv.x = v.x; vv.y = v.y;
+    __builtin_nontemporal_store(vv, reinterpret_cast<km_u2v*>(p));
+#else
     *reinterpret_cast<uint2*>(p) = v;
+#endif
 }
 __device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 v;
     v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
     KM_CHECK_ALIGNED(p, 8);
+#ifdef KM_NT_ST
+    __builtin_nontemporal_store(v, reinterpret_cast<h4*>(p));
+#else
     *reinterpret_cast<h4*>(p) = v;
+#endif
 }
 // two adjacent pixels with one 8-byte / 4-byte store
 __device__ __forceinline__ void km_st2(float* p, float a, float b) {

@@ -586,7 +586,15 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
                 } else {
                     v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
                 }
+#ifdef KM_NT_ST
+                {
+                    typedef float km_f4v __attribute__((ext_vector_type(4)));
+                    km_f4v vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
+                    __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v*>(outp));
+                }
+#else
                 *reinterpret_cast<float4*>(outp) = v;
+#endif
                 outp += ostep;
                 accp += (KMT_NT / 16) * KMT_TW;
             }
