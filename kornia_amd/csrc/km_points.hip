@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void km_transform_points_fwd_vec_kernel(const 
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         KM_CHECK_ALIGNED(a.out + off + 4 * q, 16);
+#ifdef KM_NT_ST
+        typedef float km_f4v __attribute__((ext_vector_type(4)));
+        km_f4v vv; vv.x = v[4 * q]; vv.y = v[4 * q + 1]; vv.z = v[4 * q + 2]; vv.w = v[4 * q + 3];
+        __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v*>(a.out + off + 4 * q));
+#else
         *reinterpret_cast<float4*>(a.out + off + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+#endif
     }
 }
 

@@ -76,16 +76,30 @@ __device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
 // two adjacent pixels with one 8-byte / 4-byte store
 __device__ __forceinline__ void km_st2(float* p, float a, float b) {
     KM_CHECK_ALIGNED(p, 8);
+#ifdef KM_NT_ST
+    typedef float km_f2v __attribute__((ext_vector_type(2)));
+    km_f2v v; v.x = a; v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<km_f2v*>(p));
+#else
     *reinterpret_cast<float2*>(p) = make_float2(a, b);
+#endif
 }
 __device__ __forceinline__ void km_st2(km_bf16* p, float a, float b) {
     KM_CHECK_ALIGNED(p, 4);
+#ifdef KM_NT_ST
+    __builtin_nontemporal_store((uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16), reinterpret_cast<uint32_t*>(p));
+#else
     *reinterpret_cast<uint32_t*>(p) = (uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16);
+#endif
 }
 __device__ __forceinline__ void km_st2(km_f16* p, float a, float b) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     h2 v;
     v.x = (_Float16)a; v.y = (_Float16)b;
     KM_CHECK_ALIGNED(p, 4);
+#ifdef KM_NT_ST
+    __builtin_nontemporal_store(v, reinterpret_cast<h2*>(p));
+#else
     *reinterpret_cast<h2*>(p) = v;
+#endif
 }
