@@ -175,6 +175,18 @@ int km_spatial_gradient_fwd(const void* x, const void* kern_host, void* out, voi
 int km_spatial_gradient_bwd(const void* gout, const void* kern_host, void* gx, int B, int C, int H, int W, int n_out,
                             int kS, int dtype, void* stream);
 
+/* ---- Canny: back half -----------------------------------------------------------------------------
+ * Replaces the elementwise / fixed-kernel-convolution tail of canny (kornia/filters/canny.py:119-159) after the Gaussian blur and
+ * the Sobel derivatives (km_filter2d_sep_fwd, km_spatial_gradient_fwd).  fp32.
+ * km_canny_nms_fwd: magnitude sqrt(gx^2 + gy^2 + eps) (:120), direction binning (:123-127), non-maximum suppression against the two
+ *   neighbours along the gradient (:129-146, the 8 one-hot difference kernels of kornia/filters/kernels.py:943-976) and the two
+ *   thresholds (:149-153).   grads (B,2,H,W) = spatial_gradient's (B,1,2,H,W);  mag, edges (B,H,W) written (edges: 0 / 0.5 / 1).
+ * km_canny_hysteresis_sweep: the `while` loop of :156-176 (weak pixels touching strong ones are promoted until nothing changes) as
+ *   block-local fixed points: state (B,H,W) in place, out (B,H,W) = 1 where state is strong else 0 (rewritten by every sweep),
+ *   *changed (device int) OR-ed with 1 if a pixel was promoted - zero it, sweep, read it back, repeat while set. */
+int km_canny_nms_fwd(const void* grads, void* mag, void* edges, int B, int H, int W, double low, double high, double eps, void* stream);
+int km_canny_hysteresis_sweep(void* state, void* out, int* changed, int B, int H, int W, void* stream);
+
 /* ---- image pyramid ---------------------------------------------------------------------------
  * km_pyrdown_fwd replaces pyrdown (kornia/geometry/transform/pyramid.py:409-453): filter2d with the fixed 5x5
  * binomial kernel / 256 (:32-47) and border mode `border` (codes as km_filter2d_fwd), then

@@ -58,6 +58,8 @@ _PROTOTYPES = {
     "km_color_params_fwd": [_P] * 8 + [_I, _P],
     "km_color_jitter_bwd": [_P] * 10 + [_I] * 5 + [_P],
     "km_select_samples_fwd": [_P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P],
+    "km_canny_nms_fwd": [_P, _P, _P, _I, _I, _I, c_double, c_double, c_double, _P],
+    "km_canny_hysteresis_sweep": [_P, _P, _P, _I, _I, _I, _P],
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
     "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
 }

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import _native as N
 from ..core.check import KORNIA_CHECK, KORNIA_CHECK_IS_TENSOR, KORNIA_CHECK_SHAPE
 from .gaussian import gaussian_blur2d
 from .sobel import spatial_gradient
@@ -61,6 +62,9 @@ def canny(input: torch.Tensor, low_threshold: float = 0.1, high_threshold: float
 
     blurred = gaussian_blur2d(input, kernel_size, sigma)
     grads = spatial_gradient(blurred, normalized=False)
+    if dtype == torch.float32 and grads.is_cuda and not (torch.is_grad_enabled() and grads.requires_grad):
+        return _canny_tail_native(grads, low_threshold, high_threshold, hysteresis, eps)
+    # differentiable / half-precision calls: the same arithmetic as tensor expressions (autograd through the magnitude)
     gx, gy = grads[:, :, 0], grads[:, :, 1]
     magnitude = torch.sqrt(gx * gx + gy * gy + eps)
     direction = (torch.atan2(gy, gx) * (4 / math.pi)).round()  # -4 .. 4, multiples of 45 degrees
@@ -83,6 +87,32 @@ def canny(input: torch.Tensor, low_threshold: float = 0.1, high_threshold: float
             previous = edges.clone()
             edges = promoted + (promoted == 0) * weak * 0.5
         edges = promoted
+    return magnitude, edges
+
+
+def _canny_tail_native(grads: torch.Tensor, low: float, high: float, hysteresis: bool, eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """Magnitude, direction binning, suppression and thresholds in one launch (km_canny_nms_fwd); the hysteresis as sweeps of
+    block-local fixed points (km_canny_hysteresis_sweep), repeated until a sweep promotes nothing.  The reference's loop reads a
+    flag back once per promotion step (canny.py:160); this one once per sweep - a few per image whatever the edge length."""
+    B, _, _, H, W = grads.shape
+    grads = grads.contiguous()
+    lib = N.lib()
+    dev = grads.device
+    magnitude = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+    edges = torch.empty_like(magnitude)
+    with N.device_guard(dev):
+        stream = N.stream_ptr(dev)
+        N.check(lib.km_canny_nms_fwd(grads.data_ptr(), magnitude.data_ptr(), edges.data_ptr(), B, H, W, float(low), float(high), float(eps), stream),
+                "km_canny_nms_fwd")
+        if hysteresis:
+            out = torch.empty_like(edges)
+            flag = torch.zeros(1, device=dev, dtype=torch.int32)
+            while True:
+                N.check(lib.km_canny_hysteresis_sweep(edges.data_ptr(), out.data_ptr(), flag.data_ptr(), B, H, W, stream), "km_canny_hysteresis_sweep")
+                if int(flag.item()) == 0:
+                    break
+                flag.zero_()
+            edges = out
     return magnitude, edges
 
 

@@ -1,6 +1,7 @@
 """GPU: canny (kornia_amd/filters/canny.py) against the reference's outputs (tests/golden/canny.npz).  The front half runs on
-km_filter2d_sep_fwd + km_spatial_gradient_fwd; the rest is pointwise torch code.  Verified through the host build of the
-kernels (tests/test_emulated_kernels.py); the file sorts last because it has not been run on a device yet this round."""
+km_filter2d_sep_fwd + km_spatial_gradient_fwd, the back half on km_canny_nms_fwd + km_canny_hysteresis_sweep (fp32 without
+autograd; differentiable calls keep the tensor expressions).  Also run through the host build of the kernels
+(tests/test_emulated_kernels.py)."""
 import pytest
 import torch
 
@@ -73,3 +74,28 @@ def test_canny_known_answer_cross():
     nc = torch.rand(2, 3, 5, 5).cuda().expand(2, -1, -1, -1)[..., ::1]
     m, e = K.filters.canny(nc.transpose(2, 3))
     assert m.is_contiguous() and e.shape == (2, 1, 5, 5)
+
+
+@pytest.mark.parametrize("shape,hyst", [((2, 3, 70, 130), True), ((1, 1, 64, 64), True), ((2, 1, 33, 200), False)])
+def test_canny_native_tail_matches_the_tensor_expressions(shape, hyst):
+    """km_canny_nms_fwd + km_canny_hysteresis_sweep against the differentiable composition of the same arithmetic (taken when the
+    input requires grad): same magnitude where both keep a pixel, edge maps equal up to threshold crossings of 1-ulp differences, and the
+    hysteresis fixed point - long weak chains that cross tile borders included - is the same set of pixels."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(*shape, generator=g)
+    # smooth structure so that weak edges form chains: a few blurred blobs on top of the noise
+    yy, xx = torch.meshgrid(torch.arange(shape[2], dtype=torch.float32), torch.arange(shape[3], dtype=torch.float32), indexing="ij")
+    x = 0.15 * x + 0.85 * (torch.sin(xx / 9.0) * torch.cos(yy / 7.0))[None, None] * 0.5 + 0.4
+    xd = x.cuda()
+    mag_n, edges_n = K.filters.canny(xd, 0.05, 0.4, hysteresis=hyst)
+    mag_c, edges_c = K.filters.canny(xd.clone().requires_grad_(), 0.05, 0.4, hysteresis=hyst)
+    mag_c, edges_c = mag_c.detach(), edges_c.detach()
+    assert mag_n.shape == mag_c.shape and edges_n.shape == edges_c.shape
+    assert _agree(mag_n > 0, mag_c > 0) < 2e-3 and _agree(edges_n, edges_c) < 2e-3
+    keep = (mag_n > 0) & (mag_c > 0)
+    assert torch.allclose(mag_n[keep], mag_c[keep], atol=1e-6, rtol=0)
+    assert set(edges_n.unique().tolist()) <= ({0.0, 1.0} if hyst else {0.0, 0.5, 1.0})
+    if hyst:
+        assert edges_n.sum() > 0
