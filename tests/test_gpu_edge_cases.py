@@ -91,3 +91,35 @@ def test_mixed_dtypes_and_streams(oracle):
     y64 = K.gaussian_blur2d(K.warp_perspective(xc.double(), Mc.double(), (16, 18)), (5, 5), (1.5, 1.5))
     ref64 = oracle.gaussian_blur2d(oracle.warp_perspective(x.double(), M.double(), (16, 18)), (5, 5), (1.5, 1.5))
     assert y64.dtype == torch.float64 and torch.allclose(y64.cpu(), ref64, atol=1e-13)
+
+
+def test_batch_traversal_direction_does_not_change_results():
+    """km_set_traversal: consecutive launches of the streaming kernels walk the batch in alternating directions (a consumer starts on what
+    its producer left in the Infinity Cache).  A launch policy only: forward, blur and the image gradient are bit-identical whatever the
+    direction (the scatter accumulates integers), the matrix gradient - fp64 atomics in workgroup order - within 1e-12 relative."""
+    import kornia_amd as K
+    from kornia_amd import _native as N
+
+    lib = N.lib()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(5, 3, 96, 130, generator=g).cuda()
+    M = (torch.eye(3) + 0.02 * torch.randn(5, 3, 3, generator=g)).cuda()
+    M[:, 2, :2] *= 0.01
+    go = torch.rand(5, 3, 80, 112, generator=g).cuda()
+
+    def run():
+        xx, MM = x.clone().requires_grad_(), M.clone().requires_grad_()
+        y = K.filters.gaussian_blur2d(K.geometry.transform.warp_perspective(xx, MM, (80, 112)), (5, 5), (1.5, 1.5))
+        y.backward(go)
+        return y.detach(), xx.grad, MM.grad
+
+    prev = lib.km_set_traversal(1)  # fixed: every launch forward
+    try:
+        ref = run()
+        assert lib.km_set_traversal(0) == 1  # alternating (the default): two runs start with opposite parities at some launch
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            assert torch.allclose(got[2], ref[2], rtol=1e-6, atol=1e-9)
+    finally:
+        lib.km_set_traversal(prev)
