@@ -101,7 +101,7 @@ __device__ __forceinline__ uint16_t km_f32_to_bf16_bits(float f) {
 // Outputs are written once and read by the NEXT kernel, after ~0.8 GB of other traffic at the hot sizes: streaming (non-temporal)
 // stores keep them from displacing the lines the running kernel still needs in L2.  Measured on MI355X, config 2, same box: step
 // 1.798 -> 1.744 ms (forward 0.384 -> 0.370, blur 0.332 -> 0.319, blur adjoint 0.332 -> 0.323, scatter 0.398 -> 0.391 ms).
-// Non-temporal LOADS measured slower (blur 0.332 -> 0.35 ms).  -DKM_NO_NT_ST builds with plain stores (A/B).
+// Non-temporal LOADS measured slower (blur 0.332 -> 0.35 ms; grad_out in the scatter, which reads it once: step 1.64 -> 1.67 ms).  -DKM_NO_NT_ST builds with plain stores (A/B).
 #ifndef KM_NO_NT_ST
 #define KM_NT_ST 1
 #endif
