@@ -10,8 +10,9 @@ for spec in "$@"; do
   f=${spec%%:*}; fl=${spec#*:}
   IFS='|' read -ra FL <<< "$fl"
   hipcc $F "${FL[@]}" -c kornia_amd/csrc/$f.hip -o $d/$f.o &
+  pids="$pids $!"
 done
-wait
+for p in $pids; do wait $p || { echo "compile FAILED: no library written"; rm -rf $d; exit 1; }; done
 objs=""
 for o in kornia_amd/lib/obj/*.o; do b=$(basename $o); if [ -f $d/$b ]; then objs="$objs $d/$b"; else objs="$objs $o"; fi; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o kornia_amd/lib/var/lib_$tag.so $objs
