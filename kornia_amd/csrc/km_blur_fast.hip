@@ -17,6 +17,8 @@
 //
 // Requirements checked by the host: K odd, 3 <= K <= 9, kW == kH == K, 'same' padding, W % 4 == 0,
 // W >= 8, H >= K, 16-byte aligned planes.  Everything else takes the generic LDS kernel.
+#include <stdlib.h>
+
 #include "km_regtile.h"
 
 
@@ -25,6 +27,12 @@
 #else
 #define KMB_ROWS 32  // output rows per thread (strip height); measured at 256x3x512^2: 8 -> 0.32 ms, 16 -> 0.31, 32 -> 0.295, 64 -> 0.31
 #endif
+// A wave walks its strip row by row, so a launch with few waves per SIMD (BASELINE config 3's 256x3x224^2: 5376 strips of 32 rows on 1024
+// SIMDs) has little to overlap its row loads with.  For the 16-bit storage types such launches use strips of KMB_ROWS_SMALL rows - 4x the
+// waves, (8 + K - 1) / 8 instead of (32 + K - 1) / 32 input rows per output row, the extra ones L2 hits: bf16 256x3x224^2 56.2 -> 52.0 us.
+// fp32 does not gain (224^2: 53.5 -> 56.5 us, 64x3x512^2: 64 -> 78 us: twice the bytes per row, the halo re-reads cost more) and keeps 32.
+#define KMB_ROWS_SMALL 8
+#define KMB_SMALL_BELOW_WAVES 8192  // 8 waves per SIMD of the 32-row form
 
 template <typename T>
 struct KmVec4;
@@ -57,6 +65,7 @@ struct KmBlurArgs {
     uint32_t bx, by;     // blocks per plane in x / y
     uint32_t nblocks;
     uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
+    uint32_t small;      // strips of KMB_ROWS_SMALL rows (host-side choice of the instantiation)
 };
 
 // Adjoint taps along one axis for output position p:  w[d] multiplies the (zero-extended) gradient at
@@ -82,7 +91,7 @@ __device__ __forceinline__ void kmb_adjoint_taps(const float (&k)[K], int p, int
     }
 }
 
-template <typename T, int K, bool BWD>
+template <typename T, int K, bool BWD, int ROWS = KMB_ROWS>
 __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a) {
     constexpr int L = (K - 1) / 2, R = K - 1 - L;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     const uint32_t bc = bid / a.by;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx = (int)tbx * 64 + lane;                      // column group (4 px)
-    const int r0 = ((int)tby * 4 + wave) * KMB_ROWS;          // first output row of this thread's strip
+    const int r0 = ((int)tby * 4 + wave) * ROWS;              // first output row of this thread's strip
     if (gx >= (int)a.groups_x || r0 >= a.H) return;
     const int H = a.H, W = a.W, border = a.border;
     const int c0 = gx * 4;
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     if (right) offR = (border == KM_BORDER_CIRCULAR) ? 0 : c0;
 
     float ring[K][4];  // rolling window of row-pass results
-    const int n_rows = (r0 + KMB_ROWS <= H ? KMB_ROWS : H - r0);
+    const int n_rows = (r0 + ROWS <= H ? ROWS : H - r0);
     const int total = n_rows + K - 1;
 
     for (int it0 = 0; it0 < total; it0 += K) {
@@ -223,7 +232,14 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
 
 template <typename T, int K>
 static int km_blur_launch(bool bwd, const KmBlurArgs<T>& a, hipStream_t s) {
-    if (bwd)
+    if (a.small) {
+        if constexpr (sizeof(T) == 2) {  // (the caller sets `small` for the 16-bit types only)
+            if (bwd)
+                hipLaunchKernelGGL((km_blur_reg_kernel<T, K, true, KMB_ROWS_SMALL>), dim3(a.nblocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((km_blur_reg_kernel<T, K, false, KMB_ROWS_SMALL>), dim3(a.nblocks), dim3(256), 0, s, a);
+        }
+    } else if (bwd)
         hipLaunchKernelGGL((km_blur_reg_kernel<T, K, true>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((km_blur_reg_kernel<T, K, false>), dim3(a.nblocks), dim3(256), 0, s, a);
@@ -238,7 +254,12 @@ static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, 
     a.C = C; a.H = H; a.W = W; a.Bk = Bk; a.border = border;
     a.groups_x = (uint32_t)(W / 4);
     a.bx = (a.groups_x + 63) / 64;
-    a.by = (uint32_t)((H + 4 * KMB_ROWS - 1) / (4 * KMB_ROWS));
+    const char* fr = getenv("KM_BLUR_ROWS");  // 8 / 32: forces the instantiation (tests, A/B timing); read per call so that a test can switch it
+    const int force_rows = fr ? atoi(fr) : 0;
+    const uint64_t waves_big = (uint64_t)a.bx * (uint64_t)((H + KMB_ROWS - 1) / KMB_ROWS) * (uint64_t)B * C;
+    a.small = sizeof(T) != 2 ? 0u : (force_rows ? (force_rows == KMB_ROWS_SMALL ? 1u : 0u) : (waves_big < KMB_SMALL_BELOW_WAVES ? 1u : 0u));
+    const int rows = a.small ? KMB_ROWS_SMALL : KMB_ROWS;
+    a.by = (uint32_t)((H + 4 * rows - 1) / (4 * rows));
     const uint64_t nb = (uint64_t)a.bx * a.by * (uint64_t)B * C;
     KM_REQUIRE(nb < (1ull << 31), "km_blur: grid too large");
     a.nblocks = (uint32_t)nb;

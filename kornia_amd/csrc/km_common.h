@@ -92,12 +92,31 @@ __device__ __forceinline__ double km_ld(const double* p) { return *p; }
 __device__ __forceinline__ float km_ld(const km_bf16* p) { return __uint_as_float(((uint32_t)p->bits) << 16); }
 __device__ __forceinline__ float km_ld(const km_f16* p) { return (float)(*p); }
 
-__device__ __forceinline__ uint16_t km_f32_to_bf16_bits(float f) {
+// float -> bfloat16, round to nearest even, NaN stays a quiet NaN.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two
+// values per instruction: what `(__bf16)f` compiles to in the device pass); everywhere else - the host pass, the host build of the
+// kernels under tests/emu - the same rounding in integer arithmetic (5 instructions per value).  Measured on the bf16 blur of
+// BASELINE config 3 (256x3x224^2): see DESIGN.md.
+__device__ __forceinline__ uint16_t km_f32_to_bf16_bits_sw(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
     return (uint16_t)(u >> 16);
 }
+#if defined(__gfx950__)
+__device__ __forceinline__ uint16_t km_f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+// (lo, hi) -> one 32-bit word of two bfloat16, lo in the low half
+__device__ __forceinline__ uint32_t km_f32x2_to_bf16x2_bits(float lo, float hi) {
+    typedef __bf16 km_bf2v __attribute__((ext_vector_type(2)));
+    typedef float km_f2v_ __attribute__((ext_vector_type(2)));
+    km_f2v_ v; v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, km_bf2v));
+}
+#else
+__device__ __forceinline__ uint16_t km_f32_to_bf16_bits(float f) { return km_f32_to_bf16_bits_sw(f); }
+__device__ __forceinline__ uint32_t km_f32x2_to_bf16x2_bits(float lo, float hi) {
+    return (uint32_t)km_f32_to_bf16_bits_sw(lo) | ((uint32_t)km_f32_to_bf16_bits_sw(hi) << 16);
+}
+#endif
 // Outputs are written once and read by the NEXT kernel, after ~0.8 GB of other traffic at the hot sizes: streaming (non-temporal)
 // stores keep them from displacing the lines the running kernel still needs in L2.  Measured on MI355X, config 2, same box: step
 // 1.798 -> 1.744 ms (forward 0.384 -> 0.370, blur 0.332 -> 0.319, blur adjoint 0.332 -> 0.323, scatter 0.398 -> 0.391 ms).

@@ -51,8 +51,8 @@ __device__ __forceinline__ void km_st4(float* p, const float (&o)[4]) {
 }
 __device__ __forceinline__ void km_st4(km_bf16* p, const float (&o)[4]) {
     uint2 v;
-    v.x = (uint32_t)km_f32_to_bf16_bits(o[0]) | ((uint32_t)km_f32_to_bf16_bits(o[1]) << 16);
-    v.y = (uint32_t)km_f32_to_bf16_bits(o[2]) | ((uint32_t)km_f32_to_bf16_bits(o[3]) << 16);
+    v.x = km_f32x2_to_bf16x2_bits(o[0], o[1]);
+    v.y = km_f32x2_to_bf16x2_bits(o[2], o[3]);
     KM_CHECK_ALIGNED(p, 8);
 #ifdef KM_NT_ST
     typedef uint32_t km_u2v __attribute__((ext_vector_type(2)));
@@ -87,9 +87,9 @@ __device__ __forceinline__ void km_st2(float* p, float a, float b) {
 __device__ __forceinline__ void km_st2(km_bf16* p, float a, float b) {
     KM_CHECK_ALIGNED(p, 4);
 #ifdef KM_NT_ST
-    __builtin_nontemporal_store((uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16), reinterpret_cast<uint32_t*>(p));
+    __builtin_nontemporal_store(km_f32x2_to_bf16x2_bits(a, b), reinterpret_cast<uint32_t*>(p));
 #else
-    *reinterpret_cast<uint32_t*>(p) = (uint32_t)km_f32_to_bf16_bits(a) | ((uint32_t)km_f32_to_bf16_bits(b) << 16);
+    *reinterpret_cast<uint32_t*>(p) = km_f32x2_to_bf16x2_bits(a, b);
 #endif
 }
 __device__ __forceinline__ void km_st2(km_f16* p, float a, float b) {
