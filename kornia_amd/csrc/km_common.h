@@ -158,8 +158,10 @@ __device__ __forceinline__ void km_ld2(const km_bf16* p, float& a, float& b) {
     const km_u16x2_u v = *reinterpret_cast<const km_u16x2_u*>(p);
     a = __uint_as_float(((uint32_t)v.x) << 16); b = __uint_as_float(((uint32_t)v.y) << 16);
 }
+struct __attribute__((packed, aligned(2))) km_h16x2_u { km_f16 x, y; };
 __device__ __forceinline__ void km_ld2(const km_f16* p, float& a, float& b) {
-    a = (float)p[0]; b = (float)p[1];
+    const km_h16x2_u v = *reinterpret_cast<const km_h16x2_u*>(p);  // one 4-byte request, like the bf16 pair
+    a = (float)v.x; b = (float)v.y;
 }
 
 // four horizontally adjacent pixels with one load (element-aligned address), for the bicubic taps

@@ -374,28 +374,42 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
         // shape of a copy - 0.324; identity / pure translation matrices 0.355 - 0.366: the floor of a lane-per-pixel tile copy is ~0.32.
         // Rows per thread 2 / 3 / 4 (62 / 80 / 94 registers, 8 / 6 / 5 waves per SIMD): 0.381 / 0.389 / 0.389 - occupancy is not it.)
         float v[KM_ROWS][NCC][4];
-        bool nb[KM_ROWS];
+        if constexpr (sizeof(T) == 2) {
+            // 16-bit storage: (x0, x0 + 1) IS one 4-byte request - the cheapest class the memory pipeline has - so every lane loads its own
+            // pair and there is neither a neighbour exchange nor a fallback load (config 3's rotated 224^2 bf16 images: 108 -> see DESIGN.md)
 #pragma unroll
-        for (int r = 0; r < KM_ROWS; ++r) {
-            const uint32_t off = (uint32_t)__mul24((int)t[r].yf, W) + (uint32_t)(int)t[r].xf;
-            nb[r] = (km_next64(off) == off + 1u);  // (lane 63 reads itself: false; lane 31's neighbour is on another row: false)
+            for (int r = 0; r < KM_ROWS; ++r) {
+                const uint32_t off = (uint32_t)__mul24((int)t[r].yf, W) + (uint32_t)(int)t[r].xf;
 #pragma unroll
-            for (int c = 0; c < NCC; ++c) {
-                v[r][c][0] = (float)km_ld(km_at(sp[c], off));
-                v[r][c][2] = (float)km_ld(km_at(sp[c], off + (uint32_t)W));
-                if (!nb[r]) {
-                    v[r][c][1] = (float)km_ld(km_at(sp[c], off + 1u));
-                    v[r][c][3] = (float)km_ld(km_at(sp[c], off + (uint32_t)W + 1u));
+                for (int c = 0; c < NCC; ++c) {
+                    km_ld2(km_at(sp[c], off), v[r][c][0], v[r][c][1]);
+                    km_ld2(km_at(sp[c], off + (uint32_t)W), v[r][c][2], v[r][c][3]);
                 }
             }
-        }
+        } else {
+            bool nb[KM_ROWS];
 #pragma unroll
-        for (int r = 0; r < KM_ROWS; ++r)
+            for (int r = 0; r < KM_ROWS; ++r) {
+                const uint32_t off = (uint32_t)__mul24((int)t[r].yf, W) + (uint32_t)(int)t[r].xf;
+                nb[r] = (km_next64(off) == off + 1u);  // (lane 63 reads itself: false; lane 31's neighbour is on another row: false)
 #pragma unroll
-            for (int c = 0; c < NCC; ++c) {
-                const float n0 = km_next64(v[r][c][0]), n2 = km_next64(v[r][c][2]);
-                if (nb[r]) { v[r][c][1] = n0; v[r][c][3] = n2; }
+                for (int c = 0; c < NCC; ++c) {
+                    v[r][c][0] = (float)km_ld(km_at(sp[c], off));
+                    v[r][c][2] = (float)km_ld(km_at(sp[c], off + (uint32_t)W));
+                    if (!nb[r]) {
+                        v[r][c][1] = (float)km_ld(km_at(sp[c], off + 1u));
+                        v[r][c][3] = (float)km_ld(km_at(sp[c], off + (uint32_t)W + 1u));
+                    }
+                }
             }
+#pragma unroll
+            for (int r = 0; r < KM_ROWS; ++r)
+#pragma unroll
+                for (int c = 0; c < NCC; ++c) {
+                    const float n0 = km_next64(v[r][c][0]), n2 = km_next64(v[r][c][2]);
+                    if (nb[r]) { v[r][c][1] = n0; v[r][c][3] = n2; }
+                }
+        }
 #pragma unroll
         for (int r = 0; r < KM_ROWS; ++r) {
             const float w00 = t[r].wx1 * t[r].wy1, w01 = t[r].wx0 * t[r].wy1, w10 = t[r].wx1 * t[r].wy0, w11 = t[r].wx0 * t[r].wy0;
