@@ -99,3 +99,48 @@ def test_canny_native_tail_matches_the_tensor_expressions(shape, hyst):
     assert set(edges_n.unique().tolist()) <= ({0.0, 1.0} if hyst else {0.0, 0.5, 1.0})
     if hyst:
         assert edges_n.sum() > 0
+
+
+def test_hysteresis_sweeps_follow_a_chain_across_tiles():
+    """km_canny_hysteresis_sweep on a hand-made state: a weak serpentine that crosses the 64 x 64 tile grid many times with ONE strong
+    seed at its end must be promoted completely (several sweeps: a sweep carries a promotion only as far as tiles that were already
+    consistent), an isolated weak segment must be dropped, and the result must equal the reference's pixel-by-pixel loop."""
+    from kornia_amd import _native as N
+
+    lib = N.lib()
+    H, W = 150, 200
+    state = torch.zeros(1, 1, H, W)
+    # serpentine: horizontal runs every 6 rows joined at alternating ends
+    rows = list(range(3, H - 3, 6))
+    for k, r in enumerate(rows):
+        state[0, 0, r, 5:W - 5] = 0.5
+        if k + 1 < len(rows):
+            c = W - 6 if k % 2 == 0 else 5
+            state[0, 0, r:rows[k + 1] + 1, c] = 0.5
+    state[0, 0, rows[-1], 5 if len(rows) % 2 == 0 else W - 6] = 1.0  # the seed, at the far end of the chain
+    state[0, 0, 1, 20:40] = 0.5  # touches nothing strong (two rows above the first run)
+    # the reference's loop (kornia/filters/canny.py:156-176) on the host
+    ref = state.clone()
+    while True:
+        strong = ref == 1
+        grown = torch.nn.functional.max_pool2d(strong.float(), 3, 1, 1) > 0
+        new = torch.where((ref == 0.5) & grown, torch.ones_like(ref), ref)
+        if torch.equal(new, ref):
+            break
+        ref = new
+    want = (ref == 1).float()
+    assert want.sum() > (W - 10) * len(rows)  # the whole chain
+
+    st = state.cuda().contiguous()
+    out = torch.empty_like(st)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sweeps = 0
+    while True:
+        N.check(lib.km_canny_hysteresis_sweep(st.data_ptr(), out.data_ptr(), flag.data_ptr(), 1, H, W, N.stream_ptr(st.device)), "sweep")
+        sweeps += 1
+        if int(flag.item()) == 0:
+            break
+        flag.zero_()
+        assert sweeps < 200
+    assert torch.equal(out.cpu(), want)
+    assert 2 <= sweeps <= 2 + len(rows) * 4  # more than one sweep (the chain crosses tiles), far fewer than one per pixel of its length
