@@ -39,6 +39,9 @@ _NATIVE = {
     "kornia.filters.filter": {"filter2d": _f.filter2d, "filter2d_separable": _f.filter2d_separable},
     "kornia.filters.gaussian": {"gaussian_blur2d": _f.gaussian_blur2d},
     "kornia.filters.sobel": {"spatial_gradient": _f.spatial_gradient, "sobel": _f.sobel},
+    # blur + Sobel were already native through the two entries above; this one also replaces the ~25 elementwise / fixed-kernel
+    # convolution launches and the host-synchronised hysteresis loop behind them (km_canny_nms_fwd, km_canny_hysteresis_sweep)
+    "kornia.filters.canny": {"canny": _f.canny},
     # fused colour kernels (the ColorJitter leg)
     "kornia.enhance.adjust": {
         "adjust_brightness_accumulative": _e.adjust_brightness_accumulative,
