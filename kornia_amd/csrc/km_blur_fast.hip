@@ -66,6 +66,7 @@ struct KmBlurArgs {
     uint32_t nblocks;
     uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
     uint32_t small;      // strips of KMB_ROWS_SMALL rows (host-side choice of the instantiation)
+    uint32_t stream_out; // streaming stores (km_stream_stores)
 };
 
 // Adjoint taps along one axis for output position p:  w[d] multiplies the (zero-extended) gradient at
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
                             res[o] = acc;
                         }
                     }
-                    km_st4(out + (size_t)r * W + c0, res);
+                    km_st4_pol(out + (size_t)r * W + c0, res, a.stream_out != 0u);
                 }
             }
         }
@@ -265,6 +266,7 @@ static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, 
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
     a.reverse = km_traversal_next();
+    a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(T));
     switch (K) {
         case 3: return km_blur_launch<T, 3>(bwd, a, s);
         case 5: return km_blur_launch<T, 5>(bwd, a, s);

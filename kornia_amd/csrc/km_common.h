@@ -129,9 +129,28 @@ __device__ __forceinline__ void km_st(float* p, float v) { __builtin_nontemporal
 #else
 __device__ __forceinline__ void km_st(float* p, float v) { *p = v; }
 #endif
+// The three kernels of the hot step choose per launch: an output that fits in the 256 MB Infinity Cache with room to spare is what the next
+// kernel will find there, and streaming it out costs that (config 2 at B = 16, 50 MB tensors: step 0.152 ms with plain stores, 0.166 ms with
+// streaming ones; B = 64, 201 MB: 0.486 / 0.478; B = 256, 805 MB: 1.74 / 1.69).  stream = km_stream_stores(bytes of the output), wave-uniform.
+#define KM_STREAM_MIN_BYTES (128ull << 20)
+static inline uint32_t km_stream_stores(uint64_t out_bytes) {
+#ifdef KM_NT_ST
+    return out_bytes >= KM_STREAM_MIN_BYTES ? 1u : 0u;
+#else
+    (void)out_bytes;
+    return 0u;
+#endif
+}
+__device__ __forceinline__ void km_st_pol(float* p, float v, bool stream) {
+    if (stream) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 __device__ __forceinline__ void km_st(double* p, double v) { *p = v; }
 __device__ __forceinline__ void km_st(km_bf16* p, float v) { p->bits = km_f32_to_bf16_bits(v); }
 __device__ __forceinline__ void km_st(km_f16* p, float v) { *p = (km_f16)v; }
+__device__ __forceinline__ void km_st_pol(double* p, double v, bool) { *p = v; }
+__device__ __forceinline__ void km_st_pol(km_bf16* p, float v, bool) { km_st(p, v); }  // (2-byte stores: no streaming form worth having)
+__device__ __forceinline__ void km_st_pol(km_f16* p, float v, bool) { km_st(p, v); }
 
 // a compute-precision value as the storage dtype T would hold it (used where the reference materialises an intermediate)
 __device__ __forceinline__ float km_round_as(float v, const float*) { return v; }

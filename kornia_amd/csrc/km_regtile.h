@@ -73,6 +73,28 @@ __device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
     *reinterpret_cast<h4*>(p) = v;
 #endif
 }
+// km_st4 with the store policy chosen per launch (km_stream_stores): streaming or plain
+__device__ __forceinline__ void km_st4_pol(float* p, const float (&o)[4], bool stream) {
+    if (stream) { km_st4(p, o); return; }
+    KM_CHECK_ALIGNED(p, 16);
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void km_st4_pol(km_bf16* p, const float (&o)[4], bool stream) {
+    if (stream) { km_st4(p, o); return; }
+    uint2 v;
+    v.x = km_f32x2_to_bf16x2_bits(o[0], o[1]);
+    v.y = km_f32x2_to_bf16x2_bits(o[2], o[3]);
+    KM_CHECK_ALIGNED(p, 8);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void km_st4_pol(km_f16* p, const float (&o)[4], bool stream) {
+    if (stream) { km_st4(p, o); return; }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 v;
+    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    KM_CHECK_ALIGNED(p, 8);
+    *reinterpret_cast<h4*>(p) = v;
+}
 // two adjacent pixels with one 8-byte / 4-byte store
 __device__ __forceinline__ void km_st2(float* p, float a, float b) {
     KM_CHECK_ALIGNED(p, 8);

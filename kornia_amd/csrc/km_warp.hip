@@ -417,7 +417,7 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
                 const float acc = km_fma(v[r][c][3], w11, km_fma(v[r][c][2], w10, km_fma(v[r][c][1], w01, km_fma(v[r][c][0], w00, 0.0f))));
-                km_st(km_at_mut(dp[c], oo), acc);
+                km_st_pol(km_at_mut(dp[c], oo), acc, a.stream_out != 0u);
             }
         }
         return;
@@ -811,6 +811,7 @@ static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
     a.tiles_y = (uint32_t)((a.g.h + KML_TILE_H - 1) / KML_TILE_H);
     a.nblocks = a.tiles_x * a.tiles_y * (uint32_t)a.g.B;  // (<= the 64 x 16 grid the caller checked)
     a.reverse = km_traversal_next();
+    a.stream_out = km_stream_stores((uint64_t)a.g.B * a.g.C * a.g.h * a.g.w * sizeof(T));
     if (a.g.align)
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
     else
@@ -900,6 +901,7 @@ static int km_warp_run(bool bwd, const void* src, const void* mat, void* dst, co
     KM_REQUIRE(nb < (1ull << 31), "km_warp2d: grid too large (%llu blocks)", (unsigned long long)nb);
     a.nblocks = (uint32_t)nb;
     a.reverse = 0;
+    a.stream_out = 0;
     if (nb == 0) return 0;
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return km_warp_dispatch_interp<T, KM_COORD_PERSPECTIVE>(bwd, a, s);

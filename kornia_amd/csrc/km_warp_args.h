@@ -19,6 +19,7 @@ struct KmWarpArgs {
     KmWarpGeom<R> g;
     uint32_t tiles_x, tiles_y, nblocks;
     uint32_t reverse;  // lean forward only: the XCDs walk their block ranges backwards (km_traversal_next)
+    uint32_t stream_out;  // lean forward only: streaming stores (km_stream_stores)
 };
 
 // The per-sample probability blend of the augmentation layer (kornia/augmentation/base.py:348-393) folded into the forward: a

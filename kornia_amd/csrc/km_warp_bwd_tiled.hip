@@ -62,6 +62,7 @@ struct KmWarpTiledArgs {
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, nblocks;
     uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
+    uint32_t stream_out; // streaming stores of the tile flush (km_stream_stores)
 };
 
 // [host-testable begin: tile_box]  (tests/test_tile_box_spec.py compiles this span for the host with g++)
@@ -586,15 +587,13 @@ __device__ __forceinline__ void kmt_tile_chunk(const KmWarpTiledArgs<T>& a, cons
                 } else {
                     v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
                 }
-#ifdef KM_NT_ST
-                {
+                if (a.stream_out) {
                     typedef float km_f4v __attribute__((ext_vector_type(4)));
                     km_f4v vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
                     __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v*>(outp));
+                } else {
+                    *reinterpret_cast<float4*>(outp) = v;
                 }
-#else
-                *reinterpret_cast<float4*>(outp) = v;
-#endif
                 outp += ostep;
                 accp += (KMT_NT / 16) * KMT_TW;
             }
@@ -705,6 +704,7 @@ static int kmt_run(const void* gout, const void* mat, void* gsrc, int B, int C, 
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
     a.reverse = km_traversal_next();
+    a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(float));
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmt_launch<T, KM_COORD_PERSPECTIVE>(a, s);
         case KM_COORD_AFFINE: return kmt_launch<T, KM_COORD_AFFINE>(a, s);
