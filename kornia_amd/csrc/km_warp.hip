@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
 // A wave instruction covers a KM_PATCH_W x (64 / KM_PATCH_W) patch of the output rather than a 64 x 1 row: under rotation
 // the taps of a 64 x 1 row are spread over up to 64 sin(angle) source rows (one cache line each), a squarer patch keeps
 // them within ~(PW sin + PH cos) rows.  Stores stay KM_PATCH_W * 4-byte contiguous runs.
-template <typename T, int CM, int NC, int ALIGN, bool FAST, int PH = 64 / KM_PATCH_W>  // PH: tile rows between a thread's consecutive rows
+template <typename T, int CM, int NC, int ALIGN, bool FAST, int PH = 64 / KM_PATCH_W, bool STREAM = true>  // PH: tile rows between a thread's consecutive rows
 __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, const float (&m)[9], const float4* s_rv, uint32_t b, int j, int li_base,
                                                       int i_base) {
     const KmWarpGeom<float>& g = a.g;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
                 const float acc = km_fma(v[r][c][3], w11, km_fma(v[r][c][2], w10, km_fma(v[r][c][1], w01, km_fma(v[r][c][0], w00, 0.0f))));
-                km_st_pol(km_at_mut(dp[c], oo), acc, a.stream_out != 0u);
+                km_st_pol(km_at_mut(dp[c], oo), acc, STREAM);  // (compile-time: a run-time policy test at each of the 12 stores cost 4 % of the kernel)
             }
         }
         return;
@@ -509,8 +509,14 @@ __global__ KML_BOUNDS void km_warp_fwd_lean_kernel(const KmWarpArgs<T> a) {
     for (int gr = 0; gr < KML_GROUPS; ++gr) {
         const int ib = i_base + gr * KM_TILE_H;
         if ((int)ty * KML_TILE_H + gr * KM_TILE_H >= g.h) break;  // block-uniform: the group lies below the image
-        if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
-        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+        constexpr int PH_ = 64 / KM_PATCH_W;
+        if (a.stream_out) {  // (kernel-uniform) streaming stores for outputs of km_stream_stores' size, plain ones below
+            if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, PH_, true>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+            else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, PH_, true>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+        } else {
+            if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, PH_, false>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+            else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, PH_, false>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, ib);
+        }
     }
 }
 
