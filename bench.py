@@ -38,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (measured streaming copy on these boxes: 6.2 TB/s)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+if not os.path.exists(PMC_FILE):
+    PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse_args():
@@ -55,6 +57,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip other_configs / generic_gpu (profiling runs)")
     p.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU baseline sample")
+    p.add_argument("--input-sets", type=int, default=3,
+                   help="distinct (x, M, grad_out) sets rotated through the timed loop: a training loop feeds a new batch every step, so "
+                        "nothing of step k's inputs may be found in the 256 MB Infinity Cache by step k+1 (1 = one set, reported beside it)")
     return p.parse_args()
 
 
@@ -125,8 +130,15 @@ def kernel_roofline(x, M, go, size, iters):
     def warp_bwd_gmat():  # forward-shaped reduction: grad wrt the homography
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), None, gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wm")
 
-    def warp_bwd():  # the public op = both launches back to back
+    def warp_bwd_two():  # both gradients as two launches (each reads grad_out): the form without a workspace
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
+
+    ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, 1, 0, 0))
+    ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+
+    def warp_bwd():  # the public op as the Python layer calls it: with a workspace, both gradients from one read of grad_out
+        N.check(lib.km_warp2d_bwd_ws(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0,
+                                     ws.data_ptr() if ws_bytes else None, ws_bytes, stream), "wb")
 
     # per LAUNCH: the bytes that launch itself must move (every tensor it reads once + every tensor it writes once); the two
     # backward launches both read grad_out, so their sum (4e) exceeds the op's algorithmic 3e - which is why the op line exists
@@ -142,6 +154,7 @@ def kernel_roofline(x, M, go, size, iters):
         ("km_blur_reg_kernel<bwd>", blur_bwd, 2 * e * n_el, "read grad_y, write grad_x"),
         ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el, "read grad_out, write grad_src"),
         ("km_warp_gm_kernel", warp_bwd_gmat, 2 * e * n_el, "read grad_out, read src"),
+        ("km_warp_bwd_fused_kernel (+ boxes, general)", warp_bwd, 3 * e * n_el, "read grad_out, read src, write grad_src"),
     ):
         ms = event_time_ms(fn, iters)
         kernels[name] = {"ms": round(ms, 4), "launch_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "moves": what}
@@ -157,6 +170,8 @@ def kernel_roofline(x, M, go, size, iters):
         nbytes = mult * e * n_el
         ops[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
     ops["km_warp2d_bwd"]["ms_fixed_traversal"] = round(bwd_fixed_ms, 4)
+    ops["km_warp2d_bwd"]["form"] = "one read of grad_out (km_warp2d_bwd_ws with a workspace)" if ws_bytes and lib.km_config_get(b"warp_bwd_fused") == 1 else "two launches"
+    ops["km_warp2d_bwd"]["ms_two_launches"] = round(event_time_ms(warp_bwd_two, iters), 4)
     return kernels, ops
 
 
@@ -226,6 +241,10 @@ def other_configs(dev):
     def t(fn, n=10):
         return round(event_time_ms(fn, n), 4)
 
+    def roof(ms, alg_bytes):
+        """SURVEY.md 8(d) algorithmic bytes of the public ops in the timed sequence / time, as GB/s and fraction of the 8 TB/s HBM peak"""
+        return {"ms": ms, "alg_bytes": int(alg_bytes), "GBps": round(alg_bytes / ms / 1e6, 1), "frac_of_hbm_peak": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
     try:  # config 3: 256 images per GPU, bf16, RandomAffine + ColorJitter + RandomGaussianBlur with device-resident parameters (p = 1)
         with torch.no_grad():
             B = 256
@@ -246,6 +265,8 @@ def other_configs(dev):
             w = K.warp_affine(x, M[:, :2], (224, 224), align_corners=False)
             c = A.color_jitter(w, Pj, order)
             out["cfg3_bf16_256x3x224_eager_ms"] = t(lambda: seq(x, Pa, Pj, Pb))
+            # 3 public ops x 2e, e = 2 bytes (0.462 GB per GPU)
+            out["cfg3_roofline"] = roof(out["cfg3_bf16_256x3x224_eager_ms"], 3 * 2 * 2 * x.numel())
             out["cfg3_breakdown_ms"] = {
                 "affine_matrix": t(lambda: A.affine_matrix(Pa, dev)), "warp_affine": t(lambda: K.warp_affine(x, M[:, :2], (224, 224), align_corners=False)),
                 "color_jitter": t(lambda: A.color_jitter(w, Pj, order)), "gaussian_blur(per-sample sigma)": t(lambda: A.random_gaussian_blur(c, Pb))}
@@ -259,6 +280,8 @@ def other_configs(dev):
             R = K.get_rotation_matrix2d(torch.tensor([[959.5, 539.5]], device=dev).repeat(64, 1), torch.full((64,), 2.0, device=dev), torch.ones(64, 2, device=dev))
             out["cfg4_64x1x1080x1920_spatial_gradient_ms"] = t(lambda: K.spatial_gradient(x))
             out["cfg4_64x1x1080x1920_warp_affine_bicubic_ms"] = t(lambda: K.warp_affine(x, R, (1080, 1920), mode="bicubic"))
+            out["cfg4_roofline"] = {"spatial_gradient (3e)": roof(out["cfg4_64x1x1080x1920_spatial_gradient_ms"], 3 * 4 * x.numel()),
+                                    "warp_affine bicubic (2e)": roof(out["cfg4_64x1x1080x1920_warp_affine_bicubic_ms"], 2 * 4 * x.numel())}
             del x
         x = torch.rand(128, 3, 256, 256, device=dev)
         H = (torch.eye(3, device=dev)[None] + 0.01 * torch.randn(128, 3, 3, device=dev)).requires_grad_()
@@ -269,6 +292,8 @@ def other_configs(dev):
             return gh
 
         out["cfg5_128x3x256x256_l1(homography_warp)+gradH_eager_ms"] = t(lambda: learn_h(x, H, tgt))
+        # homography_warp 2e forward + 2e backward wrt H only (0.403 GB per GPU); the loss itself is outside the path
+        out["cfg5_roofline"] = roof(out["cfg5_128x3x256x256_l1(homography_warp)+gradH_eager_ms"], 4 * 4 * x.numel())
         gstep = K.graph.capture(learn_h, x, H, tgt)
         out["cfg5_128x3x256x256_l1(homography_warp)+gradH_hip_graph_replay_ms"] = t(gstep.replay)
         T = K.geometry.transform
@@ -279,12 +304,15 @@ def other_configs(dev):
 
         out["cfg5_128x3x256x256_fused_loss+gradH_one_launch_eager_ms"] = t(lambda: fused(x, H, tgt))
         out["cfg5_128x3x256x256_fused_loss+gradH_one_launch_hip_graph_replay_ms"] = t(K.graph.capture(fused, x, H, tgt).replay)
-        # transform_points at config 5's grid size (512 x 65536 x 2 is one GPU's share of warp_grid): 2e bytes per coordinate
-        P = torch.rand(512, 65536, 2, device=dev)
-        Tm = torch.eye(3, device=dev)[None].repeat(512, 1, 1) + 0.01 * torch.randn(512, 3, 3, device=dev)
+        # the fused op is another public op (masked_warp_loss, the ImageRegistrator's level loss): reads image and target once = 2e
+        out["cfg5_fused_loss_roofline"] = roof(out["cfg5_128x3x256x256_fused_loss+gradH_one_launch_eager_ms"], 2 * 4 * x.numel())
+        # transform_points well beyond the 256 MB Infinity Cache: 2048 x 65536 x 2 fp32 = 1.07 GB in, 1.07 GB out (2e bytes per coordinate),
+        # a fresh output every call; profiles/r03_transform_points_* hold the rocprofv3 kernel stats and FETCH / WRITE sizes of this loop
+        P = torch.rand(2048, 65536, 2, device=dev)
+        Tm = torch.eye(3, device=dev)[None].repeat(2048, 1, 1) + 0.01 * torch.randn(2048, 3, 3, device=dev)
         with torch.no_grad():
             ms = event_time_ms(lambda: K.transform_points(Tm, P), 10)
-        out["transform_points_512x65536x2"] = {"ms": round(ms, 4), "GBps": round(2 * P.numel() * 4 / ms / 1e6, 1), "mfma": "not used: K = 3 contraction, 15 flop per 16 bytes (profiles/README.md)"}
+        out["transform_points_2048x65536x2"] = {**roof(round(ms, 4), 2 * P.numel() * 4), "mfma": "not used: K = 3 contraction, 15 flop per 16 bytes (profiles/README.md)"}
         del P
     except Exception as e:
         out["error_cfg45"] = f"{type(e).__name__}: {e}"
@@ -399,15 +427,22 @@ def main():
         B, global_batch = args.batch, world * args.batch
     gen = torch.Generator().manual_seed(1000 * rank)
     ggen = torch.Generator(device=dev).manual_seed(1000 * rank)
-    x = torch.rand(B, C, S, S, device=dev, generator=ggen).requires_grad_()
-    M = flagship_homographies(B, S, S, gen).to(dev).requires_grad_()
-    go = torch.rand(B, C, S, S, device=dev, generator=ggen)
+    n_sets = max(1, args.input_sets)
+    sets = []
+    for _ in range(n_sets):
+        sets.append((torch.rand(B, C, S, S, device=dev, generator=ggen).requires_grad_(), flagship_homographies(B, S, S, gen).to(dev).requires_grad_(),
+                     torch.rand(B, C, S, S, device=dev, generator=ggen)))
+    x, M, go = sets[0]
+    counter = [0]
 
-    def step():
-        x.grad = None
-        M.grad = None
-        y = K.gaussian_blur2d(K.warp_perspective(x, M, (S, S)), (5, 5), (1.5, 1.5))
-        y.backward(go)
+    def step(fixed_set=None):
+        # every step works on the NEXT input set: step k+1 cannot start on what step k left in the Infinity Cache
+        xs, Ms, gos = sets[(counter[0] % n_sets) if fixed_set is None else fixed_set]
+        counter[0] += 1
+        xs.grad = None
+        Ms.grad = None
+        y = K.gaussian_blur2d(K.warp_perspective(xs, Ms, (S, S)), (5, 5), (1.5, 1.5))
+        y.backward(gos)
         return y
 
     def barrier():
@@ -446,6 +481,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # informational: the same loop over ONE input set (what rounds 1-2 timed; cross-step reuse of x in the Infinity Cache included)
+    single_ms = None
+    if n_sets > 1 and world == 1:
+        for _ in range(3):
+            step(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(0)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,7 +548,8 @@ def main():
         traffic = None
         if (B, C, S) == (256, 3, 512) and os.path.exists(PMC_FILE):
             pmc = json.load(open(PMC_FILE)).get("kernels", {})
-            want = {"km_warp2d_bwd": ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_lean_kernel",),
+            fused = "one read" in ops["km_warp2d_bwd"].get("form", "")
+            want = {"km_warp2d_bwd": ("km_warp_bwd_fused_kernel",) if fused else ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_lean_kernel",),
                     "km_filter2d_sep_fwd": ("km_blur_reg_kernel<float, 5, false>",), "km_filter2d_sep_bwd_input": ("km_blur_reg_kernel<float, 5, true>",)}[dom_op]
             tot = 0
             for frag in want:
@@ -511,13 +558,13 @@ def main():
             traffic = tot
         roofline = {
             "bound": "hbm",
-            "kernel": {"km_warp2d_bwd": "km_warp2d_bwd = km_warp_bwd_tiled_kernel + km_warp_gm_kernel (dominant launch: " + dom_kernel + ")"}.get(dom_op, dom_op),
+            "kernel": {"km_warp2d_bwd": "km_warp2d_bwd (" + ops["km_warp2d_bwd"].get("form", "") + "; dominant launch: " + dom_kernel + ")"}.get(dom_op, dom_op),
             "achieved": ops[dom_op]["GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ops[dom_op]["frac_of_hbm_peak"],
             "traffic": traffic,
-            "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)" if traffic else None,
+            "traffic_source": f"profiles/{os.path.basename(PMC_FILE)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)" if traffic else None,
             "op_ms": ops[dom_op]["ms"],
             "alg_bytes_per_call": ops[dom_op]["alg_bytes"],
             "accounting": "SURVEY.md 8(d): warp fwd 2e, blur fwd 2e, blur bwd 2e, warp bwd 3e bytes per element; op = every launch of the public entry point",
@@ -543,6 +590,8 @@ def main():
                 "global_batch": global_batch,
                 "parallelism": f"batch-shard x{world} ({args.scaling} scaling), no data-path collective",
             },
+            "inputs": f"{n_sets} distinct (x, M, grad_out) sets rotated through the timed loop (a new batch every step)",
+            "ms_per_step_one_input_set": round(single_ms, 4) if single_ms is not None else None,
             "step_GBps_algorithmic": round(alg_step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_frac_of_hbm_peak": round(alg_step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roofline,

@@ -43,6 +43,14 @@ int km_device_info(char* name, int n);
  * every launch forward (what a per-kernel timing loop over one input needs: otherwise launch k+1 re-reads the tail launch k just
  * read).  Results do not depend on it.  Returns the previous mode.  (No reference counterpart: the reference has no launch policy.) */
 int km_set_traversal(int mode);
+/* Launch policy.  The library reads its A/B switches (profiles/README.md: KM_WARP_FWD_ALGO, KM_BLUR_ROWS, ...) from the environment ONCE,
+ * when it is first used; no launcher calls getenv.  km_config_set changes one entry explicitly ("traversal_fixed", "warp_fwd_algo",
+ * "warp_gm_algo", "warp_bwd_generic", "warp_bwd_fused", "sep_lds", "sg_generic", "pyrdown_separable", "blur_rows") and returns its
+ * previous value (-1: unknown key).  For tests and A/B timing - call it between launches, not concurrently with them.  The alternating
+ * traversal itself keeps its parity per (device, stream): what one stream launches never changes the order another stream's kernels
+ * walk the batch.  (No reference counterpart.) */
+int km_config_set(const char* key, int value);
+int km_config_get(const char* key);
 
 /* ---- batched 3x3 homography chain -----------------------------------------------------------
  * Replaces normalize_homography (kornia/geometry/conversions.py:1691-1726),
@@ -79,6 +87,15 @@ int km_warp2d_fwd(const void* src, const void* mat, void* dst, int B, int C, int
 int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
                   int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align_corners,
                   const void* fill, int dtype, void* stream);
+/* The same with a caller-owned workspace.  When both gsrc and gmat are wanted and workspace_bytes >= km_warp2d_bwd_workspace_bytes(...)
+ * (16-byte aligned device memory, contents irrelevant, not used after the launches it is passed to), both gradients come from ONE read
+ * of grad_out (a persistent tile-owner kernel that keeps its source tile in LDS: 3e bytes per element instead of 4e).  With a null /
+ * short workspace it is km_warp2d_bwd.  Same results to the rounding of the fixed-point scale (both within the tolerances of tests/). */
+int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
+                     int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align_corners,
+                     const void* fill, int dtype, void* workspace, long long workspace_bytes, void* stream);
+/* bytes of workspace the one-read backward uses for these sizes and modes; 0: it does not apply (pass no workspace) */
+long long km_warp2d_bwd_workspace_bytes(int B, int C, int H, int W, int h, int w, int interp, int pad, int dtype);
 
 /* 1 if km_warp2d_bwd with these modes accumulates with atomics and needs gsrc zeroed by the caller,
  * 0 if it overwrites gsrc completely (tile-owner path: bilinear, zeros/fill padding, dtype != f64). */

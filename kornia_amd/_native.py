@@ -35,6 +35,8 @@ _PROTOTYPES = {
     "km_affine_matrix2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "km_warp2d_fwd": [_P, _P, _P] + [_I] * 12 + [_P, _I, _P],
     "km_warp2d_bwd": [_P, _P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],
+    "km_warp2d_bwd_ws": [_P, _P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P, ctypes.c_longlong, _P],
+    "km_warp2d_bwd_workspace_bytes": [_I] * 9,
     "km_warp2d_bwd_needs_zero_init": [_I, _I, _I],
     "km_grid_sample2d_fwd": [_P, _P, _P] + [_I] * 10 + [_I, _P],
     "km_grid_sample2d_bwd": [_P, _P, _P, _P, _P] + [_I] * 10 + [_I, _P],
@@ -99,17 +101,21 @@ def lib() -> ctypes.CDLL:
         if fn is None:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it")
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = ctypes.c_longlong if name == "km_warp2d_bwd_workspace_bytes" else c_int
     handle.km_device_info.argtypes = [c_char_p, c_int]
     handle.km_device_info.restype = c_int
     handle.km_set_traversal.argtypes = [c_int]
     handle.km_set_traversal.restype = c_int
+    handle.km_config_set.argtypes = [c_char_p, c_int]
+    handle.km_config_set.restype = c_int
+    handle.km_config_get.argtypes = [c_char_p]
+    handle.km_config_get.restype = c_int
     _lib = handle
     return handle
 
 
 def exported_symbols() -> list[str]:
-    return ["km_abi_version", "km_last_error", "km_device_info", "km_set_traversal", *_PROTOTYPES.keys()]
+    return ["km_abi_version", "km_last_error", "km_device_info", "km_set_traversal", "km_config_set", "km_config_get", *_PROTOTYPES.keys()]
 
 
 def check(rc: int, what: str) -> None:

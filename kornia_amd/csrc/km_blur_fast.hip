@@ -255,8 +255,7 @@ static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, 
     a.C = C; a.H = H; a.W = W; a.Bk = Bk; a.border = border;
     a.groups_x = (uint32_t)(W / 4);
     a.bx = (a.groups_x + 63) / 64;
-    const char* fr = getenv("KM_BLUR_ROWS");  // 8 / 32: forces the instantiation (tests, A/B timing); read per call so that a test can switch it
-    const int force_rows = fr ? atoi(fr) : 0;
+    const int force_rows = km_config().blur_rows;  // 8 / 32: forces the instantiation (tests, A/B timing: KM_BLUR_ROWS / km_config_set)
     const uint64_t waves_big = (uint64_t)a.bx * (uint64_t)((H + KMB_ROWS - 1) / KMB_ROWS) * (uint64_t)B * C;
     a.small = sizeof(T) != 2 ? 0u : (force_rows ? (force_rows == KMB_ROWS_SMALL ? 1u : 0u) : (waves_big < KMB_SMALL_BELOW_WAVES ? 1u : 0u));
     const int rows = a.small ? KMB_ROWS_SMALL : KMB_ROWS;
@@ -265,7 +264,7 @@ static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, 
     KM_REQUIRE(nb < (1ull << 31), "km_blur: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
-    a.reverse = km_traversal_next();
+    a.reverse = km_traversal_next(s);
     a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(T));
     switch (K) {
         case 3: return km_blur_launch<T, 3>(bwd, a, s);

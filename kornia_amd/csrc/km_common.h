@@ -38,6 +38,17 @@ int km_check_launch(const char* what);
 #define KM_F2I(v) ((int)(v))
 #endif
 
+// floor(v + 0.5) as an int32 in ONE instruction (v_cvt_rpi_i32_f32; saturating, NaN -> 0): the fixed-point quantisation of the
+// tile-owner backward kernels.  (The host build of the kernels supplies a function with the instruction's semantics.)
+#ifndef KM_CVT_RPI
+__device__ __forceinline__ int km_cvt_rpi(float v) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+#define KM_CVT_RPI(v) km_cvt_rpi(v)
+#endif
+
 // Value held by the NEXT lane of the same row of 16 lanes (DPP row_shl:1 - one VALU move, no LDS traffic); the last lane of a
 // row gets its own value back.  (The host build of the kernels defines KM_NEXT16 and supplies the same function.)
 #ifndef KM_NEXT16
@@ -250,12 +261,41 @@ __device__ __forceinline__ uint32_t km_xcd_remap(uint32_t bid, uint32_t nblocks,
     return start + (reverse ? count - 1u - k : k);
 }
 
-// Direction of the next launch of a streaming kernel (host side, km_runtime.hip).  The five kernels of the hot step each stream
+// Scheduling fence: the compiler does not move instructions across it (no code is emitted).  Used between independent unrolled
+// bodies whose interleaving would raise the register count (the host build of the kernels defines it away).
+#ifndef KM_SCHED_FENCE
+#define KM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// Direction of the next launch of a streaming kernel on stream s (host side, km_runtime.hip).  The kernels of the hot step each stream
 // ~0.8 GB in and out, three times the 256 MB Infinity Cache, so a consumer that walks the batch in the producer's order finds
-// nothing of what the producer touched last.  Consecutive launches therefore alternate direction: the consumer starts where
-// the producer (or the previous reader of the same tensor) ended.  Measured on MI355X, config 2: step 1.864 -> 1.837 ms.
-// KM_TRAVERSAL=fixed keeps every launch forward (A/B).
-uint32_t km_traversal_next();
+// nothing of what the producer touched last.  Consecutive launches ON ONE STREAM therefore alternate direction: the consumer starts
+// where the producer (or the previous reader of the same tensor) ended.  Measured on MI355X, config 2: step 1.864 -> 1.837 ms.
+// The parity is per (device, stream); KM_TRAVERSAL=fixed / km_set_traversal(1) keeps every launch forward (A/B).
+uint32_t km_traversal_next(hipStream_t s);
+
+// Launch policy, read once from the environment when the library is first used (km_runtime.hip); see profiles/README.md
+struct KmConfig {
+    int traversal_fixed;    // KM_TRAVERSAL=fixed
+    int warp_fwd_algo;      // KM_WARP_FWD_ALGO: 0 default, 1 generic, 2 lds
+    int warp_gm_algo;       // KM_WARP_GM_ALGO: 0 default, 1 generic, 2 lds
+    int warp_bwd_generic;   // KM_WARP_BWD_ALGO=generic
+    int warp_bwd_fused;     // KM_WARP_BWD_FUSED=0 turns the one-read backward off (two launches)
+    int sep_lds;            // KM_SEP_ALGO=lds
+    int sg_generic;         // KM_SG_ALGO=generic
+    int pyrdown_separable;  // KM_PYRDOWN_ALGO=separable
+    int blur_rows;          // KM_BLUR_ROWS=8 / 32 (0: by the size of the launch)
+};
+const KmConfig& km_config();
+int km_device_cus();
+
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads() also waits for every global
+// load and store of the wave (vmcnt(0)), which is exactly what a kernel that keeps the NEXT tile's loads in flight across the barrier
+// must not do (km_warp_bwd_fused.hip).  Global memory written before it is NOT made visible by it.  (The host build of the kernels
+// maps it to its ordinary barrier.)
+#ifndef KM_LDS_BARRIER
+#define KM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 // wave-level sum (64 lanes) in double precision
 __device__ __forceinline__ double km_wave_sum(double v) {

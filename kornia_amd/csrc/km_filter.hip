@@ -549,12 +549,7 @@ int km_blur_fast_run(bool bwd, const void* x, const void* kx, const void* ky, vo
                      int border, int dtype, hipStream_t s);
 static int km_sep_algo() {
     // KM_SEP_ALGO=lds forces the generic LDS-tiled kernels (debugging / A-B timing)
-    static int algo = -1;
-    if (algo < 0) {
-        const char* e = getenv("KM_SEP_ALGO");
-        algo = (e && e[0] == 'l') ? 1 : 0;
-    }
-    return algo;
+    return km_config().sep_lds;
 }
 
 #define KM_DISPATCH_DTYPE(dtype, CALL)                      \

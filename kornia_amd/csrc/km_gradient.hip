@@ -371,8 +371,7 @@ static int km_grad_run(bool bwd, const void* x, const void* gout, const void* ke
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
     {
-        static int generic = -1;
-        if (generic < 0) { const char* e = getenv("KM_SG_ALGO"); generic = (e && e[0] == 'g') ? 1 : 0; }  // "generic": A/B timing
+        const int generic = km_config().sg_generic;  // KM_SG_ALGO=generic: A/B timing
         if (!bwd && !generic && sizeof(T) != 8 && km_sg_fast_ok<T>(x, out, mag, H, W, n_out, kS)) return km_sg_fast_launch<T>(a, s);
         if (bwd && !generic && sizeof(T) != 8 && H > 2 && km_sg_fast_ok<T>(gout, out, nullptr, H, W, n_out, kS)) return km_sg_fast_bwd_launch<T>(a, s);
     }

@@ -421,8 +421,7 @@ static int kmp_run2(const void* x, void* y, int B, int C, int H, int W, int bord
     KM_REQUIRE(nb < (1ull << 31), "km_pyrdown_fwd: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
-    const char* algo = getenv("KM_PYRDOWN_ALGO");  // "separable": the 5 + 5 tap evaluation (A/B timing, see above)
-    if (algo && algo[0] == 's') {
+    if (km_config().pyrdown_separable) {  // KM_PYRDOWN_ALGO=separable: the 5 + 5 tap evaluation (A/B timing, see above)
         hipLaunchKernelGGL((km_pyrdown2_sep_kernel<T>), dim3(a.nblocks), dim3(256), 0, s, a);
         return km_check_launch("km_pyrdown_fwd(x2, separable)");
     }

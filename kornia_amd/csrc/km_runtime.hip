@@ -3,7 +3,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include <atomic>
+#include <mutex>
 
 #include "km_common.h"
 
@@ -16,19 +19,73 @@ void km_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static std::atomic<int> g_km_traversal_mode{-1};  // -1: not set (KM_TRAVERSAL=fixed in the environment selects 1), 0: alternate, 1: fixed
-static int km_traversal_mode() {
-    int m = g_km_traversal_mode.load(std::memory_order_relaxed);
-    if (m < 0) {
-        const char* e = getenv("KM_TRAVERSAL");
-        m = (e && e[0] == 'f') ? 1 : 0;
-        g_km_traversal_mode.store(m, std::memory_order_relaxed);
-    }
-    return m;
+// ---- launch policy ---------------------------------------------------------------------------------------------------------------
+// Read ONCE, when the library is first used (the A/B switches of profiles/README.md); launchers read the struct, never the
+// environment.  km_config_set changes an entry explicitly (tests, A/B timing of one process) - it is not meant to race with launches.
+static KmConfig g_km_config;
+static std::once_flag g_km_config_once;
+static int km_env_first(const char* name, char c0, char c1 = 0) {
+    const char* e = getenv(name);
+    if (!e) return 0;
+    if (e[0] == c0) return 1;
+    if (c1 && e[0] == c1) return 2;
+    return 0;
 }
-uint32_t km_traversal_next() {
-    static std::atomic<uint32_t> n{0};
-    return km_traversal_mode() ? 0u : (n.fetch_add(1u, std::memory_order_relaxed) & 1u);
+static void km_config_init() {
+    KmConfig& c = g_km_config;
+    c.traversal_fixed = km_env_first("KM_TRAVERSAL", 'f');
+    c.warp_fwd_algo = km_env_first("KM_WARP_FWD_ALGO", 'g', 'l');   // 1 generic, 2 lds
+    c.warp_gm_algo = km_env_first("KM_WARP_GM_ALGO", 'g', 'l');     // 1 generic, 2 lds
+    c.warp_bwd_generic = km_env_first("KM_WARP_BWD_ALGO", 'g');
+    c.warp_bwd_fused = km_env_first("KM_WARP_BWD_FUSED", '0') ? 0 : 1;
+    c.sep_lds = km_env_first("KM_SEP_ALGO", 'l');
+    c.sg_generic = km_env_first("KM_SG_ALGO", 'g');
+    c.pyrdown_separable = km_env_first("KM_PYRDOWN_ALGO", 's');
+    const char* br = getenv("KM_BLUR_ROWS");
+    c.blur_rows = br ? atoi(br) : 0;
+}
+const KmConfig& km_config() {
+    std::call_once(g_km_config_once, km_config_init);
+    return g_km_config;
+}
+
+// Direction of the next launch of a streaming kernel ON THIS STREAM: the parity is per (device, stream), so what another thread,
+// stream or device launches never changes the order a stream's own kernels see (re-entrant: the table is lock-free, an entry is
+// claimed once and then only touched through its own atomic counter).  Beyond KM_STREAM_SLOTS live streams the direction stays fixed.
+#define KM_STREAM_SLOTS 256
+static std::atomic<uint64_t> g_km_stream_key[KM_STREAM_SLOTS];  // 0 = free
+static std::atomic<uint32_t> g_km_stream_parity[KM_STREAM_SLOTS];
+uint32_t km_traversal_next(hipStream_t s) {
+    if (km_config().traversal_fixed) return 0u;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = ((uint64_t)(uintptr_t)s) ^ ((uint64_t)(dev + 1) << 56) ^ 0x8000000000000000ull;  // never 0
+    uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56);
+    for (int probe = 0; probe < KM_STREAM_SLOTS; ++probe, h = (h + 1u) % KM_STREAM_SLOTS) {
+        uint64_t k = g_km_stream_key[h].load(std::memory_order_acquire);
+        if (k == 0) {
+            uint64_t expect = 0;
+            if (g_km_stream_key[h].compare_exchange_strong(expect, key, std::memory_order_acq_rel)) k = key;
+            else k = expect;
+        }
+        if (k == key) return g_km_stream_parity[h].fetch_add(1u, std::memory_order_relaxed) & 1u;
+    }
+    return 0u;
+}
+
+// compute units of the current device (cached per device ordinal; 0 on the host build of the kernels)
+int km_device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        v = p.multiProcessorCount > 0 ? p.multiProcessorCount : -1;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? v : 0;
 }
 
 int km_check_launch(const char* what) {
@@ -45,9 +102,41 @@ extern "C" {
 int km_abi_version(void) { return KM_ABI_VERSION; }
 
 int km_set_traversal(int mode) {
-    const int prev = km_traversal_mode();
-    g_km_traversal_mode.store(mode ? 1 : 0, std::memory_order_relaxed);
+    (void)km_config();
+    const int prev = g_km_config.traversal_fixed;
+    g_km_config.traversal_fixed = mode ? 1 : 0;
     return prev;
+}
+
+// Explicit setter of a launch-policy entry (the names of KmConfig's fields); returns the previous value, -1 for an unknown key.
+// For tests and A/B timing: call it between launches, not concurrently with them.
+static int* km_config_field(const char* key) {
+    struct { const char* name; int* field; } table[] = {
+        {"traversal_fixed", &g_km_config.traversal_fixed}, {"warp_fwd_algo", &g_km_config.warp_fwd_algo},
+        {"warp_gm_algo", &g_km_config.warp_gm_algo},       {"warp_bwd_generic", &g_km_config.warp_bwd_generic},
+        {"warp_bwd_fused", &g_km_config.warp_bwd_fused},   {"sep_lds", &g_km_config.sep_lds},
+        {"sg_generic", &g_km_config.sg_generic},           {"pyrdown_separable", &g_km_config.pyrdown_separable},
+        {"blur_rows", &g_km_config.blur_rows},
+    };
+    if (key)
+        for (auto& e : table)
+            if (strcmp(e.name, key) == 0) return e.field;
+    return nullptr;
+}
+int km_config_set(const char* key, int value) {
+    (void)km_config();
+    int* f = km_config_field(key);
+    if (!f) { km_set_error("km_config_set: unknown key '%s'", key ? key : "(null)"); return -1; }
+    const int prev = *f;
+    *f = value;
+    return prev;
+}
+// current value of a launch-policy entry (-1: unknown key)
+int km_config_get(const char* key) {
+    (void)km_config();
+    const int* f = km_config_field(key);
+    if (!f) { km_set_error("km_config_get: unknown key '%s'", key ? key : "(null)"); return -1; }
+    return *f;
 }
 
 const char* km_last_error(void) { return g_km_error; }

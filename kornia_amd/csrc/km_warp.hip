@@ -693,9 +693,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
 
 // ------------------------------------------------------------------------------------------------
 static bool km_fwd_generic_forced() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("KM_WARP_FWD_ALGO"); v = (e && e[0] == 'g') ? 1 : 0; }  // "generic": A/B timing
-    return v == 1;
+    return km_config().warp_fwd_algo == 1;  // KM_WARP_FWD_ALGO=generic: A/B timing
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,7 +814,7 @@ static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
     KmWarpArgs<T> a = a0;
     a.tiles_y = (uint32_t)((a.g.h + KML_TILE_H - 1) / KML_TILE_H);
     a.nblocks = a.tiles_x * a.tiles_y * (uint32_t)a.g.B;  // (<= the 64 x 16 grid the caller checked)
-    a.reverse = km_traversal_next();
+    a.reverse = km_traversal_next(s);
     a.stream_out = km_stream_stores((uint64_t)a.g.B * a.g.C * a.g.h * a.g.w * sizeof(T));
     if (a.g.align)
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 1>), dim3(a.nblocks), dim3(256), 0, s, a);
@@ -824,9 +822,7 @@ static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
 }
 static int km_fwd_algo() {  // KM_WARP_FWD_ALGO: "generic" | "lds" (LDS-staged kernel, A/B timing) | default: the lean gather kernel
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("KM_WARP_FWD_ALGO"); v = (e && e[0] == 'l') ? 1 : 0; }
-    return v;
+    return km_config().warp_fwd_algo == 2 ? 1 : 0;
 }
 template <typename T, int CM, int NC>
 static void km_warp_fwd_lds_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
@@ -942,6 +938,12 @@ int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, in
 int km_warp_gm_run(const void* gout, const void* src, const void* mat, double* gmat, int B, int C, int H, int W, int h, int w, int B_M,
                    int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype, hipStream_t s);
 
+// both gradients from one read of grad_out (km_warp_bwd_fused.hip)
+int km_warp_bwd_fused_supported(int interp, int pad, int dtype, int C, int H, int W, int h, int w);
+size_t km_warp_bwd_fused_workspace(int B, int H, int W);
+int km_warp_bwd_fused_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, void* ws, int B, int C, int H, int W, int h, int w,
+                          int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype, hipStream_t s);
+
 extern "C" {
 
 // Replaces the eager grid construction + F.grid_sample of
@@ -982,9 +984,9 @@ int km_warp2d_fwd_masked(const void* src, const void* mat, void* dst, const void
 // Replaces autograd of the above: aten::grid_sampler_2d_backward + the reverse of the grid chain.
 // gsrc: (B,C,H,W) in the COMPUTE dtype (fp32 for f32/bf16/f16 data, fp64 for f64), pre-zeroed, nullable.
 // gmat: (B_M,9) fp64 accumulators, pre-zeroed, nullable.
-int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
-                  int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align,
-                  const void* fill, int dtype, void* stream) {
+int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
+                     int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align,
+                     const void* fill, int dtype, void* workspace, long long workspace_bytes, void* stream) {
     if (B == 0 || C == 0) return 0;
     if (km_warp_validate("km_warp2d_bwd", src, mat, B, C, H, W, h, w, B_M, coord_mode, interp, pad, fill, dtype)) return -1;
     KM_REQUIRE(gout, "km_warp2d_bwd: null gout");
@@ -994,7 +996,10 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
     const bool gm_fast = gmat && km_warp_gm_supported(interp, pad, dtype, H, W, h, w);
     if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc)) {
         if (km_warp_bwd_tiled_dims_ok(h, w)) {
-            // both gradients in one pass over grad_out when the tile-owner kernel can gather the source taps itself
+            // both gradients wanted: one persistent launch that reads grad_out once (3e bytes per element instead of 4e)
+            if (gmat && workspace && km_warp_bwd_fused_supported(interp, pad, dtype, C, H, W, h, w) &&
+                (unsigned long long)workspace_bytes >= (unsigned long long)km_warp_bwd_fused_workspace(B, H, W) && ((uintptr_t)workspace & 15) == 0)
+                return km_warp_bwd_fused_run(gout, src, mat, gsrc, gmat, workspace, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
             // scatter first, matrix gradient second: with the alternating batch traversal (km_traversal_next) the second launch starts on the
             // part of grad_out the first one read last.  (The other order measured 1.868 against 1.845 ms per step - no better than a fixed direction.)
             const int rc = km_warp_bwd_tiled_run(gout, mat, gsrc, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, dtype, s);
@@ -1016,6 +1021,23 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
         case KM_BF16: return km_warp_run<km_bf16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
         default: return km_warp_run<km_f16>(true, src, mat, nullptr, gout, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, s);
     }
+}
+
+// km_warp2d_bwd_ws without a workspace: the image gradient and the matrix gradient as two launches (each reads grad_out)
+int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
+                  int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align,
+                  const void* fill, int dtype, void* stream) {
+    return km_warp2d_bwd_ws(gout, src, mat, gsrc, gmat, B, C, H, W, h, w, B_M, coord_mode, norm_coords, interp, pad, align, fill, dtype, nullptr, 0, stream);
+}
+
+// Bytes of workspace with which km_warp2d_bwd_ws computes BOTH gradients from one read of grad_out (0: these modes / sizes have no
+// such path - pass no workspace).  16-byte aligned device memory, contents irrelevant, not read after the call returns.
+long long km_warp2d_bwd_workspace_bytes(int B, int C, int H, int W, int h, int w, int interp, int pad, int dtype) {
+    int dummy = 0;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return 0;
+    if (!km_warp_bwd_tiled_supported(interp, pad, dtype, &dummy) || !km_warp_bwd_tiled_dims_ok(h, w)) return 0;
+    if (!km_warp_bwd_fused_supported(interp, pad, dtype, C, H, W, h, w)) return 0;
+    return (long long)km_warp_bwd_fused_workspace(B, H, W);
 }
 
 // ---- explicit sampling grid: replaces F.grid_sample(input, grid) as called by remap (imgwarp.py:702) and

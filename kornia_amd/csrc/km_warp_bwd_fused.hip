@@ -1,0 +1,856 @@
+// kornia_amd - BOTH gradients of the bilinear warps (zeros / fill padding) from ONE read of grad_out, for gfx950:
+// grad wrt the image (the tile-owner scatter of km_warp_bwd_tiled.hip) and grad wrt the (B,3,3) matrix (km_warp_gm.hip) in
+// one persistent launch.  Replaces the autograd backward of kornia/geometry/transform/imgwarp.py:143-174 (warp_perspective),
+// :246-290 (warp_affine) and :1539-1546 (homography_warp) when both the image and the matrix require a gradient.
+//
+// Why it is one kernel now.  The two launches read grad_out twice (4e bytes per element against the op's 3e, SURVEY.md 8(d):
+// 3.31 GB moved for 2.42 GB at 256x3x512^2).  Three earlier one-read forms lost to them because the matrix
+// gradient's source taps were GATHERED from global memory inside the owner loop.  Here the owner of a source tile already has
+// that tile on chip:
+//
+//   * the matrix gradient is linear in the tap values: dL/dM = sum_q J_q^T sum_taps dw_tap/d(x,y) * src[tap] * grad_out[q].
+//     Every tap belongs to exactly one tile, so each owner adds the terms of the taps IT owns - the same ownership rule that
+//     makes the scatter add every contribution to grad_src exactly once;
+//   * the owner keeps its 64 x 64 x C source tile in LDS next to the 64 x 64 x C fixed-point accumulators (96 KB of the CU's
+//     160 KB): all tap reads are ds_read, no gathers, no texture-address traffic beyond the two coalesced streams;
+//   * one workgroup per CU, PERSISTENT, walking runs of horizontally adjacent tiles.  Everything a tile needs from HBM - the
+//     box of grad_out pixels that can touch it (KMO_SLOTS pixels per thread) and its source tile - is requested one tile
+//     AHEAD into registers: the source tile when the previous tile's scatter starts, the grad_out pixels slot by slot as the
+//     previous tile's slots are consumed (one register set holds both tiles).  The loads of tile k + 1 fly while tile k is
+//     scattered and the flush of tile k drains while tile k + 1 starts: the memory pipe of the CU never waits for a phase;
+//   * because the whole box is in registers before the first contribution is added, the fixed-point scale comes from the
+//     EXACT maximum of |grad_out| over the box: no speculation, no redo pass, 3 more bits than km_warp_bwd_tiled.hip;
+//   * barriers inside the tile loop wait for LDS only (KM_LDS_BARRIER): a __syncthreads() would drain the loads in flight.
+//
+// Three launches, so that the persistent loop carries nothing it rarely needs (inlined, the general path and the box computation cost
+// the loop 250 spilled registers; as function calls, more):
+//   1. km_warp_bwd_boxes_kernel   one THREAD per tile: its box (kmt_tile_box, ~400 dependent instructions), head-room bits and
+//                                 class -> 32 bytes of the caller's workspace;
+//   2. km_warp_bwd_fused_kernel   the persistent loop over the REGULAR tiles (box fits the registers, fixed point accurate, division
+//                                 operands in range).  A regular tile that meets a non-finite gradient marks itself and leaves;
+//   3. km_warp_bwd_general_kernel the remaining tiles (minification beyond ~1.2x, the vanishing line, > 7x magnification, NaN / inf in
+//                                 grad_out): bands of the box, one pixel per thread and pass, IEEE float LDS atomics where fixed point
+//                                 is not accurate enough - the same arithmetic, slower.  Exits at once when there are none.
+//
+// HBM traffic: grad_out ~1.07x (box overlap, served by L2) + src once + grad_src once = 3e bytes / element.
+//
+// Built with -fno-slp-vectorize (kornia_amd/build.py): a packed v_pk_fma_f32 names a register PAIR, and when the unused half of the pair
+// is a slot with a load in flight the compiler waits for that load - in the middle of the scatter.  What the tile loop looks like is
+// shaped by where the compiler's waits land (it cannot count loads issued under a branch, and it orders every write of a register
+// after the loads in flight): see the comments at kmo_stage, kmo_issue_src and kmo_process.
+#include <stdlib.h>
+
+#include "km_warp_gm_rows.h"
+#include "km_warp_tile.h"
+
+#ifndef KMO_NT
+#define KMO_NT 1024        // threads per workgroup (one workgroup per CU: 16 waves)
+#endif
+#define KMO_NW (KMO_NT / 64)
+#ifndef KMO_SLOTS
+#define KMO_SLOTS 6        // grad_out pixels per thread held in registers: boxes up to KMO_NT * KMO_SLOTS pixels are "regular"
+#endif
+#ifndef KMO_TH
+#define KMO_TH 64          // tile height (the tile width is KMT_TW = 64: the flush maps 16 lanes to a 256-byte row)
+#endif
+#define KMO_PLANE (KMO_TH * KMT_TW)
+#ifndef KMO_WG_PER_CU
+#define KMO_WG_PER_CU 1    // persistent workgroups per CU (what the LDS of a workgroup allows)
+#endif
+#ifndef KMO_SRC_AT
+#define KMO_SRC_AT 0       // slot of the scatter after which the next tile's source tile is requested
+#endif
+#define KMO_RUN 64         // records wave 0 fetches from the workspace at once (lane = tile), into alternating halves of a 2 x 64 ring
+#define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, -, -, the 9 matrix entries, -, -, -
+enum { KMO_F_FIXED = 1, KMO_F_REGULAR = 4, KMO_F_NONFINITE = 8 };
+
+template <typename T>
+struct KmWarpFusedArgs {
+    const T* gout;       // (B,C,h,w)
+    const T* src;        // (B,C,H,W)
+    const float* mat;    // (B_M,9)
+    float* gsrc;         // (B,C,H,W) fp32, written completely
+    double* gmat;        // (B_M,9) fp64 accumulators, pre-zeroed
+    const float* fill;   // (C), pad == fill only
+    int* ws;             // (ntiles, KMO_BOX_INTS) workspace: the tiles' boxes and classes
+    KmWarpGeom<float> g;
+    uint32_t tiles_x, tiles_y, ntiles, nruns, run_len;  // a run = run_len horizontally adjacent tiles (run_len == tiles_x or 1)
+    uint32_t nworkers;   // == gridDim.x of the persistent launch
+    uint32_t reverse;    // the launch walks the batch backwards (km_traversal_next)
+    uint32_t stream_out; // streaming stores of the tile flush (km_stream_stores)
+};
+
+__host__ __device__ constexpr int kmo_lds_bytes(int cc) {
+    return (KMT_BAND_W + KMT_TAB) * 16 + 2 * cc * KMO_PLANE * 4 + 2 * KMO_RUN * KMO_BOX_INTS * 4 + KMO_NW * 8 + KMO_NW * 9 * 8;
+}
+
+// One tile (everything block-uniform)
+struct KmoTile {
+    int t;             // linear tile index (b, ty, tx), < 0: the sequence has ended
+    int b, X0, Y0, TWc, THc;
+    int j0, j1, i0, i1, hb;
+    bool fixed_ok, regular, svec, fvec;
+    int bw, nq;
+};
+
+template <typename T>
+__device__ __forceinline__ void kmo_tile_coords(const KmWarpFusedArgs<T>& a, uint32_t t, int& b, int& tx, int& ty) {
+    const uint32_t row = t / a.tiles_x;
+    tx = (int)(t - row * a.tiles_x);
+    b = (int)(row / a.tiles_y);
+    ty = (int)(row - (uint32_t)b * a.tiles_y);
+}
+
+// q-th tile of this worker: runs are dealt round-robin to the workers (the 32 workers of an XCD take consecutive runs, i.e.
+// neighbouring tile rows of the same images, so the rows of grad_out that neighbouring boxes share stay in one L2)
+template <typename T>
+__device__ __forceinline__ int kmo_tile_of(const KmWarpFusedArgs<T>& a, uint32_t q) {
+    const uint32_t R = a.run_len, NWK = a.nworkers, w = blockIdx.x;
+    const uint32_t lw = (NWK % 8u == 0u) ? (w % 8u) * (NWK / 8u) + w / 8u : w;
+    const uint32_t r = q / R, k = q - r * R;
+    uint32_t rho = r * NWK + lw;
+    if (rho >= a.nruns) return -1;
+    if (a.reverse) rho = a.nruns - 1u - rho;
+    return (int)(rho * R + k);  // runs tile the (image, tile row, tile column) order: run_len divides tiles_x
+}
+
+// ---- launch 1: boxes and classes of all tiles, one thread per tile ---------------------------------------------------------------
+template <typename T, int CM>
+__global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFusedArgs<T> a) {
+    const KmWarpGeom<float>& g = a.g;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.ntiles) return;
+    int b, tx, ty;
+    kmo_tile_coords(a, t, b, tx, ty);
+    float m[9];
+    const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = mp[k];
+    const int X0 = tx * KMT_TW, Y0 = ty * KMO_TH;
+    const int X1 = min(X0 + KMT_TW, g.W), Y1 = min(Y0 + KMO_TH, g.H);
+    const KmtBox bx = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
+    const int bw = bx.j1 - bx.j0 + 1, bh = bx.i1 - bx.i0 + 1;
+    const bool empty = bw <= 0 || bh <= 0;
+    const bool fits = empty || (bw <= KMT_BAND_W && bh <= KMT_TAB && (long long)bw * bh <= (long long)KMO_NT * KMO_SLOTS);
+    // every pixel of the box has division operands inside the range of the shared-reciprocal division (km_lean.h)
+    const bool fast = empty ? true : kml_div_guard<CM>(g, m, bx.j0, bx.j1, bx.i0, bx.i1);
+    int* o = a.ws + (size_t)t * KMO_BOX_INTS;
+    o[0] = bx.j0; o[1] = bx.j1; o[2] = bx.i0; o[3] = bx.i1;
+    o[4] = (int)ceilf(log2f(fmaxf(bx.mult, 1.f))) + 1;  // head-room bits
+    o[5] = (bx.fixed_ok ? KMO_F_FIXED : 0) | ((fits && fast && bx.fixed_ok) ? KMO_F_REGULAR : 0);
+    o[6] = 0; o[7] = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[8 + k] = __float_as_int(m[k]);  // (the tile loop reads its matrix from LDS, not through a vector load)
+    o[17] = 0; o[18] = 0; o[19] = 0;
+}
+
+// tile t from its (block-uniform) workspace record
+// the matrix of a tile from its record (block-uniform values in vector registers: what the caller does not use costs nothing)
+__device__ __forceinline__ void kmo_matrix(const int* rec, float (&m)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = __int_as_float(rec[8 + k]);
+}
+// record of the q-th tile of this worker in the LDS ring
+__device__ __forceinline__ const int* kmo_ring(const int* s_box, uint32_t q) { return s_box + (q % (2u * KMO_RUN)) * KMO_BOX_INTS; }
+
+template <typename T>
+__device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t, const int* rec, KmoTile& d) {
+    const KmWarpGeom<float>& g = a.g;
+    d = KmoTile{};
+    d.t = t;
+    if (t < 0) return;
+    int tx, ty;
+    kmo_tile_coords(a, (uint32_t)t, d.b, tx, ty);
+    d.X0 = tx * KMT_TW; d.Y0 = ty * KMO_TH;
+    d.TWc = min(d.X0 + KMT_TW, g.W) - d.X0; d.THc = min(d.Y0 + KMO_TH, g.H) - d.Y0;
+    d.j0 = kmt_uniform(rec[0]); d.j1 = kmt_uniform(rec[1]); d.i0 = kmt_uniform(rec[2]); d.i1 = kmt_uniform(rec[3]);
+    d.hb = kmt_uniform(rec[4]);
+    const int fl = kmt_uniform(rec[5]);
+    d.fixed_ok = (fl & KMO_F_FIXED) != 0; d.regular = (fl & KMO_F_REGULAR) != 0;
+    const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
+    d.bw = bw;
+    d.nq = (bw > 0 && bh > 0) ? bw * bh : 0;
+    // 16-byte rows of the source tile / of the tile flush
+    d.svec = (sizeof(T) == 4) && d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.src & 15) == 0;
+    d.fvec = d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0;
+}
+
+// records of tiles q0 .. q0 + 63 of this worker, workspace -> LDS, one lane per tile (wave 0)
+template <typename T>
+__device__ __forceinline__ void kmo_fetch_boxes(const KmWarpFusedArgs<T>& a, uint32_t q0, int lane, int* s_box) {
+    const int t = kmo_tile_of(a, q0 + (uint32_t)lane);
+    static_assert(KMO_BOX_INTS % 4 == 0, "16-byte pieces");
+    int4* dst = reinterpret_cast<int4*>(s_box) + (KMO_BOX_INTS / 4) * (((q0 / KMO_RUN) & 1u) * KMO_RUN + (uint32_t)lane);
+    if (t >= 0) {
+        const int4* rec = reinterpret_cast<const int4*>(a.ws + (size_t)t * KMO_BOX_INTS);
+#pragma unroll 1
+        for (int k = 0; k < KMO_BOX_INTS / 4; ++k) dst[k] = rec[k];
+    } else {
+        dst[0] = make_int4(0, -1, 0, -1);
+        dst[1] = make_int4(0, 0, 0, 0);
+    }
+}
+
+// first pixel of this thread in a box of width bw walked as a linear list (element e = tid; tid < 2^24: the float quotient is off by at most one)
+__device__ __forceinline__ void kmo_first(int tid, int bw, int& qi, int& qj) {
+    // (a reciprocal, not a division: 15 instructions fewer per thread and tile; the two corrections below absorb its error)
+    qi = (int)(((float)tid + 0.5f) * kmt_uniform(__builtin_amdgcn_rcpf((float)bw)));
+    qj = tid - qi * bw;
+    if (qj < 0) { qi -= 1; qj += bw; }
+    if (qj >= bw) { qi += 1; qj -= bw; }
+}
+
+// ---- requests of one tile: its box of grad_out (regular tiles) and its source tile -----------------------------------------------
+// Every load below is UNCONDITIONAL (rows / columns beyond a ragged tile are clamped to its last one and masked when the registers are
+// stored to LDS): a zero-initialised register + conditional load is a write the compiler orders after every load in flight.
+template <typename T, int CC>
+__device__ __forceinline__ void kmo_issue_src(const KmWarpFusedArgs<T>& a, const KmoTile& d, float (&S)[CC * KMO_PLANE / KMO_NT]) {
+    constexpr int SREG = CC * KMO_PLANE / KMO_NT;
+    static_assert(CC * KMO_PLANE % (4 * KMO_NT) == 0, "whole 16-byte pieces per thread");
+    const KmWarpGeom<float>& g = a.g;
+    const size_t src_plane = (size_t)g.H * g.W;
+    const T* src_b = a.src + (size_t)d.b * g.C * src_plane;
+    const int tid = threadIdx.x;
+    if (d.svec) {
+#pragma unroll
+        for (int k = 0; k < SREG / 4; ++k) {
+            const int idx4 = k * KMO_NT + tid;
+            const int c = idx4 / (KMO_PLANE / 4), rem = idx4 % (KMO_PLANE / 4);
+            const int r = min(rem / (KMT_TW / 4), d.THc - 1), x4 = (rem % (KMT_TW / 4)) * 4;
+            const float* p = reinterpret_cast<const float*>(src_b) + (size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (size_t)(d.X0 + x4);
+            KM_CHECK_ALIGNED(p, 16);
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            S[4 * k + 0] = v.x; S[4 * k + 1] = v.y; S[4 * k + 2] = v.z; S[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SREG; ++k) {
+            const int idx = k * KMO_NT + tid;
+            const int c = idx / KMO_PLANE, rem = idx % KMO_PLANE;
+            const int r = min(rem / KMT_TW, d.THc - 1), x = min(rem % KMT_TW, d.TWc - 1);
+            S[k] = (float)km_ld(src_b + (size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (size_t)(d.X0 + x));
+        }
+    }
+}
+
+// the source tile into LDS, as (v - fill) for pad == fill (the rounding sequence of the oracle: (v - fill) first).  Cells beyond a ragged
+// tile hold copies of its last row / column: no tap ever lands there (the in-tile test of kmo_pix uses the tile's real size).
+template <int CC>
+__device__ __forceinline__ void kmo_store_src(const KmoTile& d, const float (&S)[CC * KMO_PLANE / KMO_NT], float* s_src, const float (&fill)[CC], bool is_fill) {
+    constexpr int SREG = CC * KMO_PLANE / KMO_NT;
+    const int tid = threadIdx.x;
+    if (d.svec) {
+#pragma unroll
+        for (int k = 0; k < SREG / 4; ++k) {
+            const int idx4 = k * KMO_NT + tid;
+            float f = 0.f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) f = (idx4 / (KMO_PLANE / 4) == c) ? fill[c] : f;
+            float4 v = make_float4(S[4 * k + 0], S[4 * k + 1], S[4 * k + 2], S[4 * k + 3]);
+            if (is_fill) { v.x -= f; v.y -= f; v.z -= f; v.w -= f; }
+            reinterpret_cast<float4*>(s_src)[idx4] = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SREG; ++k) {
+            const int idx = k * KMO_NT + tid;
+            float f = 0.f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) f = (idx / KMO_PLANE == c) ? fill[c] : f;
+            s_src[idx] = is_fill ? S[k] - f : S[k];
+        }
+    }
+}
+
+// ---- one visited output pixel: contributions to grad_src (taps inside the tile) and this tile's share of its matrix-gradient terms ----
+// FIXED: int32 fixed-point LDS accumulators; otherwise IEEE float LDS atomics (non-finite gradients, vanishing-line tiles, extreme
+// magnification).  The image gradient at the sample is  gix = sum_c g_c ((ne - nw) wy1 + (se - sw) wy0),  giy = sum_c g_c ((sw - nw) wx1 +
+// (se - ne) wx0)  (km_warp_gm.hip): tap by tap,  nw: (-wy1, -wx1),  ne: (+wy1, -wx0),  sw: (-wy0, +wx1),  se: (+wy0, +wx0)  times
+// dot = sum_c g_c src[tap, c].  A tap outside the tile is another owner's (or outside the image: it does not exist in the reference's sum).
+template <int CM, int CC, bool FAST, bool FIXED>
+__device__ __forceinline__ void kmo_pix(const KmtPix& q, const float (&go)[CC], int* s_acc, const float* s_src, float scale, uint32_t TWc, uint32_t THc,
+                                        float u, float v, float mx, float my, float (&A)[9]) {
+    const KmlTaps& t = q.t;
+    const uint32_t ux = q.ux, uy = q.uy;
+    const bool in_x0 = ux < TWc, in_x1 = (ux + 1u) < TWc;
+    const bool in_y0 = uy < THc, in_y1 = (uy + 1u) < THc;
+    bool t00 = in_x0 && in_y0, t01 = in_x1 && in_y0, t10 = in_x0 && in_y1, t11 = in_x1 && in_y1;
+    if (!FIXED) {
+        const bool num = (q.x == q.x) & (q.y == q.y);  // a NaN position touches nothing (ATen: the converted index is out of bounds)
+        t00 = t00 && num; t01 = t01 && num; t10 = t10 && num; t11 = t11 && num;
+    }
+    const int l00 = (int)(uy * (uint32_t)KMT_TW + ux);
+    // scale = 2^k: (wx * wy) * scale == wx * (wy * scale) bit for bit.  Tap-outer order: one exec-mask region per tap.
+    const float wy0s = FIXED ? t.wy0 * scale : t.wy0, wy1s = FIXED ? t.wy1 * scale : t.wy1;
+    const float w00 = t.wx1 * wy1s, w01 = t.wx0 * wy1s, w10 = t.wx1 * wy0s, w11 = t.wx0 * wy0s;
+    float gix = 0.f, giy = 0.f;
+#ifndef KMO_ABL
+#define KMO_ABL 0  // timing experiments only (wrong results): 1 no matrix-gradient work, 2 no LDS atomics, 4 no per-pixel work
+#endif
+#define KMO_TAP(pred, OFF, W, SX, WX, SY, WY)                                                        \
+    if (pred) {                                                                                       \
+        float dot = 0.f;                                                                              \
+        _Pragma("unroll") for (int c = 0; c < CC; ++c) {                                              \
+            if (!(KMO_ABL & 2)) {                                                                     \
+                if (FIXED) atomicAdd(s_acc + l00 + c * KMO_PLANE + (OFF), kmt_quant((W) * go[c]));    \
+                else atomicAdd((float*)s_acc + l00 + c * KMO_PLANE + (OFF), (W) * go[c]);             \
+            }                                                                                         \
+            if (!(KMO_ABL & 1)) {                                                                     \
+                const float sv = s_src[l00 + c * KMO_PLANE + (OFF)];                                  \
+                dot = (c == 0) ? go[c] * sv : km_fma(go[c], sv, dot);                                 \
+            }                                                                                         \
+        }                                                                                             \
+        gix = km_fma(SX (WX), dot, gix);                                                              \
+        giy = km_fma(SY (WY), dot, giy);                                                              \
+    }
+    KMO_TAP(t00, 0, w00, -, t.wy1, -, t.wx1)
+    KMO_TAP(t01, 1, w01, +, t.wy1, -, t.wx0)
+    KMO_TAP(t10, KMT_TW, w10, -, t.wy0, +, t.wx1)
+    KMO_TAP(t11, KMT_TW + 1, w11, +, t.wy0, +, t.wx0)
+#undef KMO_TAP
+    // this tile's share of the pixel's terms (zero when it owns none of the taps: no 0 * inf from a degenerate position)
+    const bool any = t00 | t01 | t10 | t11;
+    float ax, ay, az;
+    kmg_terms<CM, FAST>(q.p, gix * mx, giy * my, ax, ay, az);
+    ax = any ? ax : 0.f; ay = any ? ay : 0.f; az = any ? az : 0.f;
+    A[0] = km_fma(ax, u, A[0]); A[1] = km_fma(ax, v, A[1]); A[2] += ax;
+    A[3] = km_fma(ay, u, A[3]); A[4] = km_fma(ay, v, A[4]); A[5] += ay;
+    A[6] = km_fma(az, u, A[6]); A[7] = km_fma(az, v, A[7]); A[8] += az;
+}
+
+struct KmoConsts {
+    float Wm1, Hm1, hW, hH, mx, my;
+};
+
+// Walk of a box as a linear list of pixels, KMO_NT apart: element e = s * KMO_NT + tid sits at (qi, qj) of the box
+struct KmoWalk {
+    int qi, qj, di, dj, bw, nq;
+    uint32_t row0;  // element offset of the box's first pixel in a grad_out plane
+};
+template <typename T>
+__device__ __forceinline__ void kmo_walk_init(const KmWarpFusedArgs<T>& a, const KmoTile& d, KmoWalk& wk) {
+    wk.bw = max(d.bw, 1);
+    wk.nq = d.regular ? d.nq : 0;  // (a tile of the general path loads its pixels itself)
+    wk.di = kmt_uniform(KMO_NT / wk.bw);
+    wk.dj = kmt_uniform(KMO_NT % wk.bw);
+    kmo_first(threadIdx.x, wk.bw, wk.qi, wk.qj);
+    wk.row0 = (uint32_t)d.i0 * (uint32_t)a.g.w + (uint32_t)d.j0;
+}
+// request slot s of the walk's tile (zeros beyond the end of the box) and advance
+template <typename T, int CC>
+__device__ __forceinline__ void kmo_request_slot(const T* const (&gout_c)[CC], int w, int s, KmoWalk& wk, float (&Gs)[CC]) {
+    const bool valid = s * KMO_NT + (int)threadIdx.x < wk.nq;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) Gs[c] = 0.f;
+    if (valid) kmt_load_go<T, CC>(gout_c, wk.row0 + (uint32_t)wk.qi * (uint32_t)w + (uint32_t)wk.qj, Gs);
+    kmt_advance(wk.qi, wk.qj, wk.di, wk.dj, wk.bw);
+}
+
+// The pixels a thread holds in registers (regular tiles): element e = s * KMO_NT + tid of the box walked as a linear list.  As soon
+// as slot s has been consumed its registers are REFILLED with slot s of the next tile (wn, gout_n): one register set holds both tiles,
+// and the next tile's requests are spread over the whole scatter instead of issued in one burst.
+template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED>
+__device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& d, const KmoConsts& k, float (&G)[KMO_SLOTS][CC], const float4* s_u4,
+                                            const float4* s_v4, int* s_acc, const float* s_src, float scale, float (&A)[9], int w, KmoWalk& wn,
+                                            const T* const (&gout_n)[CC], bool mine, const KmWarpFusedArgs<T>& a, const KmoTile& nxt,
+                                            float (&S)[CC * KMO_PLANE / KMO_NT]) {
+    const int tid = threadIdx.x;
+    const int bw = max(d.bw, 1);
+    const int di = kmt_uniform(KMO_NT / bw), dj = kmt_uniform(KMO_NT % bw);
+    int qi, qj;
+    kmo_first(tid, bw, qi, qj);
+#pragma unroll
+    for (int s = 0; s < KMO_SLOTS; ++s) {
+        // (mine == false: a tile this launch leaves to the general one - only the refill below happens.  One code path for both, so
+        // that the compiler sees ONE set of registers for the slots: two paths meant copies, and a wait for every load in flight)
+        if (mine && s * KMO_NT < d.nq && !(KMO_ABL & 4)) {  // block-uniform
+            const bool valid = s * KMO_NT + tid < d.nq;
+            const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
+            const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
+            KmtPix q;
+            kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
+            kmo_pix<CM, CC, FAST, FIXED>(q, G[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+            kmt_advance(qi, qj, di, dj, bw);
+        }
+        kmo_request_slot<T, CC>(gout_n, w, s, wn, G[s]);
+        // the next tile's source tile is requested here, not before the loop: registers that are live across the whole loop get
+        // moved by the register allocator at its entry, and a move of a register with a load in flight is a wait for that load
+        if (s == KMO_SRC_AT && nxt.t >= 0 && nxt.regular) kmo_issue_src<T, CC>(a, nxt, S);
+        KM_SCHED_FENCE();  // one pixel at a time: interleaving the slots costs more registers than it hides latency
+    }
+}
+
+// column / row tables of one band of a box: (m0 u, m3 u, m6 u, u) per column, (m1 v, m4 v, m7 v, v) per row
+template <int CM>
+__device__ __forceinline__ bool kmo_fill_tables(const KmWarpGeom<float>& g, const float (&m)[9], int jb, int bwb, int ib, int nrows, float4* s_u4, float4* s_v4) {
+    const int tid = threadIdx.x;
+    static_assert(KMO_NT >= KMT_BAND_W + KMT_TAB, "the column and row tables are filled by disjoint threads");
+    if (tid < bwb) {
+        const float u = km_base_x<float, CM>(g, jb + tid);
+        const KmlHalf h = kml_col_half<CM>(m, u);
+        s_u4[tid] = make_float4(h.a, h.b, h.c, u);
+    }
+    bool okr = true;
+    const int rt = tid - (KMO_NT - KMT_TAB);  // the row table is filled by the LAST threads: the first ones fill the columns
+    if (rt >= 0 && rt < nrows) {
+        const float v = km_base_y<float, CM>(g, ib + rt);
+        const KmlHalf h = kml_row_half<CM>(m, v);
+        s_v4[rt] = make_float4(h.a, h.b, h.c, v);
+        okr = kml_row_guard<CM>(g, m, v);
+    }
+    return okr;
+}
+
+// 2^k with |w g 2^k| (taps per pixel) < 2^30 for |g| <= M (M finite)
+__device__ __forceinline__ void kmo_scale(float M, int hb, float& scale, float& inv_scale) {
+    int kexp = 0;
+    if (M > 0.f) {
+        int ex2;
+        (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
+        kexp = 30 - hb - ex2;
+        kexp = max(-126, min(126, kexp));
+    }
+    scale = kmt_uniform(ldexpf(1.0f, kexp));
+    inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
+}
+
+// The general path of one tile (launch 3): exact maximum over the box, bands of the box through the tables, one pixel per thread and
+// pass; IEEE float accumulation when fixed point is not accurate enough or the gradients are not finite.
+template <typename T, int CM, int ALIGN, int CC>
+__device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, const float (&m)[9], const KmoTile& d, const KmoConsts& k, float4* s_u4, float4* s_v4,
+                                                 int* s_acc, const float* s_src, uint32_t* s_red, float (&A)[9], float& inv_scale, bool& finite) {
+    const KmWarpGeom<float>& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t dst_plane = (size_t)g.h * g.w;
+    const T* gout_c[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)d.b * g.C + (size_t)c) * dst_plane;
+    const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
+    const bool empty = (bw <= 0 || bh <= 0);
+    finite = false;
+    float scale = 1.f;
+    inv_scale = 1.f;
+    if (empty) { finite = true; return; }
+    if (d.fixed_ok) {
+        // the exact maximum of |grad_out| over the box (as integers: sign cleared, NaN / inf sort above every finite value)
+        uint32_t mb = 0;
+        const long long nq = (long long)bw * bh;
+        for (long long base = 0; base < nq; base += KMO_NT) {
+            const long long e = min(base + tid, nq - 1);  // clamped: duplicates do not change a max
+            const int qi = (int)(e / bw), qj = (int)(e - (long long)qi * bw);
+            const uint32_t off = (uint32_t)(d.i0 + qi) * (uint32_t)g.w + (uint32_t)(d.j0 + qj);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) mb = max(mb, __float_as_uint((float)km_ld(km_at(gout_c[c], off))) & 0x7fffffffu);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_down((int)mb, off, 64));
+        if (lane == 0) s_red[wave] = mb;
+        __syncthreads();
+        uint32_t Mb = s_red[0];
+#pragma unroll
+        for (int w = 1; w < KMO_NW; ++w) Mb = max(Mb, s_red[w]);
+        Mb = (uint32_t)kmt_uniform((int)Mb);
+        finite = Mb < 0x7f800000u;
+        if (finite) kmo_scale(__uint_as_float(Mb), d.hb, scale, inv_scale);
+    }
+    bool first_band = true;
+    for (int jb = d.j0; jb <= d.j1; jb += KMT_BAND_W) {
+        const int bwb = min(KMT_BAND_W, d.j1 - jb + 1);
+        for (int ib = d.i0; ib <= d.i1; ib += KMT_TAB) {
+            const int nrows = min(d.i1, ib + KMT_TAB - 1) - ib + 1;
+            if (!first_band) __syncthreads();  // the previous band's readers are done with the tables
+            first_band = false;
+            const bool okr = kmo_fill_tables<CM>(g, m, jb, bwb, ib, nrows, s_u4, s_v4);
+            const bool fast = __syncthreads_and((int)okr) != 0;  // every row of the band has safe division operands
+            const int nq = bwb * nrows;
+            const int di = kmt_uniform(KMO_NT / bwb), dj = kmt_uniform(KMO_NT % bwb);
+            int qi, qj;
+            kmo_first(tid, bwb, qi, qj);
+            const uint32_t row0 = (uint32_t)ib * (uint32_t)g.w + (uint32_t)jb;
+            for (int base = 0; base < nq; base += KMO_NT) {
+                const bool valid = base + tid < nq;
+                const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
+                float go[CC];
+                kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)vqi * (uint32_t)g.w + (uint32_t)vqj, go);
+                const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
+                KmtPix q;
+                if (!finite) {
+                    kmt_pix_position<CM, ALIGN, false>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
+                    kmo_pix<CM, CC, false, false>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                } else if (fast) {
+                    kmt_pix_position<CM, ALIGN, true>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
+                    kmo_pix<CM, CC, true, true>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                } else {
+                    kmt_pix_position<CM, ALIGN, false>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
+                    kmo_pix<CM, CC, false, true>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                }
+                kmt_advance(qi, qj, di, dj, bwb);
+            }
+        }
+    }
+}
+
+// convert and write the tile, leaving the accumulators zeroed for the next one
+template <typename T, int CC>
+__device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const KmoTile& d, int* s_acc, bool finite, float inv_scale) {
+    const KmWarpGeom<float>& g = a.g;
+    const int tid = threadIdx.x;
+    const size_t src_plane = (size_t)g.H * g.W;
+    float* gsrc_b = a.gsrc + (size_t)d.b * g.C * src_plane;
+    if (d.fvec) {
+        // full-width tile, 16-byte aligned rows: 16 lanes x 16 bytes cover a tile row, a wave writes 4 rows per store
+        const int col4 = (tid & 15) * 4, row0 = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            for (int r = row0; r < d.THc; r += KMO_NT / 16) {
+                float* outp = gsrc_b + (size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (d.X0 + col4);
+                int* accp = s_acc + c * KMO_PLANE + r * KMT_TW + col4;
+                KM_CHECK_ALIGNED(accp, 16);
+                KM_CHECK_ALIGNED(outp, 16);
+                const int4 q = *reinterpret_cast<const int4*>(accp);
+                *reinterpret_cast<int4*>(accp) = make_int4(0, 0, 0, 0);
+                float4 v;
+                if (finite) v = make_float4((float)q.x * inv_scale, (float)q.y * inv_scale, (float)q.z * inv_scale, (float)q.w * inv_scale);
+                else v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
+                if (a.stream_out) {
+                    typedef float km_f4v __attribute__((ext_vector_type(4)));
+                    km_f4v vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
+                    __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v*>(outp));
+                } else {
+                    *reinterpret_cast<float4*>(outp) = v;
+                }
+            }
+        }
+    } else {
+        // ragged right edge / unaligned rows: lane -> column, waves -> rows, one float per store
+        const int col = tid & (KMT_TW - 1), row0 = tid >> 6;
+        if (col < d.TWc) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                for (int r = row0; r < d.THc; r += KMO_NW) {
+                    int* accp = s_acc + c * KMO_PLANE + r * KMT_TW + col;
+                    const int q = *accp;
+                    *accp = 0;
+                    gsrc_b[(size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (d.X0 + col)] = finite ? (float)q * inv_scale : __int_as_float(q);
+                }
+            }
+        }
+    }
+}
+
+struct KmoLds {
+    float4 *s_u4, *s_v4;
+    int* s_acc;
+    float* s_src;
+    int* s_box;
+    uint32_t* s_red;
+    double* s_gm;
+};
+template <int CC>
+__device__ __forceinline__ KmoLds kmo_carve(char* smem_raw) {
+    KmoLds l;
+    l.s_u4 = (float4*)smem_raw;                             // [KMT_BAND_W] per column of the box
+    l.s_v4 = l.s_u4 + KMT_BAND_W;                           // [KMT_TAB] per row of the box
+    l.s_acc = (int*)(l.s_v4 + KMT_TAB);                     // [CC][TH][TW] fixed-point accumulators
+    l.s_src = (float*)(l.s_acc + CC * KMO_PLANE);           // [CC][TH][TW] the source tile (minus fill)
+    l.s_box = (int*)(l.s_src + CC * KMO_PLANE);             // [2 KMO_RUN][KMO_BOX_INTS] ring of records of this worker's tiles
+    l.s_red = (uint32_t*)(l.s_box + 2 * KMO_RUN * KMO_BOX_INTS);  // [KMO_NW] (8-byte slots: keeps s_gm aligned)
+    l.s_gm = (double*)(l.s_red + 2 * KMO_NW);               // [KMO_NW][9] matrix-gradient partials of a finished image
+    return l;
+}
+template <int ALIGN>
+__device__ __forceinline__ KmoConsts kmo_consts(const KmWarpGeom<float>& g) {
+    KmoConsts kc;
+    kc.Wm1 = (float)(g.W - 1); kc.Hm1 = (float)(g.H - 1); kc.hW = (float)g.W / 2; kc.hH = (float)g.H / 2;
+    kc.mx = ALIGN ? kc.Wm1 / 2 : kc.hW; kc.my = ALIGN ? kc.Hm1 / 2 : kc.hH;  // d (pixel) / d (normalised): km_unnormalize's multiplier
+    return kc;
+}
+// the wave partials of a finished image in s_gm -> 9 fp64 atomics
+template <int CM>
+__device__ __forceinline__ void kmo_gm_commit(const double* s_gm, double* gmat_b, int tid) {
+    if (tid < 9) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < KMO_NW; ++w) s += s_gm[w * 9 + tid];
+        if (s != 0.0 && !(CM == KM_COORD_AFFINE && tid >= 6)) km_atomic_add(gmat_b + tid, s);
+    }
+}
+
+// A tile whose requests have arrived: source tile -> LDS, exact maximum of |grad_out| over its box, coordinate tables
+template <typename T, int CM, int CC>
+__device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const KmoTile& d, const int* rec, const float (&G)[KMO_SLOTS][CC],
+                                          const float (&S)[CC * KMO_PLANE / KMO_NT], const KmoLds& l, const float (&fillv)[CC], bool is_fill, int lane, int wave) {
+    // (no early exit for a tile this launch does not own: every path through here must CONSUME the slots and the source registers,
+    // or the compiler - which cannot know that nothing was requested for such a tile - waits for them later, inside the scatter, with
+    // a wait that also covers the next tile's requests)
+    kmo_store_src<CC>(d, S, l.s_src, fillv, is_fill);
+    uint32_t mb = 0;
+#pragma unroll
+    for (int s = 0; s < KMO_SLOTS; ++s)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) mb = max(mb, __float_as_uint(G[s][c]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_down((int)mb, off, 64));
+    if (lane == 0) l.s_red[wave] = mb;
+    if (d.t >= 0 && d.regular && d.nq > 0) {
+        float m[9];
+        kmo_matrix(rec, m);
+        (void)kmo_fill_tables<CM>(a.g, m, d.j0, d.bw, d.i0, d.i1 - d.i0 + 1, l.s_u4, l.s_v4);
+    }
+}
+
+// ---- launch 2: the persistent loop over the regular tiles -------------------------------------------------------------------------
+template <typename T, int CM, int ALIGN, int CC>
+__global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_bwd_fused_kernel(const KmWarpFusedArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KmWarpGeom<float>& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const KmoLds l = kmo_carve<CC>(smem_raw);
+    const KmoConsts kc = kmo_consts<ALIGN>(g);
+    const bool is_fill = (g.pad == KM_PAD_FILL);
+    float fillv[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
+    const size_t dst_plane = (size_t)g.h * g.w;
+
+    // ---- prologue: records of the first tiles, accumulators zeroed, the first tile requested and staged ----
+    if (wave == 0) kmo_fetch_boxes(a, 0u, lane, l.s_box);
+    for (int e = tid; e < CC * KMO_PLANE / 4; e += KMO_NT) ((int4*)l.s_acc)[e] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    KmoTile cur;
+    kmo_describe(a, kmo_tile_of(a, 0u), kmo_ring(l.s_box, 0u), cur);
+    float G[KMO_SLOTS][CC];             // grad_out of this thread's pixels: the current tile's, refilled slot by slot with the next tile's
+    float S[CC * KMO_PLANE / KMO_NT];   // this thread's part of the source tile on its way to LDS
+#pragma unroll
+    for (int k = 0; k < CC * KMO_PLANE / KMO_NT; ++k) S[k] = 0.f;
+    {
+        const T* gout_c[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) gout_c[c] = a.gout;
+        KmoWalk w0;
+        kmo_walk_init(a, cur, w0);
+        if (cur.t >= 0 && cur.regular) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)cur.b * g.C + (size_t)c) * dst_plane;
+            kmo_issue_src<T, CC>(a, cur, S);
+        } else {
+            w0.nq = 0;
+        }
+#pragma unroll
+        for (int s = 0; s < KMO_SLOTS; ++s) kmo_request_slot<T, CC>(gout_c, g.w, s, w0, G[s]);
+    }
+    float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int pending_b = -1;      // image whose matrix-gradient partials sit in s_gm
+    KmoTile prev = KmoTile{};  // the tile whose accumulators wait to be flushed
+    prev.t = -1;
+    float prev_inv_scale = 1.f;
+
+    for (uint32_t q = 0; cur.t >= 0; ++q) {
+        // ---- this tile's requests have arrived: source tile -> LDS, exact maximum of |grad_out|, coordinate tables - consumed BEFORE
+        //      the flush of the previous tile issues its stores (a wait for loads that has stores behind it in the queue waits for those too)
+        kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, fillv, is_fill, lane, wave);
+        // ---- flush of the previous tile (zeroes the accumulators) ----
+        if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale);
+        if (wave == 0 && (q + 1u) % KMO_RUN == 0u) kmo_fetch_boxes(a, q + 1u, lane, l.s_box);  // (into the half of the ring tile q is not in)
+        KM_LDS_BARRIER();  // B1: source tile, maxima, tables in LDS, accumulators zero
+
+        // ---- the NEXT tile: its source tile is requested now, its grad_out slot by slot during the scatter ----
+        KmoTile nxt;
+        kmo_describe(a, kmo_tile_of(a, q + 1u), kmo_ring(l.s_box, q + 1u), nxt);
+        const T* gout_n[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) gout_n[c] = a.gout;
+        KmoWalk wn;
+        kmo_walk_init(a, nxt, wn);
+        if (nxt.t >= 0 && nxt.regular) {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) gout_n[c] = a.gout + ((size_t)nxt.b * g.C + (size_t)c) * dst_plane;
+        } else {
+            wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
+        }
+        // matrix-gradient partials of the image finished before this tile
+#ifndef EXP_NOCOMMIT
+        if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
+#endif
+        pending_b = -1;
+
+        // ---- scatter + matrix-gradient terms (the slots are refilled with the next tile's pixels as they are consumed) ----
+        float scale = 1.f, inv_scale = 1.f;
+        bool mine = cur.regular;  // this launch writes the tile
+        if (cur.regular) {
+            uint32_t Mb = l.s_red[0];
+#pragma unroll
+            for (int w = 1; w < KMO_NW; ++w) Mb = max(Mb, l.s_red[w]);
+            Mb = (uint32_t)kmt_uniform((int)Mb);
+            if (Mb >= 0x7f800000u) {
+                // NaN / inf in the box: IEEE float accumulation is the general launch's; mark the tile and leave it alone
+                mine = false;
+#ifndef EXP_NOFLAG
+                if (tid == 0) a.ws[(size_t)cur.t * KMO_BOX_INTS + 5] = (cur.fixed_ok ? KMO_F_FIXED : 0) | KMO_F_REGULAR | KMO_F_NONFINITE;
+#endif
+            } else {
+                kmo_scale(__uint_as_float(Mb), cur.hb, scale, inv_scale);
+            }
+        }
+        {
+            float m[9];
+            kmo_matrix(kmo_ring(l.s_box, q), m);
+            kmo_process<T, CM, ALIGN, CC, true, true>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, l.s_src, scale, A, g.w, wn, gout_n, mine, a, nxt, S);
+        }
+        KM_LDS_BARRIER();  // B2: every contribution is in the accumulators; the tables, s_red and the source tile are free
+
+        // ---- an image that ends here publishes its matrix-gradient partials ----
+        if (nxt.t < 0 || nxt.b != cur.b) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double s = km_wave_sum((double)A[k]);
+                if (lane == 0) l.s_gm[wave * 9 + k] = s;
+                A[k] = 0.f;
+            }
+            pending_b = cur.b;
+        }
+        prev = cur;
+        if (!mine) prev.t = -1;
+        prev_inv_scale = inv_scale;
+        cur = nxt;
+    }
+    if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale);
+    // ---- epilogue: the last image's partials ----
+    __syncthreads();
+    if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
+}
+
+// ---- launch 3: the tiles the persistent loop left (class "general", or a non-finite gradient met at run time) ---------------------
+// Workgroup w looks at the records of tiles 64 w .. 64 w + 63 (lane = tile, one ballot) and walks the marked ones.
+template <typename T, int CM, int ALIGN, int CC>
+__global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWarpFusedArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ unsigned long long s_todo;
+    const KmWarpGeom<float>& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const KmoLds l = kmo_carve<CC>(smem_raw);
+    const KmoConsts kc = kmo_consts<ALIGN>(g);
+    const bool is_fill = (g.pad == KM_PAD_FILL);
+    float fillv[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
+    const uint32_t t0 = blockIdx.x * 64u;
+    if (wave == 0) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        int fl = KMO_F_REGULAR;
+        if (t < a.ntiles) fl = a.ws[(size_t)t * KMO_BOX_INTS + 5];
+        const unsigned long long todo = __ballot(!(fl & KMO_F_REGULAR) || (fl & KMO_F_NONFINITE));
+        if (lane == 0) s_todo = todo;
+    }
+    __syncthreads();
+    unsigned long long todo = s_todo;
+    if (todo == 0ull) return;  // (block-uniform)
+    for (int e = tid; e < CC * KMO_PLANE / 4; e += KMO_NT) ((int4*)l.s_acc)[e] = make_int4(0, 0, 0, 0);
+    for (int k = 0; k < 64; ++k) {
+        if (!((todo >> k) & 1ull)) continue;
+        const int t = (int)t0 + k;
+        KmoTile d;
+        float m[9];
+        kmo_describe(a, t, a.ws + (size_t)t * KMO_BOX_INTS, d);
+        kmo_matrix(a.ws + (size_t)t * KMO_BOX_INTS, m);
+        __syncthreads();  // the previous tile's flush is done with the accumulators, its readers with the source tile
+        {
+            float S[CC * KMO_PLANE / KMO_NT];
+            kmo_issue_src<T, CC>(a, d, S);
+            kmo_store_src<CC>(d, S, l.s_src, fillv, is_fill);
+        }
+        __syncthreads();
+        float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        float inv_scale = 1.f;
+        bool finite = true;
+        kmo_general_tile<T, CM, ALIGN, CC>(a, m, d, kc, l.s_u4, l.s_v4, l.s_acc, l.s_src, l.s_red, A, inv_scale, finite);
+        __syncthreads();
+        kmo_flush<T, CC>(a, d, l.s_acc, finite, inv_scale);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double s = km_wave_sum((double)A[i]);
+            if (lane == 0) l.s_gm[wave * 9 + i] = s;
+        }
+        __syncthreads();
+        kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : d.b) * 9, tid);
+    }
+}
+
+template <typename T, int CM, int ALIGN, int CC>
+static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
+    constexpr int lds = kmo_lds_bytes(CC);
+    static bool attr_set = false;  // (idempotent: a race sets the same values twice)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)km_warp_bwd_general_kernel<T, CM, ALIGN, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { km_set_error("km_warp2d_bwd(fused): hipFuncSetAttribute(%d bytes of LDS) failed: %s", lds, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((km_warp_bwd_boxes_kernel<T, CM>), dim3((a.ntiles + 255u) / 256u), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
+    hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC>), dim3((a.ntiles + 63u) / 64u), dim3(KMO_NT), (size_t)lds, s, a);
+    return km_check_launch("km_warp2d_bwd(fused)");
+}
+template <typename T, int CM>
+static int kmo_launch(const KmWarpFusedArgs<T>& a, hipStream_t s) {
+    if (a.g.C == 3) return a.g.align ? kmo_launch_k<T, CM, 1, 3>(a, s) : kmo_launch_k<T, CM, 0, 3>(a, s);
+    return a.g.align ? kmo_launch_k<T, CM, 1, 1>(a, s) : kmo_launch_k<T, CM, 0, 1>(a, s);
+}
+
+template <typename T>
+static int kmo_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, void* ws, int B, int C, int H, int W, int h, int w, int B_M,
+                   int coord_mode, int norm_coords, int pad, int align, const void* fill, hipStream_t s) {
+    KmWarpFusedArgs<T> a;
+    a.gout = (const T*)gout; a.src = (const T*)src; a.mat = (const float*)mat; a.gsrc = (float*)gsrc; a.gmat = gmat; a.fill = (const float*)fill;
+    a.ws = (int*)ws;
+    KmWarpGeom<float>& g = a.g;
+    km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, KM_INTERP_BILINEAR, pad, align);
+    a.tiles_x = (uint32_t)((W + KMT_TW - 1) / KMT_TW);
+    a.tiles_y = (uint32_t)((H + KMO_TH - 1) / KMO_TH);
+    const uint64_t ntiles = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
+    KM_REQUIRE(ntiles < (1ull << 26), "km_warp2d_bwd: grid too large");
+    if (ntiles == 0) return 0;
+    a.ntiles = (uint32_t)ntiles;
+    const int cus = km_device_cus();
+    const uint32_t workers_max = cus > 0 ? (uint32_t)cus * KMO_WG_PER_CU : 3u;  // (the host build of the kernels reports 0 CUs: a few workers, several tiles each)
+    // a run = a row of tiles of one image when that still gives every CU several runs; single tiles otherwise
+    const uint64_t rows = (uint64_t)a.tiles_y * (uint64_t)B;
+    a.run_len = (rows >= 4ull * workers_max) ? a.tiles_x : 1u;
+    a.nruns = (uint32_t)(ntiles / a.run_len);
+    a.nworkers = (uint32_t)((uint64_t)a.nruns < (uint64_t)workers_max ? a.nruns : workers_max);
+    a.reverse = km_traversal_next(s);
+    a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(float));
+    switch (coord_mode) {
+        case KM_COORD_PERSPECTIVE: return kmo_launch<T, KM_COORD_PERSPECTIVE>(a, s);
+        case KM_COORD_AFFINE: return kmo_launch<T, KM_COORD_AFFINE>(a, s);
+        default: return kmo_launch<T, KM_COORD_HOMOGRAPHY>(a, s);
+    }
+}
+
+// 1 if the one-read kernel computes both gradients for these modes (bilinear, zeros / fill padding, fp32 compute, grey or RGB)
+int km_warp_bwd_fused_supported(int interp, int pad, int dtype, int C, int H, int W, int h, int w) {
+    if (!km_config().warp_bwd_fused) return 0;
+    if (!(interp == KM_INTERP_BILINEAR && (pad == KM_PAD_ZEROS || pad == KM_PAD_FILL) && dtype != KM_F64)) return 0;
+    if (!(C == 1 || C == 3)) return 0;
+    // 32-bit byte offsets inside a plane
+    return ((uint64_t)H * W * 4 < (1ull << 32) && (uint64_t)h * w * 4 < (1ull << 32)) ? 1 : 0;
+}
+
+// bytes of workspace the one-read backward needs for these sizes (one 32-byte record per 64 x 64 tile of the source)
+size_t km_warp_bwd_fused_workspace(int B, int H, int W) {
+    const uint64_t ntiles = (uint64_t)((W + KMT_TW - 1) / KMT_TW) * (uint64_t)((H + KMO_TH - 1) / KMO_TH) * (uint64_t)B;
+    return (size_t)(ntiles * KMO_BOX_INTS * sizeof(int));
+}
+
+int km_warp_bwd_fused_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, void* ws, int B, int C, int H, int W, int h, int w,
+                          int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case KM_F32: return kmo_run<float>(gout, src, mat, gsrc, gmat, ws, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+#ifndef KMO_DEV_F32_ONLY  // (development builds: one storage type compiles in a third of the time)
+        case KM_BF16: return kmo_run<km_bf16>(gout, src, mat, gsrc, gmat, ws, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+        default: return kmo_run<km_f16>(gout, src, mat, gsrc, gmat, ws, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, s);
+#else
+        default: return -1;
+#endif
+    }
+}

@@ -181,9 +181,7 @@ static void kmg_launch_nc(const KmWarpGmArgs<T>& a, hipStream_t s) {
         hipLaunchKernelGGL((km_warp_gm_kernel<T, CM, NC, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
 }
 static int kmg_algo() {  // KM_WARP_GM_ALGO: "generic" | "lds" (LDS-staged kernel, A/B timing) | default: the lean gather kernel
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("KM_WARP_GM_ALGO"); v = (e && e[0] == 'l') ? 1 : 0; }
-    return v;
+    return km_config().warp_gm_algo == 2 ? 1 : 0;
 }
 template <typename T, int CM, int NC>
 static void kmg_lds_launch_nc(const KmWarpGmArgs<T>& a, hipStream_t s) {
@@ -223,7 +221,7 @@ static int kmg_run(const void* gout, const void* src, const void* mat, double* g
     KM_REQUIRE(nb < (1ull << 31), "km_warp2d_bwd: grid too large");
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
-    a.reverse = km_traversal_next();
+    a.reverse = km_traversal_next(s);
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmg_launch<T, KM_COORD_PERSPECTIVE>(a, s);
         case KM_COORD_AFFINE: return kmg_launch<T, KM_COORD_AFFINE>(a, s);
@@ -233,12 +231,7 @@ static int kmg_run(const void* gout, const void* src, const void* mat, double* g
 
 // 1 if this kernel computes the matrix gradient for these modes (bilinear, zeros / fill padding, fp32 compute)
 int km_warp_gm_supported(int interp, int pad, int dtype, int H, int W, int h, int w) {
-    static int disabled = -1;
-    if (disabled < 0) {
-        const char* e = getenv("KM_WARP_GM_ALGO");  // "generic": the atomic scatter kernel computes it (A/B timing)
-        disabled = (e && e[0] == 'g') ? 1 : 0;
-    }
-    if (disabled) return 0;
+    if (km_config().warp_gm_algo == 1) return 0;  // KM_WARP_GM_ALGO=generic: the atomic scatter kernel computes it (A/B timing)
     if (!(interp == KM_INTERP_BILINEAR && (pad == KM_PAD_ZEROS || pad == KM_PAD_FILL) && dtype != KM_F64)) return 0;
     if (W < 2) return 0;  // the pair loads need two columns
     // 32-bit byte offsets inside a plane

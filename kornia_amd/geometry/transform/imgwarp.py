@@ -103,10 +103,16 @@ class _Warp2dFunction(torch.autograd.Function):
             gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
         gm = torch.zeros(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
         gmat = None
+        # both gradients wanted: a workspace lets the library take them from one read of grad_out (include/kornia_amd.h)
+        ws, ws_bytes = None, 0
+        if need_src and need_mat:
+            ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, cfg.interp, cfg.pad, N.dtype_code(x.dtype)))
+            if ws_bytes > 0:
+                ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         with N.device_guard(dev):
-            N.check(lib.km_warp2d_bwd(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
-                                      B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),
-                                      N.dtype_code(x.dtype), stream), "km_warp2d_bwd")
+            N.check(lib.km_warp2d_bwd_ws(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
+                                         B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),
+                                         N.dtype_code(x.dtype), N.ptr(ws), ws_bytes, stream), "km_warp2d_bwd_ws")
             if need_mat:
                 if cfg.coord_mode == COORD_HOMOGRAPHY:
                     gmat = gm.view(B_M, 3, 3).to(ctx.mat_dtype)

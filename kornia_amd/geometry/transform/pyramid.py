@@ -12,7 +12,6 @@ Reference behaviour mirrored: kornia/geometry/transform/pyramid.py - pyrdown :40
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional
 
 import torch
@@ -122,7 +121,7 @@ def pyrup(input: torch.Tensor, border_type: str = "reflect", align_corners: bool
     border = _check_border(border_type)
     _, _, height, width = input.shape
     x_up = resize_bilinear(input, (height * 2, width * 2), align_corners)
-    if os.environ.get("KM_PYRDOWN_ALGO", "").startswith("s"):
+    if N.lib().km_config_get(b"pyrdown_separable") == 1:
         # opt-in with the separable pyrdown (csrc/km_pyramid.hip): the rank-1 binomial kernel as the fused 5 + 5 tap blur
         taps = torch.tensor([[1.0, 4.0, 6.0, 4.0, 1.0]], device=input.device, dtype=input.dtype) / 16.0
         return filter2d_separable(x_up, taps, taps, border)

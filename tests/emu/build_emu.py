@@ -25,8 +25,6 @@ CXX = "/opt/rocm/lib/llvm/bin/clang++"
 SUBSTITUTIONS = [
     # dynamic LDS: `extern __shared__` has no host spelling
     ("*", "extern __shared__ __attribute__((aligned(16))) char smem_raw[];", "char* smem_raw = emu::dyn_smem();"),
-    # v_cvt_rpi_i32_f32 = floor(v + 0.5), saturating, NaN -> 0 (emu_cvt_rpi_i32_f32 in hip/hip_runtime.h)
-    ("km_warp_bwd_tiled.hip", 'asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));', "r = emu_cvt_rpi_i32_f32(v);"),
 ]
 
 

@@ -50,6 +50,8 @@ hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDevice(int* dev);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
     memset(p, v, n);
     return hipSuccess;
@@ -114,6 +116,9 @@ inline int emu_cvt_i32_f32(float v) {
     return (int)v;
 }
 #define KM_F2I(v) emu_cvt_i32_f32(v)
+#define KM_CVT_RPI(v) emu_cvt_rpi_i32_f32(v)
+#define KM_LDS_BARRIER() __syncthreads()
+#define KM_SCHED_FENCE() ((void)0)
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 

@@ -303,12 +303,17 @@ def test_half_precision_blur_strip_heights(dtype, K, border, shape, monkeypatch)
     x = torch.rand(*shape, generator=g).to(dtype).cuda()
     kx, ky = torch.rand(1, K, generator=g).cuda(), torch.rand(1, K, generator=g).cuda()
     go = torch.rand(*shape, generator=g).to(dtype).cuda()
+    from kornia_amd import _native as N
+
     res = {}
     for rows in ("8", "32"):
-        monkeypatch.setenv("KM_BLUR_ROWS", rows)
-        xg = x.clone().requires_grad_()
-        out = K_.filter2d_separable(xg, kx, ky, border)
-        out.backward(go)
+        prev = N.lib().km_config_set(b"blur_rows", int(rows))  # (the KM_BLUR_ROWS switch: read once at load, set explicitly here)
+        try:
+            xg = x.clone().requires_grad_()
+            out = K_.filter2d_separable(xg, kx, ky, border)
+            out.backward(go)
+        finally:
+            N.lib().km_config_set(b"blur_rows", prev)
         res[rows] = (out.detach(), xg.grad)
     assert torch.equal(res["8"][0], res["32"][0]) and torch.equal(res["8"][1], res["32"][1])
     ref = K_.filter2d_separable(x.float(), kx, ky, border)
@@ -326,8 +331,9 @@ def test_register_tiled_blur_fast_path(oracle, border, Bk, K, shape, rows, monke
     the adjoint against the oracle's scatter-form adjoint.  KM_BLUR_ROWS: see test_half_precision_blur_strip_heights (fp32 always
     takes 32-row strips; the variable must not change anything here)."""
     import kornia_amd as K_
+    from kornia_amd import _native as N
 
-    monkeypatch.setenv("KM_BLUR_ROWS", rows)
+    N.lib().km_config_set(b"blur_rows", int(rows))  # (the autouse fixture at the end of this file restores the default)
 
     B, C, H, W = shape
     g = torch.Generator().manual_seed(7)
@@ -361,3 +367,16 @@ def test_blur_adjoint_identity_at_full_size():
         ones = torch.ones(1, 1, 512, 512, device="cuda")
         if border != "constant":  # blur of a constant image is the same constant (taps sum to 1)
             assert torch.allclose(K_.gaussian_blur2d(ones, (5, 5), (1.5, 1.5), border), ones, atol=1e-6)
+
+
+@pytest.fixture(autouse=True)
+def _reset_launch_policy():
+    """Tests above switch launch-policy entries of the library (km_config_set); every test leaves the defaults behind."""
+    yield
+    from kornia_amd import _native as N
+
+    if N.is_built():
+        try:
+            N.lib().km_config_set(b"blur_rows", 0)
+        except Exception:
+            pass

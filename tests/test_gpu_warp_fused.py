@@ -1,0 +1,189 @@
+"""GPU: the one-read backward of the bilinear warps (csrc/km_warp_bwd_fused.hip: km_warp2d_bwd_ws with a workspace) - both gradients
+from one pass over grad_out - against the CPU oracle and against the two-launch form it replaces.  Also runs on the host build of the
+kernels (tests/test_emulated_kernels.py)."""
+import pytest
+import torch
+
+from _util import flagship_homographies, rotation_affines, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from kornia_amd import _native as N
+
+    return N.lib()
+
+
+def _run(fn, x, M, go, fused, **kw):
+    """(grad_x, grad_M) of fn(x, M, ...) through the public API with the one-read backward on / off"""
+    lib = _lib()
+    prev = lib.km_config_set(b"warp_bwd_fused", 1 if fused else 0)
+    try:
+        xg, Mg = x.cuda().requires_grad_(), M.cuda().requires_grad_()
+        fn(xg, Mg, **kw).backward(go.cuda())
+    finally:
+        lib.km_config_set(b"warp_bwd_fused", prev)
+    return xg.grad.cpu(), Mg.grad.cpu()
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().amax(dim=(-2, -1)) / b.double().abs().amax(dim=(-2, -1)).clamp_min(1e-30)).max().item()
+
+
+@pytest.mark.parametrize("C", [3, 1])
+@pytest.mark.parametrize("pad", ["zeros", "fill"])
+@pytest.mark.parametrize("shape", [(2, 128, 192, 128, 192), (3, 200, 130, 150, 170), (2, 70, 66, 90, 61)])
+def test_both_gradients_from_one_read_match_the_oracle(oracle, shape, pad, C):
+    """warp_perspective, several tiles per image, ragged right / bottom tiles: grad wrt the image <= 1e-5 of the oracle (the exact
+    fixed-point scale makes it tighter than the two launches'), grad wrt the matrix to 5e-5 of the fp32 oracle that shares the kernel's
+    sampling positions."""
+    import kornia_amd as K
+
+    if pad == "fill" and C != 3:
+        pytest.skip("fill_value is RGB in the reference")
+    B, H, W, h, w = shape
+    g = torch.Generator().manual_seed(B * H + w)
+    x = torch.rand(B, C, H, W, generator=g)
+    M = flagship_homographies(B, H, W, h, w, g, jitter=6.0)
+    go = torch.rand(B, C, h, w, generator=g) - 0.4
+    kw = {}
+    if pad == "fill":
+        kw = dict(padding_mode="fill", fill_value=torch.tensor([0.2, 0.5, 0.7]))
+    gx, gM = _run(lambda a, m: K.warp_perspective(a, m, (h, w), **kw), x, M, go, True)
+    gx2, gM2 = _run(lambda a, m: K.warp_perspective(a, m, (h, w), **kw), x, M, go, False)
+    gxo, gMo = oracle.warp_perspective_backward(go, x, M, (h, w), **kw)
+    assert torch.allclose(gx, gxo, atol=1e-5, rtol=0), (gx - gxo).abs().max()
+    assert _rel(gM, gMo) <= 5e-5
+    # the two forms agree with each other (they differ by the rounding of the fixed-point scale and the order of the fp64 sums)
+    assert torch.allclose(gx, gx2, atol=5e-6 * go.abs().max().item(), rtol=0)  # each within 2e-6 max|grad_out| of the exact sum
+    assert _rel(gM, gM2) <= 5e-5
+
+
+def test_affine_and_homography_modes(oracle):
+    """The other two coordinate generators (warp_affine with and without align_corners, homography_warp) through the one-read backward."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, h, w = 3, 3, 140, 200, 120, 180
+    x = smooth_image(B, C, H, W) + 0.05 * torch.rand(B, C, H, W, generator=g)
+    go = torch.rand(B, C, h, w, generator=g)
+    A = rotation_affines(B, H, W, g)
+    A[:, :, :2] *= 0.3 * torch.rand(B, 1, 1, generator=g) + 0.85  # keep the boxes of the tiles small enough for the persistent loop
+    for align in (True, False):
+        gx, gA = _run(lambda a, m: K.warp_affine(a, m, (h, w), align_corners=align), x, A, go, True)
+        gxo, gAo = oracle.warp_affine_backward(go, x, A, (h, w), align_corners=align)
+        assert torch.allclose(gx, gxo, atol=1e-5, rtol=0)
+        assert _rel(gA, gAo) <= 5e-5
+    Hn = torch.eye(3)[None] + 0.03 * torch.randn(B, 3, 3, generator=g)
+    gx, gH = _run(lambda a, m: K.homography_warp(a, m, (h, w)), x, Hn, go, True)
+    gx2, gH2 = _run(lambda a, m: K.homography_warp(a, m, (h, w)), x, Hn, go, False)
+    assert torch.allclose(gx, gx2, atol=5e-6, rtol=0)
+    assert _rel(gH, gH2) <= 5e-5
+
+
+def test_more_tiles_than_workers():
+    """Every workgroup of the persistent launch walks SEVERAL tiles: the register prefetch of tile k + 1 during tile k, the ring of tile
+    records (more than 64 tiles per worker on the host build), runs that span images.  Against the two launches on the same inputs."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(9)
+    # the device has 256 workers (one per CU): 24 x 64 tiles = 6 per worker; the host build has 3 workers: 5 x 63 tiles = 105 per worker
+    B, H, W = (24, 512, 512) if _lib().km_device_info(None, 0) > 0 else (5, 400, 560)
+    x = torch.rand(B, 3, H, W, generator=g)
+    M = flagship_homographies(B, H, W, H, W, g, jitter=8.0)
+    go = torch.rand(B, 3, H, W, generator=g)
+    gx, gM = _run(lambda a, m: K.warp_perspective(a, m, (H, W)), x, M, go, True)
+    gx2, gM2 = _run(lambda a, m: K.warp_perspective(a, m, (H, W)), x, M, go, False)
+    assert torch.allclose(gx, gx2, atol=5e-6, rtol=0), (gx - gx2).abs().max()
+    assert _rel(gM, gM2) <= 5e-5
+
+
+def test_shared_matrix_accumulates_over_the_batch(oracle):
+    """One (1,3,3) matrix for the whole batch: every image's share of the matrix gradient lands in the same nine accumulators."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(4, 3, 96, 150, generator=g)
+    M = flagship_homographies(1, 96, 150, 96, 150, g, jitter=3.0)
+    go = torch.rand(4, 3, 96, 150, generator=g)
+    gx, gM = _run(lambda a, m: K.warp_perspective(a, m.expand(4, 3, 3), (96, 150)), x, M, go, True)
+    gxo, gMo = oracle.warp_perspective_backward(go, x, M.expand(4, 3, 3), (96, 150))
+    assert torch.allclose(gx, gxo, atol=1e-5, rtol=0)
+    assert _rel(gM, gMo.sum(0, keepdim=True)) <= 5e-5
+
+
+@pytest.mark.parametrize("case", ["minify", "magnify", "nonfinite", "vanishing"])
+def test_tiles_of_the_general_launch(oracle, case):
+    """Tiles the persistent loop leaves to the general launch: boxes that do not fit its registers (2.2x minification), magnification
+    beyond the fixed-point head-room, NaN / inf in grad_out (IEEE propagation like the oracle's), the vanishing line inside the image."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(11)
+    B, C = 2, 3
+    if case == "minify":
+        H, W, h, w = 192, 256, 80, 112
+    elif case == "magnify":
+        H, W, h, w = 24, 20, 200, 180
+    else:
+        H, W, h, w = 128, 128, 128, 128
+    x = torch.rand(B, C, H, W, generator=g)
+    M = flagship_homographies(B, H, W, h, w, g, jitter=2.0)
+    if case == "vanishing":
+        M = torch.eye(3).repeat(B, 1, 1)
+        M[:, 2, 0] = 1.0 / 90.0   # the denominator vanishes on a line that crosses the image
+        M[:, 2, 2] = -0.35
+    go = torch.rand(B, C, h, w, generator=g) - 0.5
+    if case == "nonfinite":
+        go[0, 1, 40, 50] = float("nan")
+        go[1, 2, 70, 3] = float("inf")
+    gx, gM = _run(lambda a, m: K.warp_perspective(a, m, (h, w)), x, M, go, True)
+    gx2, gM2 = _run(lambda a, m: K.warp_perspective(a, m, (h, w)), x, M, go, False)
+    if case == "nonfinite":
+        gxo, _ = oracle.warp_perspective_backward(go, x, M, (h, w))
+        assert torch.equal(torch.isnan(gx), torch.isnan(gxo)) and torch.equal(torch.isinf(gx), torch.isinf(gxo))
+        fin = torch.isfinite(gxo)
+        assert torch.allclose(gx[fin], gxo[fin], atol=1e-5, rtol=0)
+        assert torch.isnan(gM).any()
+        return
+    fin = torch.isfinite(gx2)
+    assert torch.equal(torch.isfinite(gx), fin)
+    scale = max(1.0, gx2[fin].abs().max().item())
+    assert torch.allclose(gx[fin], gx2[fin], atol=2e-5 * scale, rtol=0), (gx[fin] - gx2[fin]).abs().max()
+    if torch.isfinite(gM2).all():
+        assert _rel(gM, gM2) <= 2e-4
+
+
+def test_workspace_contract():
+    """km_warp2d_bwd_workspace_bytes is 0 for what the one-read backward does not cover; a short or missing workspace falls back to the
+    two launches with the same results; the workspace is not needed after the call."""
+    import kornia_amd as K
+    from kornia_amd import _native as N
+
+    lib = _lib()
+    B, C, H, W = 2, 3, 130, 140
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 0, 0) == 80 * B * 3 * 3  # one 80-byte record per 64 x 64 tile
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 2, 0, 0) == 0   # bicubic
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 1, 0) == 0   # border padding
+    assert lib.km_warp2d_bwd_workspace_bytes(B, 4, H, W, H, W, 1, 0, 0) == 0   # RGBA: the two launches
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 0, 1) == 0   # fp64
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, C, H, W, generator=g).cuda()
+    M = flagship_homographies(B, H, W, H, W, g, jitter=3.0)
+    go = torch.rand(B, C, H, W, generator=g).cuda()
+    m = K.geometry.conversions._ChainFunction.apply(M.cuda(), (H, W), (H, W), True).contiguous()
+    stream = N.stream_ptr(x.device)
+    need = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 0, 0))
+    outs = []
+    for ws_bytes in (need, need - 16, 0):
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8).cuda()
+        gsrc = torch.empty(B, C, H, W).cuda()
+        gm = torch.zeros(B, 9, dtype=torch.float64).cuda()
+        N.check(lib.km_warp2d_bwd_ws(go.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, H, W, B, 0, 1, 1, 0, 1, None, 0,
+                                     ws.data_ptr() if ws_bytes else None, ws_bytes, stream), "bwd")
+        ws.fill_(255)  # not read after the call
+        torch.cuda.synchronize()
+        outs.append((gsrc.cpu(), gm.cpu()))
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])  # short workspace == no workspace (two launches)
+    assert torch.allclose(outs[0][0], outs[2][0], atol=5e-6, rtol=0)
+    assert _rel(outs[0][1].view(B, 3, 3), outs[2][1].view(B, 3, 3)) <= 5e-5

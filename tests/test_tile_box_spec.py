@@ -1,4 +1,4 @@
-"""CPU: executable specification of the owner-tile box (kmt_tile_box, kornia_amd/csrc/km_warp_bwd_tiled.hip).
+"""CPU: executable specification of the owner-tile box (kmt_tile_box, kornia_amd/csrc/km_warp_tile.h).
 
 The backward scatter is only correct if the box of output pixels a workgroup visits contains EVERY output pixel whose
 bilinear footprint touches its source tile.  The kernel source between the `[host-testable ...]` markers is extracted
@@ -60,7 +60,7 @@ def _build(name, mutate=None):
     os.makedirs(BUILD, exist_ok=True)
     src = os.path.join(BUILD, name + ".cpp")
     so = os.path.join(BUILD, "lib" + name + ".so")
-    box = _span(os.path.join(CSRC, "km_warp_bwd_tiled.hip"), "tile_box")
+    box = _span(os.path.join(CSRC, "km_warp_tile.h"), "tile_box")
     if mutate is not None:
         box = mutate(box)
     code = SHIM + _span(os.path.join(CSRC, "km_sampler.h"), "coords") + "\n#define KMT_TIGHT_BOX 1\n" + box + WRAP

@@ -172,22 +172,24 @@ def test_reference_own_pyramid_cases():
 
 
 def test_separable_pyrdown_variant(oracle, monkeypatch):
-    """KM_PYRDOWN_ALGO=separable (opt-in, csrc/km_pyramid.hip): the 5 + 5 tap evaluation of the factor-2 path agrees with the
+    """pyrdown_separable (KM_PYRDOWN_ALGO=separable at load, km_config_set here) (opt-in, csrc/km_pyramid.hip): the 5 + 5 tap evaluation of the factor-2 path agrees with the
     25-tap chain to a few ulp, in every border mode and storage dtype; without the variable the default stays bit-identical."""
+    from kornia_amd import _native as _N
+
     g = torch.Generator().manual_seed(11)
     x = torch.rand(2, 3, 70, 264, generator=g) * 2 - 0.5
     for border in BORDERS:
         ref = oracle.pyrdown(x, border)
-        monkeypatch.setenv("KM_PYRDOWN_ALGO", "separable")
+        _N.lib().km_config_set(b"pyrdown_separable", 1)
         sep = T().pyrdown(x.cuda(), border).cpu()
         up = T().pyrup(x[:, :, :20, :40].cuda(), border).cpu()
-        monkeypatch.delenv("KM_PYRDOWN_ALGO")
+        _N.lib().km_config_set(b"pyrdown_separable", 0)
         assert torch.allclose(sep, ref, atol=1e-6, rtol=0) and not torch.equal(sep, ref)
         assert torch.allclose(up, oracle.pyrup(x[:, :, :20, :40], border), atol=1e-6, rtol=0)
         assert torch.equal(T().pyrdown(x.cuda(), border).cpu(), ref)
     for dt in (torch.bfloat16, torch.float16):
         xh = x.clamp(0, 1).to(dt)
-        monkeypatch.setenv("KM_PYRDOWN_ALGO", "separable")
+        _N.lib().km_config_set(b"pyrdown_separable", 1)
         out = T().pyrdown(xh.cuda()).cpu()
-        monkeypatch.delenv("KM_PYRDOWN_ALGO")
+        _N.lib().km_config_set(b"pyrdown_separable", 0)
         assert out.dtype == dt and (out.float() - oracle.pyrdown(xh.float())).abs().max().item() <= 1e-2
