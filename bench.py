@@ -93,74 +93,88 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_roofline(x, M, go, size, iters):
+def kernel_roofline(sets, size, iters):
     """Times every launch of the step and the four public ops by calling the C ABI directly (pre-allocated buffers, no allocator /
-    autograd in the timed loop).  Returns (per-launch stats, per-op stats)."""
+    autograd in the timed loop).  Like the step, every timed call works on the NEXT of the input sets (each with its own intermediate
+    tensors), under the product's launch policy: nothing a call finds in the 256 MB Infinity Cache was left there by the previous call
+    of the loop.  Returns (per-launch stats, per-op stats)."""
     from kornia_amd import _native as N
     from kornia_amd.filters.gaussian import _cached_taps
 
     lib = N.lib()
-    dev = x.device
-    B, C, H, W = x.shape
+    dev = sets[0][0].device
+    B, C, H, W = sets[0][0].shape
     h = w = size
     stream = N.stream_ptr(dev)
-    m = torch.empty(B, 9, device=dev)
-    N.check(lib.km_homography_chain_fwd(M.data_ptr(), 3, None, m.data_ptr(), B, H, W, h, w, 0, stream), "chain")
-    warped = torch.empty(B, C, h, w, device=dev)
-    blurred = torch.empty_like(warped)
-    gw = torch.empty_like(warped)
-    gsrc = torch.zeros_like(x)
-    gm = torch.zeros(B, 9, device=dev, dtype=torch.float64)
     kx, ky = _cached_taps(5, 5, (1.5, 1.5), torch.float32, dev)
     n_el = B * C * h * w
     e = 4
+    ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, 1, 0, 0))
+    ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+    blurred = torch.empty(B, C, h, w, device=dev)  # outputs nobody reads are shared between the sets
+    gsrc = torch.empty(B, C, H, W, device=dev)
+    gm = torch.zeros(B, 9, device=dev, dtype=torch.float64)
+    bufs = []
+    for x, M, go in sets:
+        x, M = x.detach(), M.detach()
+        m = torch.empty(B, 9, device=dev)
+        N.check(lib.km_homography_chain_fwd(M.data_ptr(), 3, None, m.data_ptr(), B, H, W, h, w, 0, stream), "chain")
+        warped = torch.empty(B, C, h, w, device=dev)
+        gw = torch.empty_like(warped)
+        N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), warped.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wf")
+        N.check(lib.km_filter2d_sep_bwd_input(go.data_ptr(), kx.data_ptr(), ky.data_ptr(), gw.data_ptr(), B, C, h, w, 1, 5, 5, 1, 1, 0, stream), "bb")
+        bufs.append((x, m, go, warped, gw))
+    k = [0]
+
+    def nxt():
+        k[0] += 1
+        return bufs[k[0] % len(bufs)]
 
     def warp_fwd():
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_warp2d_fwd(x.data_ptr(), m.data_ptr(), warped.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wf")
 
     def blur_fwd():
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_filter2d_sep_fwd(warped.data_ptr(), kx.data_ptr(), ky.data_ptr(), blurred.data_ptr(), B, C, h, w, 1, 5, 5, 1, 1, 0, stream), "bf")
 
     def blur_bwd():
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_filter2d_sep_bwd_input(go.data_ptr(), kx.data_ptr(), ky.data_ptr(), gw.data_ptr(), B, C, h, w, 1, 5, 5, 1, 1, 0, stream), "bb")
 
-    def warp_bwd_gsrc():  # tile-owner scatter: grad wrt the image
+    def warp_bwd_gsrc():  # tile-owner scatter: grad wrt the image only
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), None, B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
 
-    def warp_bwd_gmat():  # forward-shaped reduction: grad wrt the homography
+    def warp_bwd_gmat():  # forward-shaped reduction: grad wrt the homography only
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), None, gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wm")
 
     def warp_bwd_two():  # both gradients as two launches (each reads grad_out): the form without a workspace
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_warp2d_bwd(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0, stream), "wb")
 
-    ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, 1, 0, 0))
-    ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-
     def warp_bwd():  # the public op as the Python layer calls it: with a workspace, both gradients from one read of grad_out
+        x, m, go, warped, gw = nxt()
         N.check(lib.km_warp2d_bwd_ws(gw.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, H, W, h, w, B, 0, 1, 1, 0, 1, None, 0,
                                      ws.data_ptr() if ws_bytes else None, ws_bytes, stream), "wb")
 
-    # per LAUNCH: the bytes that launch itself must move (every tensor it reads once + every tensor it writes once); the two
-    # backward launches both read grad_out, so their sum (4e) exceeds the op's algorithmic 3e - which is why the op line exists
-    # Single-kernel loops run with the batch traversal FIXED (km_set_traversal(1)): with the product's alternating direction,
-    # launch k+1 of a loop over ONE input would start on the ~256 MB that launch k just left in the Infinity Cache - a hit rate
-    # no kernel of the real step sees on its own input.  The op loop of km_warp2d_bwd keeps the product's policy (its second
-    # launch reads grad_out where the first one ended, as in the step); the fixed-direction figure is reported beside it.
+    fused = bool(ws_bytes) and lib.km_config_get(b"warp_bwd_fused") == 1
+    # per LAUNCH: the bytes that launch itself must move (every tensor it reads once + every tensor it writes once)
     kernels = {}
-    prev_mode = lib.km_set_traversal(1)
-    for name, fn, nbytes, what in (
+    launches = [
         ("km_warp_fwd_lean_kernel", warp_fwd, 2 * e * n_el, "read src, write out"),
         ("km_blur_reg_kernel<fwd>", blur_fwd, 2 * e * n_el, "read x, write y"),
         ("km_blur_reg_kernel<bwd>", blur_bwd, 2 * e * n_el, "read grad_y, write grad_x"),
-        ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el, "read grad_out, write grad_src"),
-        ("km_warp_gm_kernel", warp_bwd_gmat, 2 * e * n_el, "read grad_out, read src"),
-        ("km_warp_bwd_fused_kernel (+ boxes, general)", warp_bwd, 3 * e * n_el, "read grad_out, read src, write grad_src"),
-    ):
+        ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el, "read grad_out, write grad_src (the image gradient alone)"),
+        ("km_warp_gm_kernel", warp_bwd_gmat, 2 * e * n_el, "read grad_out, read src (the matrix gradient alone)"),
+    ]
+    if fused:
+        launches.append(("km_warp_bwd_fused_kernel (+ boxes, general)", warp_bwd, 3 * e * n_el, "read grad_out, read src, write grad_src: both gradients"))
+    for name, fn, nbytes, what in launches:
         ms = event_time_ms(fn, iters)
         kernels[name] = {"ms": round(ms, 4), "launch_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "moves": what}
     # per PUBLIC OP: SURVEY 8(d)'s algorithmic bytes (compulsory traffic at the API boundary)
-    bwd_fixed_ms = event_time_ms(warp_bwd, iters)
-    lib.km_set_traversal(prev_mode)
     ops = {}
     for name, fn, mult in (("km_warp2d_fwd", warp_fwd, 2), ("km_filter2d_sep_fwd", blur_fwd, 2), ("km_filter2d_sep_bwd_input", blur_bwd, 2),
                            ("km_warp2d_bwd", warp_bwd, 3)):
@@ -169,9 +183,9 @@ def kernel_roofline(x, M, go, size, iters):
                 kernels["km_blur_reg_kernel<bwd>"]["ms"] if name == "km_filter2d_sep_bwd_input" else event_time_ms(fn, iters)))
         nbytes = mult * e * n_el
         ops[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
-    ops["km_warp2d_bwd"]["ms_fixed_traversal"] = round(bwd_fixed_ms, 4)
-    ops["km_warp2d_bwd"]["form"] = "one read of grad_out (km_warp2d_bwd_ws with a workspace)" if ws_bytes and lib.km_config_get(b"warp_bwd_fused") == 1 else "two launches"
+    ops["km_warp2d_bwd"]["form"] = "one read of grad_out (km_warp2d_bwd_ws with a workspace)" if fused else "two launches"
     ops["km_warp2d_bwd"]["ms_two_launches"] = round(event_time_ms(warp_bwd_two, iters), 4)
+    ops["km_warp2d_bwd"]["timing"] = f"{len(bufs)} input sets rotated: no call starts on what the previous call of the loop left in the Infinity Cache"
     return kernels, ops
 
 
@@ -540,7 +554,7 @@ def main():
 
     if rank == 0:
         with torch.no_grad():
-            kstats, ops = kernel_roofline(x.detach(), M.detach(), go, S, max(5, min(args.steps, 20)))
+            kstats, ops = kernel_roofline(sets, S, max(6, min(args.steps, 21)))
         dom_op = max(ops, key=lambda k: ops[k]["ms"])
         dom_kernel = max(kstats, key=lambda k: kstats[k]["ms"])
         # HBM traffic of the dominant op: rocprofv3 PMC cannot run inside this process, so the figure is the committed
@@ -550,7 +564,7 @@ def main():
             pmc = json.load(open(PMC_FILE)).get("kernels", {})
             fused = "one read" in ops["km_warp2d_bwd"].get("form", "")
             want = {"km_warp2d_bwd": ("km_warp_bwd_fused_kernel",) if fused else ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_lean_kernel",),
-                    "km_filter2d_sep_fwd": ("km_blur_reg_kernel<float, 5, false>",), "km_filter2d_sep_bwd_input": ("km_blur_reg_kernel<float, 5, true>",)}[dom_op]
+                    "km_filter2d_sep_fwd": ("km_blur_reg_kernel<float, 5, false",), "km_filter2d_sep_bwd_input": ("km_blur_reg_kernel<float, 5, true",)}[dom_op]
             tot = 0
             for frag in want:
                 hit = [rec["hbm_bytes_per_launch"] for kname, rec in pmc.items() if frag in kname]

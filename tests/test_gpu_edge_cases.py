@@ -120,6 +120,6 @@ def test_batch_traversal_direction_does_not_change_results():
         for _ in range(3):
             got = run()
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-            assert torch.allclose(got[2], ref[2], rtol=1e-6, atol=1e-9)
+            assert (got[2] - ref[2]).abs().max().item() <= 1e-6 * ref[2].abs().max().item()  # fp32 partial sums per thread over the tiles a workgroup walks: the grouping follows the direction
     finally:
         lib.km_set_traversal(prev)
