@@ -32,10 +32,11 @@ from . import _native as N
 from .enhance.adjust import color_jitter as _color_jitter, color_jitter_from_table
 from .filters.filter import filter2d_separable
 from .filters.gaussian import gaussian_blur2d
-from .geometry.transform.builders import get_affine_matrix2d
-from .geometry.transform.imgwarp import _warp_affine_from_chain, warp_affine
+from .geometry.transform.builders import get_affine_matrix2d, get_perspective_transform
+from .geometry.transform.imgwarp import COORD_PERSPECTIVE, _warp, _warp_affine_from_chain, warp_affine, warp_perspective
 
-__all__ = ["affine_chain", "affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "select_samples"]
+__all__ = ["affine_chain", "affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "random_perspective",
+           "select_samples"]
 
 
 def _p(params: Mapping[str, Any], key: str, device) -> torch.Tensor:
@@ -136,6 +137,20 @@ def random_affine(input: torch.Tensor, params: Mapping[str, Any], resample: str 
     size = (input.shape[-2], input.shape[-1])
     out = warp_affine(input, M[:, :2, :], size, resample, padding_mode, align_corners, fill_value)
     return select_samples(out, input, mask)
+
+
+def random_perspective(input: torch.Tensor, params: Mapping[str, Any], resample: str = "bilinear", align_corners: bool = False) -> torch.Tensor:
+    """RandomPerspective.compute_transformation + apply_transform + the batch_prob blend (perspective.py:92-115, base.py:380-393):
+    ``start_points`` / ``end_points`` (B,4,2) -> homography (``km_perspective_transform_fwd``, one launch) -> normalise / invert (one
+    launch) -> warp with the per-sample switch inside its launch (``km_warp2d_fwd_masked``: samples whose draw failed are copied)."""
+    N.require_device(input, "input")
+    dev = input.device
+    M = get_perspective_transform(_p(params, "start_points", dev), _p(params, "end_points", dev))
+    size = (input.shape[-2], input.shape[-1])
+    mask = _apply_mask(params, dev)
+    if mask is not None and input.dim() == 4 and mask.numel() == input.shape[0] and not (torch.is_grad_enabled() and input.requires_grad):
+        return _warp(input, M, size, COORD_PERSPECTIVE, 1, resample, "zeros", align_corners, torch.zeros(3), mask)
+    return select_samples(warp_perspective(input, M, size, resample, "zeros", align_corners), input, mask)
 
 
 def color_jitter(input: torch.Tensor, params: Mapping[str, Any], order: Optional[Sequence[int]] = None) -> torch.Tensor:

@@ -13,6 +13,7 @@ from __future__ import annotations
 import functools
 import importlib
 import sys
+import weakref
 from typing import Callable
 
 import torch
@@ -116,7 +117,17 @@ def _color_jitter_apply(original: Callable) -> Callable:
             return original(self, input, params, flags, transform)
         bf, cf, sf, hf = (params[k].to(input.device) for k in keys)
         enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
-        return _e.color_jitter(input, bf, cf, sf, hf, order, enable=enable)
+        # the per-sample probability switch of transform_inputs (augmentation/base.py:380-393) inside the same launch: a sample whose
+        # draw failed is passed through untouched, and the torch.where pass that follows finds nothing to do (_blend_by_prob below)
+        apply = None
+        if not (getattr(self, "p", 1.0) == 1.0 and getattr(self, "p_batch", 1.0) == 1.0) and not (torch.is_grad_enabled() and input.requires_grad):
+            bp = params.get("batch_prob")
+            if isinstance(bp, torch.Tensor) and bp.numel() == input.shape[0]:
+                apply = torch.atleast_1d(bp.to(input.device) > 0.5)
+        out = _e.color_jitter(input, bf, cf, sf, hf, order, enable=enable, apply=apply)
+        if apply is not None:
+            out._kornia_amd_blended_with = weakref.ref(input)
+        return out
 
     apply_transform.__wrapped__ = original
     return apply_transform
@@ -157,6 +168,11 @@ def _blend_by_prob(original: Callable) -> Callable:
     from .augmentation import select_samples
 
     def blend(transformed, not_transformed, to_apply):
+        # a geometric augmentation whose apply step already carried the per-sample switch inside its warp launch (_geometric_apply):
+        # the samples that are not transformed were copied there, nothing is left to select
+        tag = getattr(transformed, "_kornia_amd_blended_with", None)
+        if tag is not None and tag() is not_transformed:
+            return transformed
         ok = (
             isinstance(transformed, torch.Tensor) and isinstance(not_transformed, torch.Tensor) and isinstance(to_apply, torch.Tensor)
             and _N.on_device(transformed) and _N.on_device(not_transformed) and transformed.shape == not_transformed.shape
@@ -201,6 +217,50 @@ def _gaussian_blur_apply(original: Callable) -> Callable:
     return apply_transform
 
 
+def _geometric_apply(original: Callable, kind: str) -> Callable:
+    """RandomAffine.apply_transform (kornia/augmentation/_2d/geometric/affine.py:143-162) and RandomPerspective.apply_transform
+    (_2d/geometric/perspective.py:100-115) with the per-sample probability switch of ``transform_inputs`` (augmentation/base.py:380-393)
+    folded INTO the warp's launch: the matrix chain (normalise, invert) is one launch, the warp with the switch another
+    (``km_warp2d_fwd_masked`` copies the samples whose ``batch_prob`` draw failed), and the ``torch.where`` pass that follows in the
+    reference finds nothing to do (``_blend_by_prob`` above recognises the result).  The matrix is the one the module hands over
+    (``transform``: what ``compute_transformation`` - already one native launch - produced, or the caller's own in
+    ``inverse_transform``), never re-derived from the parameters.  Anything unusual falls through to the module's own method."""
+    from .geometry.transform.imgwarp import COORD_AFFINE, COORD_PERSPECTIVE, _warp
+
+    @functools.wraps(original)
+    def apply_transform(self, input, params, flags, transform=None):
+        ok = (
+            isinstance(input, torch.Tensor) and isinstance(transform, torch.Tensor) and _N.on_device(input) and _N.on_device(transform)
+            and input.dim() == 4 and input.dtype in _COLOR_DTYPES and transform.dim() == 3 and tuple(transform.shape[-2:]) == (3, 3)
+            and transform.shape[0] == input.shape[0] and transform.dtype in _SUPPORTED
+            and not (torch.is_grad_enabled() and (input.requires_grad or transform.requires_grad))
+            and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
+        )
+        if not ok:
+            return original(self, input, params, flags, transform)
+        B, _, height, width = input.shape
+        apply = None
+        if not (getattr(self, "p", 1.0) == 1.0 and getattr(self, "p_batch", 1.0) == 1.0):
+            bp = params.get("batch_prob") if hasattr(params, "get") else None
+            if isinstance(bp, torch.Tensor) and bp.numel() == B:  # (inverse_inputs may call with a subset of the batch: no switch then)
+                apply = torch.atleast_1d(bp.to(input.device) > 0.5)
+        mode = flags["resample"].name.lower()
+        if kind == "affine":
+            padding_mode = flags["padding_mode"].name.lower()
+            fill_value = flags.get("fill_value")
+            if padding_mode == "fill" and fill_value is None:
+                fill_value = torch.zeros(input.shape[1], device=input.device, dtype=input.dtype)
+            out = _warp(input, transform[:, :2, :], (height, width), COORD_AFFINE, 1, mode, padding_mode, flags["align_corners"], fill_value, apply)
+        else:
+            out = _warp(input, transform, (height, width), COORD_PERSPECTIVE, 1, mode, "zeros", flags["align_corners"], torch.zeros(3), apply)
+        if apply is not None:
+            out._kornia_amd_blended_with = weakref.ref(input)
+        return out
+
+    apply_transform.__wrapped__ = original
+    return apply_transform
+
+
 def patch() -> int:
     """Activate the native path inside Kornia. Returns the number of rebound module attributes."""
     if _patched:
@@ -240,7 +300,14 @@ def patch() -> int:
     original = gb_mod.RandomGaussianBlur.apply_transform
     gb_mod.RandomGaussianBlur.apply_transform = _gaussian_blur_apply(original)
     _patched_methods.append((gb_mod.RandomGaussianBlur, "apply_transform", original))
-    return count + 4
+    # the geometric leg of the same layer: the probability switch rides in the warp's own launch
+    for mod_name, cls_name, kind in (("kornia.augmentation._2d.geometric.affine", "RandomAffine", "affine"),
+                                     ("kornia.augmentation._2d.geometric.perspective", "RandomPerspective", "perspective")):
+        cls = getattr(importlib.import_module(mod_name), cls_name)
+        original = cls.apply_transform
+        cls.apply_transform = _geometric_apply(original, kind)
+        _patched_methods.append((cls, "apply_transform", original))
+    return count + 6
 
 
 def unpatch() -> int:

@@ -436,6 +436,26 @@ def main():
     assert torch.equal(st, out3)
     save("config3", **d3)
 
+    # ---- the geometric augmentations with p < 1 (kornia/augmentation/_2d/geometric/{affine,perspective}.py, base.py:348-393): the sampled
+    #      parameters - batch_prob included - and the reference's output, for the replay of kornia_amd.augmentation on the device ----------------
+    torch.manual_seed(19)
+    xg = torch.rand(6, 3, 48, 64, generator=torch.Generator().manual_seed(91))
+    dg = {"x": xg}
+    for name, mod in (("perspective", A.RandomPerspective(0.4, p=0.6)), ("perspective_nearest_align", A.RandomPerspective(0.3, resample="nearest", align_corners=True, p=0.6)),
+                      ("affine", A.RandomAffine(degrees=25.0, translate=(0.1, 0.2), scale=(0.7, 1.3), shear=8.0, p=0.6)),
+                      ("affine_border", A.RandomAffine(degrees=10.0, padding_mode="border", align_corners=True, p=0.6))):
+        for attempt in range(20):  # a draw that mixes transformed and untouched samples
+            out = mod(xg)
+            bp = mod._params["batch_prob"] > 0.5
+            if 0 < int(bp.sum()) < xg.shape[0]:
+                break
+        dg[f"{name}__out"] = out
+        dg[f"{name}__matrix"] = mod.transform_matrix
+        for k, v in mod._params.items():
+            if isinstance(v, torch.Tensor):
+                dg[f"{name}__{k}"] = v
+    save("geometric_aug", **dg)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

@@ -121,6 +121,101 @@ def test_config3_pipeline_parameter_replay_on_the_host_build():
     assert out16.dtype == torch.bfloat16 and err16.mean().item() < 5e-3 and err16.max().item() < 0.15, (err16.mean(), err16.max())
 
 
+def test_augmentation_hooks_with_probabilities_on_the_host_build():
+    """The hooks patch() installs on the augmentation layer, executed - not fallen through - inside the reference's own modules:
+    AugmentationSequential(RandomAffine, RandomPerspective, ColorJitter, RandomGaussianBlur) with p < 1 runs once unpatched on the CPU,
+    then its sampled parameters are replayed through the patched modules on "device" tensors (the host build of the kernels).  Checked:
+    every hook ran its native branch, the per-sample switch rode inside the warp / colour launches (no select pass for those stages),
+    the output equals the reference's, gradients flow through the patched ColorJitter, unpatch() restores the staticmethod."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("host build of the kernels needs ROCm's clang++")
+    K = ref_shim.import_reference()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from mode import emulated_device
+
+    import kornia_amd.augmentation as native_aug
+    import kornia_amd.kornia_patch as P
+
+    A = K.augmentation
+    base_mod = sys.modules["kornia.augmentation.base"]
+    blend_before = base_mod._AugmentationBase.__dict__["_blend_by_prob"]
+    assert isinstance(blend_before, staticmethod)
+    torch.manual_seed(11)
+    aug = A.AugmentationSequential(
+        A.RandomAffine(degrees=20.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=0.6),
+        A.RandomPerspective(0.3, p=0.7),
+        A.ColorJitter(0.2, 0.2, 0.2, 0.1, p=0.5),
+        A.RandomGaussianBlur((5, 5), (0.1, 2.0), p=0.5),
+    )
+    x = torch.rand(8, 3, 40, 56, generator=torch.Generator().manual_seed(5))
+    ref = aug(x)
+    params = aug._params
+    probs = [torch.as_tensor(p.data["batch_prob"]) > 0.5 for p in params]
+    assert all(0 < int(m.sum()) < 8 for m in probs[:3]), "the draw must mix transformed and untouched samples"
+    assert torch.equal(aug(x, params=params), ref)
+
+    selects = []
+    real_select = native_aug.select_samples
+    with emulated_device() as lib:
+        import emu_lib
+
+        n = P.patch()
+        try:
+            def spy(t_, o_, a_):
+                selects.append(tuple(t_.shape))
+                return real_select(t_, o_, a_)
+
+            # the blend hook closes over select_samples: count the select passes that really run
+            blend_fn = base_mod._AugmentationBase.__dict__["_blend_by_prob"].__func__
+            cell = [c for c in blend_fn.__closure__ if c.cell_contents is real_select]
+            assert len(cell) == 1, "the blend hook closes over select_samples"
+            cell[0].cell_contents = spy
+            before = emu_lib.stats()["launches"]
+            # forward: every stage through its hook
+            names = {}
+            for cls_name, mod in (("RandomAffine", "kornia.augmentation._2d.geometric.affine"), ("RandomPerspective", "kornia.augmentation._2d.geometric.perspective"),
+                                  ("ColorJitter", "kornia.augmentation._2d.intensity.color_jitter"), ("RandomGaussianBlur", "kornia.augmentation._2d.intensity.gaussian_blur")):
+                cls = getattr(sys.modules[mod], cls_name)
+                assert cls.apply_transform.__wrapped__ is not None
+                orig = cls.apply_transform.__wrapped__
+                names[cls_name] = [0]
+
+                def fell_through(self, *a, _n=cls_name, _o=orig, **k):
+                    names[_n][0] += 1
+                    return _o(self, *a, **k)
+
+                # the hook calls `original` from its closure: count the calls that reach it
+                for c in cls.apply_transform.__closure__:
+                    if c.cell_contents is orig:
+                        c.cell_contents = fell_through
+            out = aug(x.cuda(), params=params)
+            launches = emu_lib.stats()["launches"] - before
+            assert all(v[0] == 0 for v in names.values()), f"hooks fell through to the reference's own methods: {names}"
+            # backward through the patched ColorJitter (km_color_jitter_bwd) - the input requires a gradient, so the geometric
+            # hooks and the switch-in-launch forms step aside (forward-only) and the dispatchers' autograd functions take over
+            xg = x.cuda().requires_grad_()
+            cj = A.ColorJitter(0.2, 0.2, 0.2, 0.1, p=0.5)
+            yg = cj(xg, params=params[2].data)
+            yg.sum().backward()
+            xr = x.clone().requires_grad_()
+        finally:
+            assert P.unpatch() == n
+    # one select pass only - the blur's (its switch cannot ride in the taps bit for bit, kornia_amd/augmentation.py); the warps and
+    # the colour kernel carried theirs inside their own launches
+    assert selects == [tuple(x.shape)], selects
+    # the reference's own backward on the CPU for the same parameters
+    cj_ref = A.ColorJitter(0.2, 0.2, 0.2, 0.1, p=0.5)
+    cj_ref(xr, params=params[2].data).sum().backward()
+    assert torch.allclose(xg.grad, xr.grad, atol=2e-5, rtol=1e-4), (xg.grad - xr.grad).abs().max()
+    assert launches >= 8
+    assert out.dtype == torch.float32 and torch.allclose(out, ref, atol=2e-5, rtol=0), (out - ref).abs().max()
+    # samples no stage touched come back bit for bit
+    untouched = ~(probs[0] | probs[1] | probs[2] | probs[3])
+    assert torch.equal(out[untouched], x[untouched])
+    blend_after = base_mod._AugmentationBase.__dict__["_blend_by_prob"]
+    assert blend_after is blend_before and isinstance(blend_after, staticmethod)
+
+
 def test_reference_own_tests_pass_on_the_native_path():
     """The reference's own test files for the hot path, its callers and the augmentation layer (14 of the 23 files of tests/run_reference_tests_on_native.py here, ~830 cases: known-answer
     literals, gradchecks, error conventions, modules, containers) with the reference patched, every hot call going to the native kernels (their host build).
