@@ -81,7 +81,8 @@ def select_samples(transformed: torch.Tensor, original: torch.Tensor, apply: Opt
 def gaussian_taps(sigma: torch.Tensor, kernel_size, apply: Optional[torch.Tensor] = None) -> tuple:
     """Per-sample 1-D Gaussian taps from ``sigma`` (B,2) = (sigma_y, sigma_x): ``(taps_x (B,kx), taps_y (B,ky))`` in float32, one
     launch (``km_gaussian_taps_fwd``) for the ~16 elementwise launches of the reference's two ``get_gaussian_kernel1d`` calls.
-    ``apply`` (B,) bool: a sample whose entry is False gets the identity kernel (odd sizes), so the blur returns it unchanged."""
+    ``apply`` (B,) bool: a sample whose entry is False gets the identity kernel (odd sizes), so the blur returns it unchanged - bit for
+    bit when the image is finite (0 * inf is NaN).  A sigma of 0 gives the identity kernel too (the sigma -> 0 limit), NaN gives NaN taps."""
     ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
     s = sigma.detach().to(torch.float32).contiguous()
     B = s.shape[0]
@@ -190,7 +191,9 @@ def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_
         ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
         mask = _apply_mask(params, input.device)
         if mask is None or (kx % 2 == 1 and ky % 2 == 1):
-            # the switch rides in the taps: a sample that is not blurred gets the identity kernel (1 * x + 0 * neighbours = x, bit for bit)
+            # the switch rides in the taps: a sample that is not blurred gets the identity kernel: 1 * x + 0 * neighbours = x bit for bit
+            # for FINITE images (an inf / NaN pixel of an untouched sample spreads NaN over its neighbourhood, -0.0 comes back as +0.0:
+            # patch() therefore keeps the select pass for RandomGaussianBlur; this entry function states the precondition)
             taps_x, taps_y = gaussian_taps(sigma, kernel_size, mask)
             return filter2d_separable(input, taps_x, taps_y, border_type)
         taps_x, taps_y = gaussian_taps(sigma, kernel_size)

@@ -28,6 +28,13 @@ __global__ __launch_bounds__(64) void km_gaussian_taps_kernel(const float* __res
     }
     const float mean = (float)(k / 2);
     const float den = 2.0f * (s * s);
+    if (den == 0.0f) {
+        // sigma == 0: the reference refuses it on the host (kornia/filters/gaussian.py:103-108, a device-to-host read this path does not
+        // make); here the formula would give 0 / 0 taps and a NaN image.  The limit of the Gaussian for sigma -> 0 is what is emitted
+        // instead: the identity kernel (odd sizes), two taps of one half (even sizes).  A NaN sigma still gives NaN taps.
+        for (int i = 0; i < k; ++i) out[i] = (k & 1) ? ((i == k / 2) ? 1.0f : 0.0f) : ((i == k / 2 - 1 || i == k / 2) ? 0.5f : 0.0f);
+        return;
+    }
     float g[MAXK];
     float sum = 0.f;
 #pragma unroll

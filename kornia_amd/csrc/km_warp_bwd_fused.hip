@@ -76,6 +76,7 @@ struct KmWarpFusedArgs {
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, ntiles, nruns, run_len;  // a run = run_len horizontally adjacent tiles (run_len == tiles_x or 1)
     uint32_t nworkers;   // == gridDim.x of the persistent launch
+    uint32_t general_tiles;  // tiles a workgroup of the general launch looks at (1 .. 64)
     uint32_t reverse;    // the launch walks the batch backwards (km_traversal_next)
     uint32_t stream_out; // streaming stores of the tile flush (km_stream_stores)
 };
@@ -467,7 +468,30 @@ __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, co
             int qi, qj;
             kmo_first(tid, bwb, qi, qj);
             const uint32_t row0 = (uint32_t)ib * (uint32_t)g.w + (uint32_t)jb;
-            for (int base = 0; base < nq; base += KMO_NT) {
+            int base = 0;
+            if (finite && fast) {
+                // the common case of this launch (a box that did not fit the persistent loop's registers: rotation, minification): 4 pixels
+                // per thread and pass, their loads issued together - a pass costs one memory latency, not four
+                constexpr int GS = 4;
+                for (; base + GS * KMO_NT <= nq; base += GS * KMO_NT) {
+                    float go4[GS][CC];
+                    int pqi[GS], pqj[GS];
+#pragma unroll
+                    for (int s = 0; s < GS; ++s) {
+                        pqi[s] = qi; pqj[s] = qj;
+                        kmt_load_go<T, CC>(gout_c, row0 + (uint32_t)qi * (uint32_t)g.w + (uint32_t)qj, go4[s]);
+                        kmt_advance(qi, qj, di, dj, bwb);
+                    }
+#pragma unroll
+                    for (int s = 0; s < GS; ++s) {
+                        const float4 c0 = s_u4[pqj[s]], r0 = s_v4[pqi[s]];
+                        KmtPix q;
+                        kmt_pix_position<CM, ALIGN, true>(m, kmt_half(c0), kmt_half(r0), true, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
+                        kmo_pix<CM, CC, true, true>(q, go4[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                    }
+                }
+            }
+            for (; base < nq; base += KMO_NT) {
                 const bool valid = base + tid < nq;
                 const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
                 float go[CC];
@@ -721,7 +745,8 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 }
 
 // ---- launch 3: the tiles the persistent loop left (class "general", or a non-finite gradient met at run time) ---------------------
-// Workgroup w looks at the records of tiles 64 w .. 64 w + 63 (lane = tile, one ballot) and walks the marked ones.
+// Workgroup w looks at the records of tiles general_tiles * w ... (lane = tile, one ballot; up to 64 of them, fewer for small problems so
+// that a batch of a few images whose every tile is marked still spreads over the chip) and walks the marked ones.
 template <typename T, int CM, int ALIGN, int CC>
 __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWarpFusedArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -734,11 +759,11 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
     float fillv[CC];
 #pragma unroll
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
-    const uint32_t t0 = blockIdx.x * 64u;
+    const uint32_t t0 = blockIdx.x * a.general_tiles;
     if (wave == 0) {
         const uint32_t t = t0 + (uint32_t)lane;
         int fl = KMO_F_REGULAR;
-        if (t < a.ntiles) fl = a.ws[(size_t)t * KMO_BOX_INTS + 5];
+        if ((uint32_t)lane < a.general_tiles && t < a.ntiles) fl = a.ws[(size_t)t * KMO_BOX_INTS + 5];
         const unsigned long long todo = __ballot(!(fl & KMO_F_REGULAR) || (fl & KMO_F_NONFINITE));
         if (lane == 0) s_todo = todo;
     }
@@ -788,7 +813,7 @@ static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((km_warp_bwd_boxes_kernel<T, CM>), dim3((a.ntiles + 255u) / 256u), dim3(256), 0, s, a);
     hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
-    hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC>), dim3((a.ntiles + 63u) / 64u), dim3(KMO_NT), (size_t)lds, s, a);
+    hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC>), dim3((a.ntiles + a.general_tiles - 1u) / a.general_tiles), dim3(KMO_NT), (size_t)lds, s, a);
     return km_check_launch("km_warp2d_bwd(fused)");
 }
 template <typename T, int CM>
@@ -820,6 +845,10 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     a.nworkers = (uint32_t)((uint64_t)a.nruns < (uint64_t)workers_max ? a.nruns : workers_max);
     a.reverse = km_traversal_next(s);
     a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(float));
+    {   // the general launch: about 4 workgroups per CU when every tile needs it, 64 tiles per workgroup at most (one ballot)
+        const uint64_t per = (ntiles + 4ull * workers_max - 1) / (4ull * workers_max);
+        a.general_tiles = (uint32_t)(per < 1 ? 1 : (per > 64 ? 64 : per));
+    }
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmo_launch<T, KM_COORD_PERSPECTIVE>(a, s);
         case KM_COORD_AFFINE: return kmo_launch<T, KM_COORD_AFFINE>(a, s);

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void km_warp_gm_lds_kernel(const KmWarpGmArgs<
                 float ax, ay, az;
                 if (bx.fast) kmg_terms<CM, true>(p[r], gx_, gy_, ax, ay, az);
                 else kmg_terms<CM, false>(p[r], gx_, gy_, ax, ay, az);
+                ax = ok[r] ? ax : 0.0f; ay = ok[r] ? ay : 0.0f; az = ok[r] ? az : 0.0f;  // (a padding pixel's 0 * inf must not reach the sums)
                 S[0] += ax; S[1] += ay; S[2] += az;
                 Sv[0] = km_fma(ax, vrow[r], Sv[0]); Sv[1] = km_fma(ay, vrow[r], Sv[1]); Sv[2] = km_fma(az, vrow[r], Sv[2]);
             }

@@ -1,5 +1,5 @@
 // kornia_amd - the per-thread rows of the matrix gradient of the bilinear warps and its block reduction, shared by the
-// matrix-gradient kernel (km_warp_gm.hip) and the one-launch backward (km_warp_bwd_tiled.hip: km_warp_bwd_pair_kernel).
+// matrix-gradient kernel (km_warp_gm.hip) and its LDS-staged variant; kmg_terms also serves the one-read backward (km_warp_bwd_fused.hip).
 #pragma once
 
 #include "km_warp_stage.h"
@@ -166,6 +166,9 @@ __device__ __forceinline__ void km_warp_gm_rows(const KmWarpGmArgs<T>& a, const 
             const float gx_ = ok[q] ? gix[q] * mx : 0.0f, gy_ = ok[q] ? giy[q] * my : 0.0f;
             float ax, ay, az;
             kmg_terms<CM, FAST>(p[q], gx_, gy_, ax, ay, az);
+            // select the TERMS, not only their inputs: a padding lane / row whose position is not finite (den == 0 beyond the output's
+            // last row) would otherwise add 0 * inf = NaN to the whole image's gradient
+            ax = ok[q] ? ax : 0.0f; ay = ok[q] ? ay : 0.0f; az = ok[q] ? az : 0.0f;
             S[0] += ax; S[1] += ay; S[2] += az;
             Sv[0] = km_fma(ax, vrow[q], Sv[0]); Sv[1] = km_fma(ay, vrow[q], Sv[1]); Sv[2] = km_fma(az, vrow[q], Sv[2]);
         }

@@ -42,6 +42,13 @@ def _is_batched(k: int, t, batch: int, batched: Optional[Sequence[int]]) -> bool
                 raise ValueError(f"argument {k} was declared batched but its leading dimension is not {batch}")
             return True
         return False
+    if isinstance(t, torch.Tensor) and t.dim() == 1 and t.shape[0] == batch and batch > 4:
+        # a (B,) vector - per-sample angle / sigma / scale, or a coincidence? It is NOT sliced by the shape rule (a fill_value of shape
+        # (3,) is not a batch of three); replicated, it meets its rank's slice inside the op or in gather_batch with an error that does
+        # not name the cause.  Sizes up to 4 (channel-like) are left alone; anything longer must be declared.
+        raise ValueError(
+            f"argument {k} is a one-dimensional tensor whose length equals the batch size {batch}: it is ambiguous whether it is a per-sample vector. "
+            f"List the per-sample arguments in batched= (e.g. batched=(0, {k})), or pass batched=(...) without it to replicate it.")
     return isinstance(t, torch.Tensor) and t.dim() >= 2 and t.shape[0] == batch and batch != 1
 
 
@@ -56,7 +63,8 @@ def shard_batch(tensors: Sequence[Optional[torch.Tensor]], batch: int, world_siz
     ``batched`` = positions (in ``tensors``) of the arguments that carry the batch on their leading dimension.
     Without it the rule is by shape: a tensor with at least two dimensions whose leading one equals ``batch`` is
     batched (images, (B,3,3) matrices, (B,2) sigmas); one-dimensional tensors never are - a ``fill_value`` of shape
-    (3,) is not a batch of three - so per-sample vectors must be named through ``batched``."""
+    (3,) is not a batch of three - so per-sample vectors must be named through ``batched``.  A one-dimensional tensor whose length
+    equals a batch size above 4 is refused as ambiguous instead of being silently replicated."""
     lo, hi = shard_bounds(batch, world_size, rank)
     return _slice_batched(tensors, batch, lo, hi, batched)
 

@@ -41,7 +41,8 @@ def _check_tensor_sigma(sigma: torch.Tensor, like: torch.Tensor) -> torch.Tensor
     """A tensor sigma is validated where its values live on the host (the reference's ``bool((sigma > 0).all())``,
     gaussian.py:103-108).  A sigma that is already on the device is NOT read back: that would drain the stream in the
     middle of an augmentation pipeline; the Gaussian only uses sigma^2, so a negative entry then acts as
-    its magnitude and a zero gives non-finite taps, like any other bad device value.  ``kornia_amd.core.check.set_device_value_checks(True)`` restores the
+    its magnitude, and a zero gives the limit of the Gaussian for sigma -> 0 - the identity kernel (km_gaussian_taps_fwd) - instead of
+    the reference's exception; a NaN sigma gives NaN taps.  (INTEGRATION.md lists the divergence.)  ``kornia_amd.core.check.set_device_value_checks(True)`` restores the
     reference's synchronising check (the reference's own tests run with it)."""
     KORNIA_CHECK_IS_TENSOR(sigma)
     on_host = sigma.device.type == "cpu"
@@ -79,6 +80,16 @@ def gaussian_blur2d(input: torch.Tensor, kernel_size: Union[tuple[int, int], int
         sigma = torch.tensor([sigma], device=input.device, dtype=input.dtype)
     else:
         sigma = _check_tensor_sigma(sigma, input)
+        if (separable and N.on_device(input) and N.on_device(sigma) and input.dtype in (torch.float32, torch.bfloat16, torch.float16) and kx <= 64 and ky <= 64
+                and not (torch.is_grad_enabled() and sigma.requires_grad)):
+            # per-sample sigma already on the device: both tap vectors in ONE launch (km_gaussian_taps_fwd) instead of the ~16
+            # elementwise launches of two get_gaussian_kernel1d calls - the call was host-bound on them (265 us of enqueue for
+            # 256 x 3 x 224^2).  Taps are evaluated in float32 (the device's expf: within 2 ulp of the reference's) and rounded to the
+            # image dtype by filter2d_separable like any kernel (kornia/filters/filter.py:126).
+            from ..augmentation import gaussian_taps
+
+            taps_x, taps_y = gaussian_taps(sigma, (ky, kx))
+            return filter2d_separable(input, taps_x, taps_y, border_type)
 
     if not separable:
         return filter2d(input, get_gaussian_kernel2d(kernel_size, sigma), border_type)

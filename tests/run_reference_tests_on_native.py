@@ -62,6 +62,11 @@ def main() -> int:
     n_files = next((i for i, a in enumerate(args) if a.startswith("-")), len(args))  # test files first, pytest options after
     files, extra = args[:n_files] or DEFAULT_FILES, args[n_files:]
     ref = ref_shim.REFERENCE_ROOT
+    # values that live "on the device" are validated like the reference validates them (its tests expect the exceptions):
+    # the synchronising checks the product leaves off by default are on for this run
+    from kornia_amd.core.check import set_device_value_checks
+
+    set_device_value_checks(True)
     with emulated_device():
         import emu_lib
 

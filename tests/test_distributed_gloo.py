@@ -82,8 +82,12 @@ def test_shard_bounds():
     xs, ms, n = shard_batch([x, m, None], 8, 4, 1)
     assert xs.shape[0] == 2 and ms is m and n is None
     v = torch.zeros(8)
-    assert shard_batch([x, v], 8, 4, 1)[1] is v  # one-dimensional tensors are not batched by shape ...
-    assert shard_batch([x, v], 8, 4, 1, batched=(0, 1))[1].shape[0] == 2  # ... only by declaration
+    with pytest.raises(ValueError, match="ambiguous"):  # a (B,) vector is neither sliced nor silently replicated by the shape rule ...
+        shard_batch([x, v], 8, 4, 1)
+    assert shard_batch([x, v], 8, 4, 1, batched=(0, 1))[1].shape[0] == 2  # ... it is sliced by declaration ...
+    assert shard_batch([x, v], 8, 4, 1, batched=(0,))[1] is v  # ... or replicated by declaration
+    f3 = torch.zeros(3)
+    assert shard_batch([torch.zeros(3, 3, 4, 4), f3], 3, 3, 1)[1] is f3  # channel-like sizes (a (3,) fill value with batch 3) pass
     with pytest.raises(ValueError):
         shard_batch([x, m], 8, 4, 1, batched=(0, 1))
 

@@ -24,6 +24,7 @@ SKIP = {
     ("test_gpu_warp", "test_identity_is_exact_and_errors"),      # asserts that host tensors are refused
     ("test_gpu_color", "test_half_precision_and_errors"),        # same
     ("test_gpu_edge_cases", "test_mixed_dtypes_and_streams"),    # HIP streams
+    ("test_gpu_edge_cases", "test_two_threads_two_streams_share_no_launch_state"),  # HIP streams, host threads
 }
 
 for _m in MODULES:

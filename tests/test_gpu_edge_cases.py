@@ -123,3 +123,43 @@ def test_batch_traversal_direction_does_not_change_results():
             assert (got[2] - ref[2]).abs().max().item() <= 1e-6 * ref[2].abs().max().item()  # fp32 partial sums per thread over the tiles a workgroup walks: the grouping follows the direction
     finally:
         lib.km_set_traversal(prev)
+
+
+def test_two_threads_two_streams_share_no_launch_state(oracle):
+    """the C ABI is re-entrant - no launch state shared between streams.  Two host threads drive the hot step on two
+    streams at once; the traversal parity of the streaming kernels is kept per (device, stream), so each thread's launches alternate
+    on their own, and both get the results of a lone run (bit-identical forward and image gradient)."""
+    import threading
+
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.rand(3, 3, 96, 130, generator=g) for _ in range(2)]
+    Ms = [torch.eye(3) + 0.02 * torch.randn(3, 3, 3, generator=g) for _ in range(2)]
+    for M in Ms:
+        M[:, 2, :2] *= 0.01
+    gos = [torch.rand(3, 3, 80, 112, generator=g) for _ in range(2)]
+
+    def run(k, stream, out, reps):
+        with torch.cuda.stream(stream):
+            for _ in range(reps):
+                x = xs[k].cuda().requires_grad_()
+                M = Ms[k].cuda().requires_grad_()
+                y = K.filters.gaussian_blur2d(K.geometry.transform.warp_perspective(x, M, (80, 112)), (5, 5), (1.5, 1.5))
+                y.backward(gos[k].cuda())
+            stream.synchronize()
+            out[k] = (y.detach().cpu(), x.grad.cpu(), M.grad.cpu())
+
+    lone = {}
+    for k in range(2):
+        run(k, torch.cuda.current_stream(), lone, 1)
+    both = {}
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    threads = [threading.Thread(target=run, args=(k, streams[k], both, 5 + k)) for k in range(2)]  # 5 and 6 steps: the parities drift apart
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join()
+    for k in range(2):
+        assert torch.equal(both[k][0], lone[k][0]) and torch.equal(both[k][1], lone[k][1])
+        assert (both[k][2] - lone[k][2]).abs().max().item() <= 1e-6 * lone[k][2].abs().max().item()

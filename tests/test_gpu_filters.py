@@ -120,6 +120,12 @@ def test_gaussian_blur2d_backward_and_errors(oracle):
     bad = torch.tensor([[1.0, -1.0]]).cuda()
     if bad.device.type != "cpu":  # (under the host build of the kernels "cuda" tensors are host tensors: checked like host data)
         K.gaussian_blur2d(x.cuda(), (5, 5), bad)
+        # ... and a zero is the limit of the Gaussian for sigma -> 0, the identity kernel, not 0 / 0 taps (km_gaussian_taps_fwd)
+        zero = torch.tensor([[0.0, 1.2]]).cuda()
+        y0 = K.gaussian_blur2d(x.cuda(), (5, 5), zero)
+        kx = K.filters.get_gaussian_kernel1d(5, torch.tensor([[1.2]])).cuda()
+        ident = torch.tensor([[0.0, 0.0, 1.0, 0.0, 0.0]]).cuda()
+        assert torch.isfinite(y0).all() and torch.allclose(y0, K.filter2d_separable(x.cuda(), kx, ident), atol=3e-7)
     old = set_device_value_checks(True)  # ... unless the reference's synchronising check is asked for
     try:
         with pytest.raises(BaseError, match="sigma must be positive"):
