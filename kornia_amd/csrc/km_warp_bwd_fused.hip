@@ -92,7 +92,9 @@ struct KmoTile {
     int j0, j1, i0, i1, hb;
     bool fixed_ok, regular, svec, fvec;
     int bw, nq;
+    int p, npass;      // the box is walked in npass passes of KMO_CAP pixels; this work item is pass p
 };
+#define KMO_CAP (KMO_NT * KMO_SLOTS)  // pixels of a box the registers of a workgroup hold
 
 template <typename T>
 __device__ __forceinline__ void kmo_tile_coords(const KmWarpFusedArgs<T>& a, uint32_t t, int& b, int& tx, int& ty) {
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFuse
     const KmtBox bx = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
     const int bw = bx.j1 - bx.j0 + 1, bh = bx.i1 - bx.i0 + 1;
     const bool empty = bw <= 0 || bh <= 0;
-    const bool fits = empty || (bw <= KMT_BAND_W && bh <= KMT_TAB && (long long)bw * bh <= (long long)KMO_NT * KMO_SLOTS);
+    // one band of the coordinate tables; larger boxes than the registers hold are walked in several passes (rotations, magnification)
+    const bool fits = empty || (bw <= KMT_BAND_W && bh <= KMT_TAB);
     // every pixel of the box has division operands inside the range of the shared-reciprocal division (km_lean.h)
     const bool fast = empty ? true : kml_div_guard<CM>(g, m, bx.j0, bx.j1, bx.i0, bx.i1);
     int* o = a.ws + (size_t)t * KMO_BOX_INTS;
@@ -171,6 +174,8 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
     const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
     d.bw = bw;
     d.nq = (bw > 0 && bh > 0) ? bw * bh : 0;
+    d.p = 0;
+    d.npass = max(1, (d.nq + KMO_CAP - 1) / KMO_CAP);
     // 16-byte rows of the source tile / of the tile flush
     d.svec = (sizeof(T) == 4) && d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.src & 15) == 0;
     d.fvec = d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0;
@@ -193,7 +198,7 @@ __device__ __forceinline__ void kmo_fetch_boxes(const KmWarpFusedArgs<T>& a, uin
 }
 
 // first pixel of this thread in a box of width bw walked as a linear list (element e = tid; tid < 2^24: the float quotient is off by at most one)
-__device__ __forceinline__ void kmo_first(int tid, int bw, int& qi, int& qj) {
+__device__ __forceinline__ void kmo_first(int tid, int bw, int& qi, int& qj) {  // tid: element index (< 2^24)
     // (a reciprocal, not a division: 15 instructions fewer per thread and tile; the two corrections below absorb its error)
     qi = (int)(((float)tid + 0.5f) * kmt_uniform(__builtin_amdgcn_rcpf((float)bw)));
     qj = tid - qi * bw;
@@ -331,10 +336,10 @@ struct KmoWalk {
 template <typename T>
 __device__ __forceinline__ void kmo_walk_init(const KmWarpFusedArgs<T>& a, const KmoTile& d, KmoWalk& wk) {
     wk.bw = max(d.bw, 1);
-    wk.nq = d.regular ? d.nq : 0;  // (a tile of the general path loads its pixels itself)
+    wk.nq = d.regular ? min(d.nq - d.p * KMO_CAP, KMO_CAP) : 0;  // pixels of this pass (a tile of the general path loads its pixels itself)
     wk.di = kmt_uniform(KMO_NT / wk.bw);
     wk.dj = kmt_uniform(KMO_NT % wk.bw);
-    kmo_first(threadIdx.x, wk.bw, wk.qi, wk.qj);
+    kmo_first(d.p * KMO_CAP + (int)threadIdx.x, wk.bw, wk.qi, wk.qj);
     wk.row0 = (uint32_t)d.i0 * (uint32_t)a.g.w + (uint32_t)d.j0;
 }
 // request slot s of the walk's tile (zeros beyond the end of the box) and advance
@@ -358,14 +363,15 @@ __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& 
     const int tid = threadIdx.x;
     const int bw = max(d.bw, 1);
     const int di = kmt_uniform(KMO_NT / bw), dj = kmt_uniform(KMO_NT % bw);
+    const int nqp = min(d.nq - d.p * KMO_CAP, KMO_CAP);  // pixels of this pass
     int qi, qj;
-    kmo_first(tid, bw, qi, qj);
+    kmo_first(d.p * KMO_CAP + tid, bw, qi, qj);
 #pragma unroll
     for (int s = 0; s < KMO_SLOTS; ++s) {
         // (mine == false: a tile this launch leaves to the general one - only the refill below happens.  One code path for both, so
         // that the compiler sees ONE set of registers for the slots: two paths meant copies, and a wait for every load in flight)
-        if (mine && s * KMO_NT < d.nq && !(KMO_ABL & 4)) {  // block-uniform
-            const bool valid = s * KMO_NT + tid < d.nq;
+        if (mine && s * KMO_NT < nqp && !(KMO_ABL & 4)) {  // block-uniform
+            const bool valid = s * KMO_NT + tid < nqp;
             const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
             const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
             KmtPix q;
@@ -376,7 +382,7 @@ __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& 
         kmo_request_slot<T, CC>(gout_n, w, s, wn, G[s]);
         // the next tile's source tile is requested here, not before the loop: registers that are live across the whole loop get
         // moved by the register allocator at its entry, and a move of a register with a load in flight is a wait for that load
-        if (s == KMO_SRC_AT && nxt.t >= 0 && nxt.regular) kmo_issue_src<T, CC>(a, nxt, S);
+        if (s == KMO_SRC_AT && nxt.t >= 0 && nxt.regular && nxt.p == 0) kmo_issue_src<T, CC>(a, nxt, S);
         KM_SCHED_FENCE();  // one pixel at a time: interleaving the slots costs more registers than it hides latency
     }
 }
@@ -402,7 +408,16 @@ __device__ __forceinline__ bool kmo_fill_tables(const KmWarpGeom<float>& g, cons
     return okr;
 }
 
-// 2^k with |w g 2^k| (taps per pixel) < 2^30 for |g| <= M (M finite)
+// k with |w g 2^k| (taps per pixel) < 2^30 for |g| <= M (M finite)
+__device__ __forceinline__ int kmo_scale_exp(float M, int hb) {
+    int kexp = 0;
+    if (M > 0.f) {
+        int ex2;
+        (void)frexpf(M, &ex2);  // M = f * 2^ex2, f in [0.5, 1)  =>  M < 2^ex2
+        kexp = max(-126, min(126, 30 - hb - ex2));
+    }
+    return kmt_uniform(kexp);
+}
 __device__ __forceinline__ void kmo_scale(float M, int hb, float& scale, float& inv_scale) {
     int kexp = 0;
     if (M > 0.f) {
@@ -516,7 +531,7 @@ __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, co
 
 // convert and write the tile, leaving the accumulators zeroed for the next one
 template <typename T, int CC>
-__device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const KmoTile& d, int* s_acc, bool finite, float inv_scale) {
+__device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const KmoTile& d, int* s_acc, bool finite, float inv_scale, bool discard = false) {
     const KmWarpGeom<float>& g = a.g;
     const int tid = threadIdx.x;
     const size_t src_plane = (size_t)g.H * g.W;
@@ -536,7 +551,9 @@ __device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const Kmo
                 float4 v;
                 if (finite) v = make_float4((float)q.x * inv_scale, (float)q.y * inv_scale, (float)q.z * inv_scale, (float)q.w * inv_scale);
                 else v = make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
-                if (a.stream_out) {
+                if (discard) {
+                    // (a tile that met a non-finite gradient after its first pass: the accumulators are zeroed, the general launch writes it)
+                } else if (a.stream_out) {
                     typedef float km_f4v __attribute__((ext_vector_type(4)));
                     km_f4v vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
                     __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v*>(outp));
@@ -555,7 +572,7 @@ __device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const Kmo
                     int* accp = s_acc + c * KMO_PLANE + r * KMT_TW + col;
                     const int q = *accp;
                     *accp = 0;
-                    gsrc_b[(size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (d.X0 + col)] = finite ? (float)q * inv_scale : __int_as_float(q);
+                    if (!discard) gsrc_b[(size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (d.X0 + col)] = finite ? (float)q * inv_scale : __int_as_float(q);
                 }
             }
         }
@@ -607,7 +624,7 @@ __device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const Kmo
     // (no early exit for a tile this launch does not own: every path through here must CONSUME the slots and the source registers,
     // or the compiler - which cannot know that nothing was requested for such a tile - waits for them later, inside the scatter, with
     // a wait that also covers the next tile's requests)
-    kmo_store_src<CC>(d, S, l.s_src, fillv, is_fill);
+    if (d.p == 0) kmo_store_src<CC>(d, S, l.s_src, fillv, is_fill);  // (later passes of a box: the tile is in LDS already, no request was made)
     uint32_t mb = 0;
 #pragma unroll
     for (int s = 0; s < KMO_SLOTS; ++s)
@@ -616,7 +633,7 @@ __device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const Kmo
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_down((int)mb, off, 64));
     if (lane == 0) l.s_red[wave] = mb;
-    if (d.t >= 0 && d.regular && d.nq > 0) {
+    if (d.t >= 0 && d.regular && d.nq > 0 && d.p == 0) {
         float m[9];
         kmo_matrix(rec, m);
         (void)kmo_fill_tables<CM>(a.g, m, d.j0, d.bw, d.i0, d.i1 - d.i0 + 1, l.s_u4, l.s_v4);
@@ -665,22 +682,38 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
     }
     float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int pending_b = -1;      // image whose matrix-gradient partials sit in s_gm
-    KmoTile prev = KmoTile{};  // the tile whose accumulators wait to be flushed
+    KmoTile prev = KmoTile{};  // the tile whose accumulators wait to be flushed (prev_discard: zeroed without being written)
     prev.t = -1;
     float prev_inv_scale = 1.f;
+    bool prev_discard = false;
+    // state of the tile across the passes of its box
+    int kexp = 0;              // the accumulators hold contributions times 2^kexp
+    uint32_t bound_bits = 0;   // ... chosen for |grad_out| <= this (bit pattern)
+    bool tile_ok = true;       // no non-finite gradient met so far
 
-    for (uint32_t q = 0; cur.t >= 0; ++q) {
-        // ---- this tile's requests have arrived: source tile -> LDS, exact maximum of |grad_out|, coordinate tables - consumed BEFORE
-        //      the flush of the previous tile issues its stores (a wait for loads that has stores behind it in the queue waits for those too)
+    // A work item is (tile, pass): a box larger than the registers of the workgroup (KMO_CAP pixels: rotations beyond ~10 degrees,
+    // magnification) is walked in several passes, the next pass requested slot by slot during the current one like a next tile.
+    for (uint32_t q = 0; cur.t >= 0;) {
+        // ---- this item's requests have arrived: (first pass: source tile -> LDS, coordinate tables;) exact maximum of |grad_out| over the
+        //      pass - consumed BEFORE the flush of the previous tile issues its stores (a wait for loads that has stores behind it in the
+        //      queue waits for those too)
         kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, fillv, is_fill, lane, wave);
         // ---- flush of the previous tile (zeroes the accumulators) ----
-        if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale);
-        if (wave == 0 && (q + 1u) % KMO_RUN == 0u) kmo_fetch_boxes(a, q + 1u, lane, l.s_box);  // (into the half of the ring tile q is not in)
-        KM_LDS_BARRIER();  // B1: source tile, maxima, tables in LDS, accumulators zero
+        if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale, prev_discard);
+        prev.t = -1;
+        const bool last_pass = cur.p + 1 >= cur.npass;
+        if (wave == 0 && last_pass && (q + 1u) % KMO_RUN == 0u) kmo_fetch_boxes(a, q + 1u, lane, l.s_box);  // (into the half of the ring tile q is not in)
+        KM_LDS_BARRIER();  // B1: source tile, maxima, tables in LDS, accumulators zero (first pass)
 
-        // ---- the NEXT tile: its source tile is requested now, its grad_out slot by slot during the scatter ----
+        // ---- the NEXT item: the next pass of this box, or the first pass of the next tile (whose source tile is requested after the
+        //      first slot of the scatter); its grad_out slot by slot during the scatter ----
         KmoTile nxt;
-        kmo_describe(a, kmo_tile_of(a, q + 1u), kmo_ring(l.s_box, q + 1u), nxt);
+        if (last_pass) {
+            kmo_describe(a, kmo_tile_of(a, q + 1u), kmo_ring(l.s_box, q + 1u), nxt);
+        } else {
+            nxt = cur;
+            nxt.p = cur.p + 1;
+        }
         const T* gout_n[CC];
 #pragma unroll
         for (int c = 0; c < CC; ++c) gout_n[c] = a.gout;
@@ -693,52 +726,69 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
             wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
         }
         // matrix-gradient partials of the image finished before this tile
-#ifndef EXP_NOCOMMIT
         if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
-#endif
         pending_b = -1;
 
-        // ---- scatter + matrix-gradient terms (the slots are refilled with the next tile's pixels as they are consumed) ----
-        float scale = 1.f, inv_scale = 1.f;
-        bool mine = cur.regular;  // this launch writes the tile
-        if (cur.regular) {
+        // ---- the fixed-point scale: from the exact maximum of the first pass; a later pass with a larger one rescales the accumulators ----
+        if (cur.p == 0) tile_ok = cur.regular;
+        if (cur.regular && tile_ok) {
             uint32_t Mb = l.s_red[0];
 #pragma unroll
             for (int w = 1; w < KMO_NW; ++w) Mb = max(Mb, l.s_red[w]);
             Mb = (uint32_t)kmt_uniform((int)Mb);
             if (Mb >= 0x7f800000u) {
-                // NaN / inf in the box: IEEE float accumulation is the general launch's; mark the tile and leave it alone
-                mine = false;
-#ifndef EXP_NOFLAG
+                // NaN / inf in the box: IEEE float accumulation is the general launch's; mark the tile and leave it alone (what earlier
+                // passes added is discarded with the accumulators; their share of the matrix gradient stays - that image's matrix
+                // gradient is not finite either way)
+                tile_ok = false;
                 if (tid == 0) a.ws[(size_t)cur.t * KMO_BOX_INTS + 5] = (cur.fixed_ok ? KMO_F_FIXED : 0) | KMO_F_REGULAR | KMO_F_NONFINITE;
-#endif
-            } else {
-                kmo_scale(__uint_as_float(Mb), cur.hb, scale, inv_scale);
+            } else if (cur.p == 0) {
+                bound_bits = Mb;
+                kexp = kmo_scale_exp(__uint_as_float(Mb), cur.hb);
+            } else if (Mb > bound_bits) {
+                const int knew = kmo_scale_exp(__uint_as_float(Mb), cur.hb);
+                bound_bits = Mb;
+                if (knew < kexp) {  // (block-uniform) a coarser scale: shift what has been accumulated, rounding to nearest
+                    const int sh = min(kexp - knew, 31);
+                    for (int e = tid; e < CC * KMO_PLANE; e += KMO_NT) {
+                        const int v = l.s_acc[e];
+                        l.s_acc[e] = sh >= 31 ? 0 : (int)(((long long)v + (1ll << (sh - 1))) >> sh);
+                    }
+                    kexp = knew;
+                    KM_LDS_BARRIER();
+                }
             }
         }
+        const bool mine = cur.regular && tile_ok;  // this launch scatters this item
+        const float scale = kmt_uniform(ldexpf(1.0f, kexp)), inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
         {
             float m[9];
             kmo_matrix(kmo_ring(l.s_box, q), m);
             kmo_process<T, CM, ALIGN, CC, true, true>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, l.s_src, scale, A, g.w, wn, gout_n, mine, a, nxt, S);
         }
-        KM_LDS_BARRIER();  // B2: every contribution is in the accumulators; the tables, s_red and the source tile are free
+        KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
 
-        // ---- an image that ends here publishes its matrix-gradient partials ----
-        if (nxt.t < 0 || nxt.b != cur.b) {
+        if (last_pass) {
+            // ---- an image that ends here publishes its matrix-gradient partials ----
+            if (nxt.t < 0 || nxt.b != cur.b) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double s = km_wave_sum((double)A[k]);
-                if (lane == 0) l.s_gm[wave * 9 + k] = s;
-                A[k] = 0.f;
+                for (int k = 0; k < 9; ++k) {
+                    const double s = km_wave_sum((double)A[k]);
+                    if (lane == 0) l.s_gm[wave * 9 + k] = s;
+                    A[k] = 0.f;
+                }
+                pending_b = cur.b;
             }
-            pending_b = cur.b;
+            if (cur.regular) {  // flushed (or, after a non-finite gradient, only zeroed) after the next item's stage
+                prev = cur;
+                prev_inv_scale = inv_scale;
+                prev_discard = !tile_ok;
+            }
+            ++q;
         }
-        prev = cur;
-        if (!mine) prev.t = -1;
-        prev_inv_scale = inv_scale;
         cur = nxt;
     }
-    if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale);
+    if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale, prev_discard);
     // ---- epilogue: the last image's partials ----
     __syncthreads();
     if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);

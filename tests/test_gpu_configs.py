@@ -30,10 +30,15 @@ def test_config2_full_size_step_is_consistent():
     assert torch.isfinite(y).all() and torch.isfinite(gx).all() and torch.isfinite(gM).all()
     y2, gx2, gM2 = step(x, M, go)
     assert torch.equal(y, y2) and torch.equal(gx, gx2)  # bit-reproducible
-    assert torch.allclose(gM, gM2, rtol=1e-6, atol=0)    # fp64 atomics: order may differ in the last bits
+    def close(a, b):  # relative to the largest entry of each matrix (the entries of one matrix span five orders of magnitude)
+        return ((a - b).abs().amax(dim=(1, 2)) <= 1e-6 * b.abs().amax(dim=(1, 2))).all()
+
+    assert close(gM, gM2)    # fp64 atomics: order may differ in the last bits
     ys, gxs, gMs = step(x[5:9], M[5:9], go[5:9])
     assert torch.equal(ys, y[5:9]) and torch.equal(gxs, gx[5:9])
-    assert torch.allclose(gMs, gM[5:9], rtol=1e-6, atol=0)
+    # a sub-batch is dealt to the workgroups of the one-read backward in other runs of tiles: the fp32 partial sums a thread keeps over
+    # the tiles of a run group differently (fp64 beyond the thread)
+    assert close(gMs, gM[5:9])
 
 
 def test_config4_sobel_and_bicubic_affine_1080p():

@@ -154,6 +154,34 @@ def test_tiles_of_the_general_launch(oracle, case):
         assert _rel(gM, gM2) <= 2e-4
 
 
+@pytest.mark.parametrize("angle,scale", [(20.0, 1.0), (45.0, 1.0), (0.0, 1.35), (33.0, 0.8)])
+def test_boxes_walked_in_several_passes(oracle, angle, scale):
+    """Rotations and magnifications whose boxes exceed what a workgroup holds in registers (6144 pixels): the persistent loop walks them
+    in passes, the accumulators rescaled when a later pass brings a larger |grad_out| (the gradient grows along the image here, so that
+    it happens).  Against the oracle and the two launches."""
+    import math
+
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(int(angle) + 3)
+    B, C, H, W = 2, 3, 200, 264
+    x = torch.rand(B, C, H, W, generator=g)
+    a = math.radians(angle)
+    ca, sa = scale * math.cos(a), scale * math.sin(a)
+    cx, cy = (W - 1) / 2, (H - 1) / 2
+    M = torch.tensor([[ca, sa, (1 - ca) * cx - sa * cy], [-sa, ca, sa * cx + (1 - ca) * cy], [0.0, 0.0, 1.0]]).repeat(B, 1, 1)
+    M[:, 2, 0] = 2e-5  # a little perspective
+    ramp = torch.linspace(0.01, 30.0, H).view(1, 1, H, 1)  # later rows carry larger gradients: later passes raise the maximum
+    go = (torch.rand(B, C, H, W, generator=g) - 0.5) * ramp
+    gx, gM = _run(lambda a_, m: K.warp_perspective(a_, m, (H, W)), x, M, go, True)
+    gx2, gM2 = _run(lambda a_, m: K.warp_perspective(a_, m, (H, W)), x, M, go, False)
+    gxo, gMo = oracle.warp_perspective_backward(go, x, M, (H, W))
+    tol = 2e-6 * go.abs().max().item() * (4.0 if scale > 1.2 else 1.0)  # (magnification: several output pixels per source pixel)
+    assert (gx - gxo).abs().max().item() <= tol, (gx - gxo).abs().max()
+    assert (gx2 - gxo).abs().max().item() <= 2 * tol
+    assert _rel(gM, gMo) <= 5e-5 and _rel(gM, gM2) <= 5e-5
+
+
 def test_workspace_contract():
     """km_warp2d_bwd_workspace_bytes is 0 for what the one-read backward does not cover; a short or missing workspace falls back to the
     two launches with the same results; the workspace is not needed after the call."""
