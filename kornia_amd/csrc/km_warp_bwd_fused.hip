@@ -742,7 +742,9 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
                 // gradient is not finite either way)
                 tile_ok = false;
                 if (tid == 0) a.ws[(size_t)cur.t * KMO_BOX_INTS + 5] = (cur.fixed_ok ? KMO_F_FIXED : 0) | KMO_F_REGULAR | KMO_F_NONFINITE;
-            } else if (cur.p == 0) {
+            } else if (cur.p == 0 || bound_bits == 0u) {
+                // (as long as every gradient met was zero the accumulators are zero and the scale is still free: a first pass over zeros
+                // must not pin it at 2^0 for the small gradients of a later pass)
                 bound_bits = Mb;
                 kexp = kmo_scale_exp(__uint_as_float(Mb), cur.hb);
             } else if (Mb > bound_bits) {

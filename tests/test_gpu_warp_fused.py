@@ -154,6 +154,60 @@ def test_tiles_of_the_general_launch(oracle, case):
         assert _rel(gM, gM2) <= 2e-4
 
 
+@pytest.mark.parametrize("case", ["growing", "zero_top", "nonfinite_bottom", "shrinking"])
+@pytest.mark.parametrize("angle", [0.0, 30.0])
+def test_fixed_point_scale_follows_the_gradients_of_the_box(oracle, case, angle):
+    """The fixed-point scale of a tile comes from the largest |grad_out| of its box - for a box walked in several passes (30 degrees) from
+    the passes seen so far, made coarser (accumulators shifted) when a later pass brings larger gradients: gradients that grow by 2^20
+    over 64 rows, boxes whose first rows are all zero (the scale must still be free when the first non-zero - and small - gradient
+    arrives: a first pass over zeros once pinned it at 2^0), a NaN / inf in the last rows of a box, and the opposite slope."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(23)
+    B, C, H, W, h, w = 2, 3, 192, 192, 192, 192
+    x = torch.rand(B, C, H, W, generator=g)
+    if angle == 0.0:
+        M = flagship_homographies(B, H, W, h, w, g, jitter=3.0)
+    else:
+        th = torch.deg2rad(torch.tensor(angle))
+        c, sn = torch.cos(th).item(), torch.sin(th).item()
+        R = torch.tensor([[c, -sn, (1 - c) * W / 2 + sn * H / 2], [sn, c, (1 - c) * H / 2 - sn * W / 2], [0.0, 0.0, 1.0]])
+        M = R[None].repeat(B, 1, 1)
+    go = torch.rand(B, C, h, w, generator=g) - 0.5
+    rows = torch.arange(h, dtype=torch.float32)
+    if case == "growing":
+        go = go * torch.exp2(rows * (20.0 / 64.0))[None, None, :, None]
+    elif case == "shrinking":
+        go = go * torch.exp2(-rows * (20.0 / 64.0))[None, None, :, None]
+    elif case == "zero_top":
+        # (rotated: the first pass over the box of the centre tile - rows 52 to ~120 of 52 to 140 - sees zeros only)
+        keep = ((rows % 64) >= 40) if angle == 0.0 else (rows >= 125)
+        go = go * keep.float()[None, None, :, None] * 1e-6
+    else:
+        go[0, 1, 60, 50] = float("nan")
+        go[1, 2, 125, 130] = float("inf")
+    gx, gM = _run(lambda a, m: K.warp_perspective(a, m, (h, w)), x, M, go, True)
+    gxo, gMo = oracle.warp_perspective_backward(go, x, M, (h, w))
+    if case == "nonfinite_bottom":
+        assert torch.equal(torch.isnan(gx), torch.isnan(gxo)) and torch.equal(torch.isinf(gx), torch.isinf(gxo))
+        fin = torch.isfinite(gxo)
+        assert torch.allclose(gx[fin], gxo[fin], atol=1e-5, rtol=0)
+        assert torch.isnan(gM).any()
+        return
+    if case == "zero_top":
+        # every non-zero gradient is ~1e-6: the error bound is relative to THAT, not to 1
+        assert (gx - gxo).abs().max().item() <= 4e-6 * go.abs().max().item(), (gx - gxo).abs().max().item()
+    else:
+        # per 64-row band of the source: within 4e-6 of the largest gradient that can reach the band (the contract of the fixed point)
+        reach = 24 if angle == 0.0 else 120
+        for y0 in range(0, H, 64):
+            band = slice(y0, y0 + 64)
+            tol = 4e-6 * max(go[:, :, max(0, y0 - reach):y0 + 64 + reach].abs().max().item(), 1e-30)
+            err = (gx[:, :, band] - gxo[:, :, band]).abs().max().item()
+            assert err <= tol, (case, y0, err, tol)
+    assert _rel(gM, gMo) <= 5e-5
+
+
 @pytest.mark.parametrize("angle,scale", [(20.0, 1.0), (45.0, 1.0), (0.0, 1.35), (33.0, 0.8)])
 def test_boxes_walked_in_several_passes(oracle, angle, scale):
     """Rotations and magnifications whose boxes exceed what a workgroup holds in registers (6144 pixels): the persistent loop walks them
