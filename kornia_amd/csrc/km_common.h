@@ -152,16 +152,26 @@ static inline uint32_t km_stream_stores(uint64_t out_bytes) {
     return 0u;
 #endif
 }
-__device__ __forceinline__ void km_st_pol(float* p, float v, bool stream) {
-    if (stream) __builtin_nontemporal_store(v, p);
+// The policy as a COMPILE-TIME parameter.  (Round 2's form - a bool argument, `if (stream) nontemporal_store else plain store` - compiled to
+// plain stores in every instantiation: the two stores of the if / else are merged into one before the constant reaches them, and the merge
+// drops the non-temporal mark; found in round 3 by reading the ISA of the forward - its hot path had not streamed a byte since.)
+#ifndef KM_FWD_PLAIN_ST
+#define KM_FWD_PLAIN_ST 0   // 1: the forward's compile-time policy is forced to plain stores (A/B against round 2's accidental behaviour)
+#endif
+template <bool STREAM>
+__device__ __forceinline__ void km_st_c(float* p, float v) {
+    if constexpr (STREAM && !KM_FWD_PLAIN_ST) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 __device__ __forceinline__ void km_st(double* p, double v) { *p = v; }
 __device__ __forceinline__ void km_st(km_bf16* p, float v) { p->bits = km_f32_to_bf16_bits(v); }
 __device__ __forceinline__ void km_st(km_f16* p, float v) { *p = (km_f16)v; }
-__device__ __forceinline__ void km_st_pol(double* p, double v, bool) { *p = v; }
-__device__ __forceinline__ void km_st_pol(km_bf16* p, float v, bool) { km_st(p, v); }  // (2-byte stores: no streaming form worth having)
-__device__ __forceinline__ void km_st_pol(km_f16* p, float v, bool) { km_st(p, v); }
+template <bool STREAM>
+__device__ __forceinline__ void km_st_c(double* p, double v) { *p = v; }
+template <bool STREAM>
+__device__ __forceinline__ void km_st_c(km_bf16* p, float v) { km_st(p, v); }  // (2-byte stores: no streaming form worth having)
+template <bool STREAM>
+__device__ __forceinline__ void km_st_c(km_f16* p, float v) { km_st(p, v); }
 
 // a compute-precision value as the storage dtype T would hold it (used where the reference materialises an intermediate)
 __device__ __forceinline__ float km_round_as(float v, const float*) { return v; }
@@ -266,6 +276,11 @@ __device__ __forceinline__ uint32_t km_xcd_remap(uint32_t bid, uint32_t nblocks,
 #ifndef KM_SCHED_FENCE
 #define KM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// An opaque copy of a per-lane value: what is computed from it stays where it is written (not hoisted out of a loop, not merged with
+// the same computation elsewhere).  No code is emitted (the host build of the kernels defines it away).
+#ifndef KM_OPAQUE
+#define KM_OPAQUE(v) asm volatile("" : "+v"(v))
+#endif
 
 // Direction of the next launch of a streaming kernel on stream s (host side, km_runtime.hip).  The kernels of the hot step each stream
 // ~0.8 GB in and out, three times the 256 MB Infinity Cache, so a consumer that walks the batch in the producer's order finds
@@ -277,7 +292,7 @@ uint32_t km_traversal_next(hipStream_t s);
 // Launch policy, read once from the environment when the library is first used (km_runtime.hip); see profiles/README.md
 struct KmConfig {
     int traversal_fixed;    // KM_TRAVERSAL=fixed
-    int warp_fwd_algo;      // KM_WARP_FWD_ALGO: 0 default, 1 generic, 2 lds
+    int warp_fwd_algo;      // KM_WARP_FWD_ALGO: 0 default, 1 generic, 3 box (km_warp_fwd_box_kernel), 4 rows (the gather kernel)
     int warp_gm_algo;       // KM_WARP_GM_ALGO: 0 default, 1 generic, 2 lds
     int warp_bwd_generic;   // KM_WARP_BWD_ALGO=generic
     int warp_bwd_fused;     // KM_WARP_BWD_FUSED=0 turns the one-read backward off (two launches)

@@ -34,7 +34,8 @@ static int km_env_first(const char* name, char c0, char c1 = 0) {
 static void km_config_init() {
     KmConfig& c = g_km_config;
     c.traversal_fixed = km_env_first("KM_TRAVERSAL", 'f');
-    c.warp_fwd_algo = km_env_first("KM_WARP_FWD_ALGO", 'g', 'l');   // 1 generic, 2 lds
+    c.warp_fwd_algo = km_env_first("KM_WARP_FWD_ALGO", 'g');        // 1 generic, 3 box, 4 rows (the gather kernel)
+    if (!c.warp_fwd_algo) c.warp_fwd_algo = km_env_first("KM_WARP_FWD_ALGO", 'b') ? 3 : (km_env_first("KM_WARP_FWD_ALGO", 'r') ? 4 : 0);
     c.warp_gm_algo = km_env_first("KM_WARP_GM_ALGO", 'g', 'l');     // 1 generic, 2 lds
     c.warp_bwd_generic = km_env_first("KM_WARP_BWD_ALGO", 'g');
     c.warp_bwd_fused = km_env_first("KM_WARP_BWD_FUSED", '0') ? 0 : 1;

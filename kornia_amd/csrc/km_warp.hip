@@ -417,7 +417,7 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
 #pragma unroll
             for (int c = 0; c < NCC; ++c) {
                 const float acc = km_fma(v[r][c][3], w11, km_fma(v[r][c][2], w10, km_fma(v[r][c][1], w01, km_fma(v[r][c][0], w00, 0.0f))));
-                km_st_pol(km_at_mut(dp[c], oo), acc, STREAM);  // (compile-time: a run-time policy test at each of the 12 stores cost 4 % of the kernel)
+                km_st_c<STREAM>(km_at_mut(dp[c], oo), acc);  // (compile-time: a run-time policy test at each of the 12 stores cost 4 % of the kernel)
             }
         }
         return;
@@ -697,104 +697,196 @@ static bool km_fwd_generic_forced() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-staged forward (bilinear + zeros, RGB / grey, fp32 compute): the default for the hot configuration.
+// Box forward (bilinear + zeros, RGB / grey, fp32 compute): the source box of an output tile through LDS, with the block's serial
+// latencies overlapped.
 //
-// The gather forward above is bound by the texture-address path, not by HBM or the ALUs: every output pixel issues two
-// 8-byte gathers per channel and a wave-wide gather costs ~30 cycles of address processing whatever it hits
-// (profiles/r02_*: 51 % of the wave time is spent waiting to ISSUE memory instructions; halving the VALU count changed
-// nothing).  Here a 256-thread block owns a KMF_T x KMF_T tile of the OUTPUT, finds the box of source pixels its footprint
-// covers (the four tile corners pushed through the forward's own coordinate arithmetic + 1 px; a projective map sends the
-// tile to a convex quad), copies that box - all channels - into LDS with 16-byte row loads (zeros outside the image, which
-// is what zeros padding samples there: fma(0, w, acc) == acc), and samples from LDS with two-dword reads.  Per pixel the
-// memory pipeline sees 3 dword stores instead of 6 gathers + 3 stores; everything else is the lean front end.
-//   * every pixel checks that its 2 x 2 footprint lies inside the staged box (wave-uniform); a wave where one does not -
-//     a box larger than the LDS tile under strong minification, a tile crossed by the vanishing line, NaN positions - takes
-//     the gather path for its rows, so the result never depends on the box being right;
-//   * same fma chain (nw, ne, sw, se from 0), same positions: bit-identical to the other forwards and to the oracle.
-template <typename T, int CM, int NC, int ALIGN>
-__global__ __launch_bounds__(256) void km_warp_fwd_lds_kernel(const KmWarpArgs<T> a) {
+// What the gather forward costs is the bytes its lanes REQUEST (8 - 12 bytes per channel and pixel for 4 bytes of
+// output; a lane-per-pixel tile copy has a floor of ~0.32 ms at config 2, a 16-byte tile copy 0.285).  Here every source byte of
+// the tile's box is requested once, with 16-byte row loads, and every tap is a ds_read2_b32.  The first LDS forward
+// (round 2's km_warp_fwd_lds_kernel, removed: 32 x 32 tiles, 112 registers, box -> barrier -> fill -> barrier -> positions -> sample, one after
+// the other) lost to the gathers (0.42 - 0.44 against 0.39 ms); this one is built around what that one lacked:
+//   * the fill's loads are issued FIRST and the thread's positions (~70 instructions each, independent of the loads) are computed
+//     while they fly; the only wait of the block is the one before the LDS stores;
+//   * the block-uniform matrix sits in scalar registers before the fill is requested (left in flight, the wait for it lands behind
+//     the fill's requests - which sit under lane predicates the compiler cannot count - and becomes a wait for the whole fill);
+//   * no persistent loop and no double buffer inside a block: 4 - 6 blocks per CU, whose phases interleave, are the overlap;
+//   * lane = output column (ds_read2_b32 of neighbouring lanes hit neighbouring banks, stores are whole 128 / 256-byte runs).
+// Same positions, same fma chain (nw, ne, sw, se from 0), zeros staged outside the image (fma(0, w, acc) == acc for the finite
+// weights of a finite position): bit-identical to the other forwards and to the oracle.
+// A block whose box does not fit (rotation, minification, the vanishing line: block-uniform) runs the gather rows of the kernel above
+// - same speed as that kernel plus the box computation; a wave with a footprint outside its box (box estimate off, NaN position)
+// gathers its rows one at a time.  The result never depends on the box estimate.
+// Shapes: KmbWide (64 x 32 tile, box up to 80 x 40: axis-aligned maps, +-7 degrees - the flagship homographies) and KmbSquare
+// (32 x 32 tile, box up to 52 x 50: ANY rotation at scale ~1; 16-bit storage, where a staged element costs half).
+struct KmbWide   { static constexpr int TW = 64, TH = 32, PITCH = 80, ROWS = 40, WAVES = 4; };
+struct KmbWide16 { static constexpr int TW = 64, TH = 16, PITCH = 80, ROWS = 24, WAVES = 5; };
+struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50, WAVES = 5; };
+#ifndef KMB_SHAPE_F32
+#define KMB_SHAPE_F32 KmbWide
+#endif
+#ifndef KMB_SHAPE_16
+#define KMB_SHAPE_16 KmbSquare
+#endif
+
+// the rows of a thread by gathers, one row at a time (plain IEEE divisions: any operands; every tap predicated): what a wave with a
+// footprint outside its box falls back to.  Deliberately small - the registers of the kernel are the maximum over its paths.
+template <typename T, int CM, int NC, int ALIGN, int RPT>
+__device__ __forceinline__ void kmb_gather_rows(const KmWarpArgs<T>& a, const float (&m)[9], const float4* s_rv, uint32_t b, int j, int li_base, int i_base) {
     const KmWarpGeom<float>& g = a.g;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks);
+    const int W = g.W, H = g.H;
+    const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
+    const T* __restrict__ src_b = a.src + (size_t)b * NC * src_plane;
+    T* __restrict__ dst_b = a.dst + (size_t)b * NC * dst_plane;
+    const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
+    const KmlHalf cu = kml_col_half<CM>(m, km_base_x<float, CM>(g, j));
+#pragma unroll 1
+    for (int r = 0; r < RPT; ++r) {
+        if (i_base + r >= g.h) break;
+        const float4 rv4 = s_rv[li_base + r];
+        KmlHalf rv;
+        rv.a = rv4.x; rv.b = rv4.y; rv.c = rv4.z;
+        KmlPos p;
+        kml_position<CM, false>(m, cu, rv, p);
+        KmBilin<float> tr;
+        km_bilinear_setup(kml_unnormalize<ALIGN>(p.gx, Wm1, hW), kml_unnormalize<ALIGN>(p.gy, Hm1, hH), W, H, tr);
+        T* __restrict__ out_px = dst_b + (size_t)(i_base + r) * g.w + j;
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            const T* img = src_b + (size_t)c * src_plane;
+            const float v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01);
+            const float v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
+            float acc = 0;
+            acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
+            acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
+            acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
+            acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+            km_st(out_px + (size_t)c * dst_plane, acc);
+        }
+    }
+}
+
+template <typename T, int CM, int NC, int ALIGN, bool STREAM, typename SH>
+__global__ __launch_bounds__(256, SH::WAVES) void km_warp_fwd_box_kernel(const KmWarpArgs<T> a) {
+    constexpr int TW = SH::TW, TH = SH::TH, PITCH = SH::PITCH, ROWS = SH::ROWS;
+    constexpr int RSLOTS = 256 / TW;       // threads per output column
+    constexpr int RPT = TH / RSLOTS;       // output rows per thread (consecutive)
+    constexpr int NCHK = PITCH / 4;        // 16-byte chunks per staged row of one channel
+    constexpr int RCPP = 256 / NCHK;       // (row, channel) pairs filled per pass of the block
+    static_assert(TW == 64 || TW == 32, "lane = output column");
+    static_assert(RPT % KM_ROWS == 0, "the gather rows walk KM_ROWS rows at a time");
+    static_assert(TH <= 64 && PITCH % 4 == 0, "one wave fills the row table; whole chunks");
+    const KmWarpGeom<float>& g = a.g;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
     const int tid = threadIdx.x;
-    const int j = (int)tx * KMF_T + (tid % KMF_T);
-    const int li_base = tid / KMF_T;                 // this thread's rows: li_base + r * KMF_RSTEP
-    const int i_base = (int)ty * KMF_T + li_base;
-    __shared__ float4 s_rv[KMF_T];
+    const int j = (int)tx * TW + (tid % TW);
+    const int li_base = (tid / TW) * RPT;             // this thread's rows: li_base + r
+    const int i_base = (int)ty * TH + li_base;
+    __shared__ float4 s_rv[TH];
     __shared__ int s_info[8];
-    __shared__ __attribute__((aligned(16))) float s_src[KMF_ROWS * NC * KMF_PITCH];  // [row][channel][x]
+    __shared__ __attribute__((aligned(16))) float s_src[ROWS * NC * PITCH];  // [row][channel][x]
 
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
+        km_fwd_copy_rows<T>(a, b, j, i_base, 1, RPT);
+        return;
+    }
     float m[9];
     {
         const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+        for (int k = 0; k < 9; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[k])));
     }
-    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
-        km_fwd_copy_rows<T>(a, b, j, i_base, KMF_RSTEP, KMF_RPT);
-        return;
-    }
-    kmf_tile_setup<CM, ALIGN>(g, m, (int)tx * KMF_T, (int)ty * KMF_T, s_rv, s_info, false);
+    kmf_tile_setup<CM, ALIGN, 0, TW, TH, PITCH, ROWS>(g, m, (int)tx * TW, (int)ty * TH, s_rv, s_info, false);
     __syncthreads();
     const KmfBox bx = kmf_read_box(s_info);
-    if (!bx.staged) {  // block-uniform
+    if (!bx.staged) {  // block-uniform: the gather rows of km_warp_fwd_lean_kernel
         if (j >= g.w) return;
-        if (bx.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
-        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
+#pragma unroll
+        for (int q = 0; q < RPT / KM_ROWS; ++q) {
+            if (bx.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, 1, STREAM>(a, m, s_rv, b, j, li_base + q * KM_ROWS, i_base + q * KM_ROWS);
+            else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, 1, STREAM>(a, m, s_rv, b, j, li_base + q * KM_ROWS, i_base + q * KM_ROWS);
+        }
         return;
     }
     const int W = g.W, H = g.H;
-    const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
     const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
     const T* __restrict__ src_b = a.src + (size_t)b * NC * src_plane;
     T* __restrict__ dst_b = a.dst + (size_t)b * NC * dst_plane;
-    float oob[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) oob[c] = 0.f;
-    kmf_stage_box<T, NC>(src_b, src_plane, W, H, bx, s_src, oob);
-    __syncthreads();
-    if (j >= g.w) return;
 
-    // ---- sample ----
+    // ---- the fill's requests: thread = (chunk of 4 columns, (row, channel) pair of the pass) ----
+    constexpr int NPASS = (ROWS * NC + RCPP - 1) / RCPP;
+    const int ck = tid % NCHK, rq = tid / NCHK;
+    const int xg = bx.xs + 4 * ck;
+    const bool filler = (rq < RCPP) && (ck < bx.nch);
+    const bool col_in = (xg >= 0) && (xg + 3 < W);  // W % 4 == 0 and xs % 4 == 0: a chunk is inside or outside as a whole
+    const int nrc = bx.nrows * NC;
+    float v[NPASS][4];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int rc = ps * RCPP + rq, r = rc / NC, c = rc - r * NC, y = bx.ys + r;
+        const bool inb = filler && col_in && (rc < nrc) && (y >= 0) && (y < H);
+        v[ps][0] = 0.f; v[ps][1] = 0.f; v[ps][2] = 0.f; v[ps][3] = 0.f;
+        if (ps * RCPP < nrc) {  // block-uniform
+            if (inb) km_ld4(km_at(src_b + c * src_plane, (uint32_t)y * (uint32_t)W + (uint32_t)xg), v[ps]);
+        }
+    }
+
+    // ---- this thread's positions, while the requests fly ----
+    const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
     const KmlHalf cu = kml_col_half<CM>(m, km_base_x<float, CM>(g, j));
-    KmlTaps t[KMF_RPT];
+    KmlTaps t[RPT];
     bool inbox = true;
 #pragma unroll
-    for (int r = 0; r < KMF_RPT; ++r) {
-        const float4 rv4 = s_rv[li_base + r * KMF_RSTEP];
+    for (int r = 0; r < RPT; ++r) {
+        const float4 rv4 = s_rv[li_base + r];
         KmlHalf rv;
         rv.a = rv4.x; rv.b = rv4.y; rv.c = rv4.z;
         KmlPos p;
         if (bx.fast) kml_position<CM, true>(m, cu, rv, p);
         else kml_position<CM, false>(m, cu, rv, p);
         kml_taps(kml_unnormalize<ALIGN>(p.gx, Wm1, hW), kml_unnormalize<ALIGN>(p.gy, Hm1, hH), t[r]);
-        // (rows of the tile below the image bottom are not stored: no constraint)
-        inbox = inbox & (kmf_in_box(t[r], bx) | (i_base + r * KMF_RSTEP >= g.h));
+        // (rows of the tile below the image bottom and columns right of it are not stored: no constraint)
+        inbox = inbox & (kmf_in_box(t[r], bx) | (i_base + r >= g.h) | (j >= g.w));
     }
+
+    // ---- requests -> LDS ----
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int rc = ps * RCPP + rq;
+        if (filler && rc < nrc) {
+            float* q = s_src + rc * PITCH + 4 * ck;
+            KM_CHECK_ALIGNED(q, 16);
+            *reinterpret_cast<float4*>(q) = make_float4(v[ps][0], v[ps][1], v[ps][2], v[ps][3]);
+        }
+    }
+    __syncthreads();
+    if (j >= g.w) return;
     if (!__all(inbox)) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
-        if (bx.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
-        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, KMF_RSTEP>(a, m, s_rv, b, j, li_base, i_base);
+        kmb_gather_rows<T, CM, NC, ALIGN, RPT>(a, m, s_rv, b, j, li_base, i_base);
         return;
     }
+
+    // ---- sample ----
     T* __restrict__ dp[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) dp[c] = dst_b + c * dst_plane;
     const uint32_t out0 = (uint32_t)i_base * (uint32_t)g.w + (uint32_t)j;
 #pragma unroll
-    for (int r = 0; r < KMF_RPT; ++r) {
-        const bool row_ok = i_base + r * KMF_RSTEP < g.h;
-        const float* q0 = kmf_tap_ptr<NC>(s_src, t[r], bx, row_ok);  // rows below the image bottom read the box origin (never stored)
-        const float* q1 = q0 + NC * KMF_PITCH;
+    for (int r = 0; r < RPT; ++r) {
+        if (i_base + r >= g.h) break;  // (the tile hangs over the bottom edge; the rows that follow do too)
+        const int xi = KM_F2I(t[r].xf) - bx.xs, yi = KM_F2I(t[r].yf) - bx.ys;
+        const float* q0 = s_src + __mul24(yi, NC * PITCH) + xi;
+        const float* q1 = q0 + NC * PITCH;
         const float w00 = t[r].wx1 * t[r].wy1, w01 = t[r].wx0 * t[r].wy1, w10 = t[r].wx1 * t[r].wy0, w11 = t[r].wx0 * t[r].wy0;
-        const uint32_t oo = out0 + (uint32_t)(r * KMF_RSTEP) * (uint32_t)g.w;
+        const uint32_t oo = out0 + (uint32_t)r * (uint32_t)g.w;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float v00 = q0[c * KMF_PITCH], v01 = q0[c * KMF_PITCH + 1], v10 = q1[c * KMF_PITCH], v11 = q1[c * KMF_PITCH + 1];
+            const float v00 = q0[c * PITCH], v01 = q0[c * PITCH + 1], v10 = q1[c * PITCH], v11 = q1[c * PITCH + 1];
             const float acc = km_fma(v11, w11, km_fma(v10, w10, km_fma(v01, w01, km_fma(v00, w00, 0.0f))));
-            if (row_ok) km_st(km_at_mut(dp[c], oo), acc);
+            km_st_c<STREAM>(km_at_mut(dp[c], oo), acc);
         }
     }
 }
@@ -821,28 +913,51 @@ static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
     else
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
 }
-static int km_fwd_algo() {  // KM_WARP_FWD_ALGO: "generic" | "lds" (LDS-staged kernel, A/B timing) | default: the lean gather kernel
-    return km_config().warp_fwd_algo == 2 ? 1 : 0;
-}
-template <typename T, int CM, int NC>
-static void km_warp_fwd_lds_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
-    const uint32_t tiles_x = (uint32_t)((a.g.w + KMF_T - 1) / KMF_T), tiles_y = (uint32_t)((a.g.h + KMF_T - 1) / KMF_T);
+template <typename T, int CM, int NC, typename SH>
+static void km_warp_fwd_box_launch_sh(const KmWarpArgs<T>& a, hipStream_t s) {
     KmWarpArgs<T> b = a;
-    b.tiles_x = tiles_x; b.tiles_y = tiles_y; b.nblocks = tiles_x * tiles_y * (uint32_t)a.g.B;
-    if (a.g.align)
-        hipLaunchKernelGGL((km_warp_fwd_lds_kernel<T, CM, NC, 1>), dim3(b.nblocks), dim3(256), 0, s, b);
-    else
-        hipLaunchKernelGGL((km_warp_fwd_lds_kernel<T, CM, NC, 0>), dim3(b.nblocks), dim3(256), 0, s, b);
+    b.tiles_x = (uint32_t)((a.g.w + SH::TW - 1) / SH::TW);
+    b.tiles_y = (uint32_t)((a.g.h + SH::TH - 1) / SH::TH);
+    b.nblocks = b.tiles_x * b.tiles_y * (uint32_t)a.g.B;
+    b.reverse = km_traversal_next(s);
+    b.stream_out = km_stream_stores((uint64_t)a.g.B * a.g.C * a.g.h * a.g.w * sizeof(T));
+    if (a.g.align) {
+        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, true, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, false, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
+    } else {
+        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, true, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, false, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
+    }
 }
+// the shape by storage type: a staged element of a 16-bit image costs half the requests, so the square, rotation-proof tile pays there
+template <typename T, int CM, int NC>
+static void km_warp_fwd_box_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) km_warp_fwd_box_launch_sh<T, CM, NC, KMB_SHAPE_16>(a, s);
+    else km_warp_fwd_box_launch_sh<T, CM, NC, KMB_SHAPE_F32>(a, s);
+}
+template <typename T>
+static uint64_t km_warp_fwd_box_blocks(const KmWarpArgs<T>& a) {
+    const int tw = sizeof(T) == 2 ? KMB_SHAPE_16::TW : KMB_SHAPE_F32::TW, th = sizeof(T) == 2 ? KMB_SHAPE_16::TH : KMB_SHAPE_F32::TH;
+    return (uint64_t)((a.g.w + tw - 1) / tw) * (uint64_t)((a.g.h + th - 1) / th) * (uint64_t)a.g.B;
+}
+#ifndef KM_FWD_BOX_DEFAULT
+#define KM_FWD_BOX_DEFAULT 1      // fp32 storage: the box forward is what the hot configuration runs (KM_WARP_FWD_ALGO=rows: the gather kernel)
+#endif
+#ifndef KM_FWD_BOX_DEFAULT_16
+#define KM_FWD_BOX_DEFAULT_16 0   // 16-bit storage
+#endif
 template <typename T, int CM>
 static void km_warp_fwd_lean_launch(const KmWarpArgs<T>& a, hipStream_t s) {
     if constexpr (CM != KM_COORD_GRID && sizeof(typename KmTraits<T>::R) == sizeof(float)) {  // (never instantiated otherwise)
-        // LDS staging: RGB / grey, rows of whole 4-element chunks (16-byte loads for fp32, 8-byte for the 16-bit types)
-        const uint64_t nb = (uint64_t)((a.g.w + KMF_T - 1) / KMF_T) * (uint64_t)((a.g.h + KMF_T - 1) / KMF_T) * (uint64_t)a.g.B;
-        if ((a.g.C == 3 || a.g.C == 1) && (a.g.W & 3) == 0 && ((uintptr_t)a.src % (4 * sizeof(T))) == 0 && nb < (1ull << 31) && km_fwd_algo() == 1) {
-            if (a.g.C == 3) km_warp_fwd_lds_launch_nc<T, CM, 3>(a, s);
-            else km_warp_fwd_lds_launch_nc<T, CM, 1>(a, s);
-            return;
+        {
+            const uint64_t nbb = km_warp_fwd_box_blocks(a);
+            const int algo = km_config().warp_fwd_algo;  // 0 default, 3 "box", 4 "rows"
+            const bool want_box = algo == 3 || ((sizeof(T) == 2 ? KM_FWD_BOX_DEFAULT_16 : KM_FWD_BOX_DEFAULT) && algo == 0);
+            if (want_box && (a.g.C == 3 || a.g.C == 1) && (a.g.W & 3) == 0 && ((uintptr_t)a.src % (4 * sizeof(T))) == 0 && nbb < (1ull << 31)) {
+                if (a.g.C == 3) km_warp_fwd_box_launch_nc<T, CM, 3>(a, s);
+                else km_warp_fwd_box_launch_nc<T, CM, 1>(a, s);
+                return;
+            }
         }
         if (a.g.C == 3) km_warp_fwd_lean_launch_nc<T, CM, 3>(a, s);
         else if (a.g.C == 1) km_warp_fwd_lean_launch_nc<T, CM, 1>(a, s);

@@ -43,6 +43,23 @@
 #include "km_warp_gm_rows.h"
 #include "km_warp_tile.h"
 
+// KMO_PROFILE (variant libraries only, profiles/time_bwd_phases.py): every wave sums the shader cycles (s_memtime) it spends in each phase
+// of the tile loop; km_debug_fused_profile() copies the table out.  Costs ~10 % of the kernel; the default build has none of it.
+#ifdef KMO_PROFILE
+#define KMO_PROF_PHASES 8
+__device__ unsigned long long kmo_prof_out[512 * 16 * KMO_PROF_PHASES];
+#define KMO_T(k)                                                              \
+    {                                                                         \
+        KM_SCHED_FENCE();                                                     \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();           \
+        prof[k] += t_ - tlast;                                                \
+        tlast = t_;                                                           \
+        KM_SCHED_FENCE();                                                     \
+    }
+#else
+#define KMO_T(k)
+#endif
+
 #ifndef KMO_NT
 #define KMO_NT 1024        // threads per workgroup (one workgroup per CU: 16 waves)
 #endif
@@ -691,19 +708,31 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
     uint32_t bound_bits = 0;   // ... chosen for |grad_out| <= this (bit pattern)
     bool tile_ok = true;       // no non-finite gradient met so far
 
+#ifdef KMO_PROFILE
+    unsigned long long prof[KMO_PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     // A work item is (tile, pass): a box larger than the registers of the workgroup (KMO_CAP pixels: rotations beyond ~10 degrees,
     // magnification) is walked in several passes, the next pass requested slot by slot during the current one like a next tile.
     for (uint32_t q = 0; cur.t >= 0;) {
         // ---- this item's requests have arrived: (first pass: source tile -> LDS, coordinate tables;) exact maximum of |grad_out| over the
         //      pass - consumed BEFORE the flush of the previous tile issues its stores (a wait for loads that has stores behind it in the
         //      queue waits for those too)
+        KMO_T(7)  // (loop tail of the previous item)
+#ifdef KMO_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        KMO_T(0)  // wait for this item's requests
         kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, fillv, is_fill, lane, wave);
+        KMO_T(1)  // stage: source tile -> LDS, maxima, tables
         // ---- flush of the previous tile (zeroes the accumulators) ----
         if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale, prev_discard);
         prev.t = -1;
+        KMO_T(2)  // flush
         const bool last_pass = cur.p + 1 >= cur.npass;
         if (wave == 0 && last_pass && (q + 1u) % KMO_RUN == 0u) kmo_fetch_boxes(a, q + 1u, lane, l.s_box);  // (into the half of the ring tile q is not in)
         KM_LDS_BARRIER();  // B1: source tile, maxima, tables in LDS, accumulators zero (first pass)
+        KMO_T(3)  // barrier B1
 
         // ---- the NEXT item: the next pass of this box, or the first pass of the next tile (whose source tile is requested after the
         //      first slot of the scatter); its grad_out slot by slot during the scatter ----
@@ -763,12 +792,15 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         }
         const bool mine = cur.regular && tile_ok;  // this launch scatters this item
         const float scale = kmt_uniform(ldexpf(1.0f, kexp)), inv_scale = kmt_uniform(ldexpf(1.0f, -kexp));
+        KMO_T(4)  // next item's description, matrix-gradient commit, scale
         {
             float m[9];
             kmo_matrix(kmo_ring(l.s_box, q), m);
             kmo_process<T, CM, ALIGN, CC, true, true>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, l.s_src, scale, A, g.w, wn, gout_n, mine, a, nxt, S);
         }
+        KMO_T(5)  // scatter
         KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
+        KMO_T(6)  // barrier B2
 
         if (last_pass) {
             // ---- an image that ends here publishes its matrix-gradient partials ----
@@ -791,6 +823,12 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         cur = nxt;
     }
     if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale, prev_discard);
+#ifdef KMO_PROFILE
+    if (lane == 0 && blockIdx.x < 512u) {
+#pragma unroll
+        for (int k = 0; k < KMO_PROF_PHASES; ++k) kmo_prof_out[((size_t)blockIdx.x * 16 + (wave & 15)) * KMO_PROF_PHASES + k] = prof[k];
+    }
+#endif
     // ---- epilogue: the last image's partials ----
     __syncthreads();
     if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
@@ -935,3 +973,10 @@ int km_warp_bwd_fused_run(const void* gout, const void* src, const void* mat, vo
 #endif
     }
 }
+
+#ifdef KMO_PROFILE
+// (variant libraries only) the per-wave phase table of the last persistent launch: [worker][wave][phase] shader cycles
+extern "C" int km_debug_fused_profile(unsigned long long* host_out, int n_entries) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(kmo_prof_out), (size_t)n_entries * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

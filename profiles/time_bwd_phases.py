@@ -1,0 +1,46 @@
+"""Where the tile loop of the one-read backward spends its time: a variant library built with -DKMO_PROFILE sums, per wave, the shader cycles
+(s_memtime) of each phase of the loop; this prints the per-tile means over waves and workers.
+  KORNIA_AMD_LIB=kornia_amd/lib/var/lib_prof.so python profiles/time_bwd_phases.py      LAB_B: batch (default 256)"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from kornia_amd import _native as N
+lib = N.lib(); dev = torch.device('cuda')
+raw = ctypes.CDLL(os.environ["KORNIA_AMD_LIB"])
+B, C, S = int(os.environ.get("LAB_B", 256)), 3, 512
+g = torch.Generator().manual_seed(0); gg = torch.Generator(device=dev).manual_seed(0)
+x = torch.rand(B, C, S, S, device=dev, generator=gg); M = bench.flagship_homographies(B, S, S, g).to(dev)
+go = torch.rand(B, C, S, S, device=dev, generator=gg)
+stream = N.stream_ptr(dev)
+lib.km_set_traversal(1)
+m = torch.empty(B, 9, device=dev); N.check(lib.km_homography_chain_fwd(M.data_ptr(), 3, None, m.data_ptr(), B, S, S, S, S, 0, stream), "c")
+nbytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, S, S, S, S, 1, 0, 0))
+ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+gsrc = torch.empty_like(x); gm = torch.zeros(B, 9, device=dev, dtype=torch.float64)
+def f():
+    gm.zero_()
+    N.check(lib.km_warp2d_bwd_ws(go.data_ptr(), x.data_ptr(), m.data_ptr(), gsrc.data_ptr(), gm.data_ptr(), B, C, S, S, S, S, B, 0, 1, 1, 0, 1, None, 0,
+                                 ws.data_ptr(), nbytes, stream), "bwd")
+t = bench.event_time_ms(f, 10)
+torch.cuda.synchronize()
+NW, PH = 16, 8
+workers = 256
+out = (ctypes.c_ulonglong * (512 * NW * PH))()
+raw.km_debug_fused_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = raw.km_debug_fused_profile(out, 512 * NW * PH)
+a = np.frombuffer(out, dtype=np.uint64).reshape(512, NW, PH)[:workers].astype(np.float64)
+tiles_per_worker = B * 64 / workers
+names = ["wait for requests", "stage (src->LDS, max, tables)", "flush of previous tile", "barrier B1 (+ box records)", "describe next, gm commit, scale",
+         "scatter (+ next requests)", "barrier B2", "loop tail (image end sums)"]
+tot = a.sum(axis=2)
+print(f"rc {rc}  kernel+boxes+general {t:.4f} ms  B={B}  tiles/worker {tiles_per_worker:.1f}  cycles per wave (mean) {tot.mean():.0f} = {tot.mean()/tiles_per_worker:.0f} per tile"
+      f"  -> {tot.mean()/ (t*1e-3) / 1e9:.2f} GHz if the loop is the whole launch")
+for k in range(PH):
+    v = a[:, :, k] / tiles_per_worker
+    print(f"  {names[k]:34s} mean {v.mean():8.0f}  min-wave {v.min():8.0f}  max-wave {v.max():8.0f}   {100*a[:,:,k].sum()/tot.sum():5.1f} %")
+# the slowest / fastest wave of a workgroup in the scatter
+sc = a[:, :, 5] / tiles_per_worker
+print(f"  scatter: per-workgroup spread (max - min over its 16 waves), mean over workgroups: {(sc.max(axis=1)-sc.min(axis=1)).mean():.0f} cycles")

@@ -14,6 +14,11 @@ g = torch.Generator().manual_seed(0); gg = torch.Generator(device=dev).manual_se
 x = torch.rand(B, C, S, S, device=dev, generator=gg); M = bench.flagship_homographies(B, S, S, g).to(dev)
 if os.environ.get('LAB_IDENTITY'):  # identity / pure translation: the kernels' structure without the perspective access pattern
     M = torch.eye(3).repeat(B, 1, 1); M[:, 0, 2] = float(os.environ['LAB_IDENTITY']); M = M.to(dev)
+if os.environ.get('LAB_ROT'):  # rotation about the image centre by LAB_ROT degrees, scale LAB_SCALE (default 1)
+    import math
+    th = math.radians(float(os.environ['LAB_ROT'])); sc = float(os.environ.get('LAB_SCALE', 1.0))
+    ca, sa, c0 = sc * math.cos(th), sc * math.sin(th), (S - 1) / 2
+    M = torch.tensor([[ca, sa, (1 - ca) * c0 - sa * c0], [-sa, ca, sa * c0 + (1 - ca) * c0], [0.0, 0.0, 1.0]]).repeat(B, 1, 1).to(dev)
 go = torch.rand(B, C, S, S, device=dev, generator=gg)
 stream = N.stream_ptr(dev)
 lib.km_set_traversal(0 if os.environ.get('LAB_ALTERNATE') else 1)  # one kernel over one input: fixed direction (bench.py: kernel_roofline)

@@ -119,6 +119,7 @@ inline int emu_cvt_i32_f32(float v) {
 #define KM_CVT_RPI(v) emu_cvt_rpi_i32_f32(v)
 #define KM_LDS_BARRIER() __syncthreads()
 #define KM_SCHED_FENCE() ((void)0)
+#define KM_OPAQUE(v) ((void)0)
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 

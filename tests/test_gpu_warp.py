@@ -376,3 +376,54 @@ def test_bicubic_lds_staged_kernel_is_bit_identical(oracle, C, dtype):
     Hn = torch.eye(3)[None].repeat(B, 1, 1) + 0.05 * torch.randn(B, 3, 3, generator=g)
     goth = K.homography_warp(xd, Hn.cuda(), (H, W), "bicubic", "zeros", True)
     assert torch.equal(goth, K.homography_warp(off, Hn.cuda(), (H, W), "bicubic", "zeros", True))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [1, 3])
+def test_box_forward_is_bit_identical(oracle, C, dtype):
+    """The box forward (km_warp_fwd_box_kernel: the source box of a 64 x 16 output tile through LDS, bilinear + zeros) against the gather
+    forward (KM_WARP_FWD_ALGO=rows) and, in fp32, the oracle, bit for bit: flagship homographies, small and large rotations (boxes that do
+    not fit -> the gather path inside the kernel), minification, magnification, a map that leaves the image, output sizes that are not
+    multiples of the tile, both align_corners, affine / homography coordinate modes, the per-sample switch."""
+    import kornia_amd as K
+    from kornia_amd import _native as N
+
+    lib = N.lib()
+    g = torch.Generator().manual_seed(43)
+    B, H, W = 7, 72, 96
+    x = torch.rand(B, C, H, W, generator=g).to(dtype)
+    ang = torch.tensor([2.0, 31.0, -88.0, 5.0, 0.0, 170.0, 45.0]) * math.pi / 180
+    sc = torch.tensor([1.0, 1.0, 1.1, 0.35, 2.7, 1.0, 0.9])
+    a, b = sc * ang.cos(), sc * ang.sin()
+    cx, cy = (W - 1) / 2, (H - 1) / 2
+    A = torch.stack([torch.stack([a, b, (1 - a) * cx - b * cy + torch.tensor([0.3, -4.0, 2.0, 0.0, 1.5, 0.0, 40.0])], -1),
+                     torch.stack([-b, a, b * cx + (1 - a) * cy + torch.tensor([-0.7, 3.0, 0.0, 2.5, 0.0, -1.0, -25.0])], -1)], 1)
+    M = torch.cat([A, torch.tensor([[0.0, 0.0, 1.0]]).expand(B, 1, 3)], 1).clone()
+    M[:, 2, 0] = torch.tensor([0.0, 1e-3, -2e-3, 0.0, 5e-4, 0.0, 2e-3])
+    M[:, 2, 1] = torch.tensor([0.0, -1e-3, 1e-3, 2e-3, 0.0, 0.0, -1e-3])
+    Mf = flagship_homographies(B, H, W, 150, 200, g, jitter=4.0)
+    Hn = torch.eye(3)[None].repeat(B, 1, 1) + 0.05 * torch.randn(B, 3, 3, generator=g)
+    xd = x.cuda()
+
+    def both(fn):
+        outs = []
+        for algo in (3, 4):
+            prev = lib.km_config_set(b"warp_fwd_algo", algo)
+            try:
+                outs.append(fn())
+            finally:
+                lib.km_config_set(b"warp_fwd_algo", prev)
+        assert torch.equal(outs[0], outs[1])
+        return outs[0]
+
+    for ds in ((H, W), (50, 64), (33, 130), (150, 200)):
+        for align in (True, False):
+            got = both(lambda: K.warp_affine(xd, A.cuda(), ds, "bilinear", "zeros", align))
+            gotp = both(lambda: K.warp_perspective(xd, M.cuda(), ds, "bilinear", "zeros", align))
+            gotf = both(lambda: K.warp_perspective(xd, Mf.cuda(), ds, "bilinear", "zeros", align))
+            if dtype == torch.float32:
+                assert torch.equal(got.cpu(), oracle.warp_affine(x, A, ds, "bilinear", "zeros", align, None)), (ds, align)
+                assert torch.equal(gotp.cpu(), oracle.warp_perspective(x, M, ds, "bilinear", "zeros", align, None)), (ds, align)
+                assert torch.equal(gotf.cpu(), oracle.warp_perspective(x, Mf, ds, "bilinear", "zeros", align, None)), (ds, align)
+    both(lambda: K.homography_warp(xd, Hn.cuda(), (H, W), "bilinear", "zeros", True))
+    both(lambda: K.homography_warp(xd, Hn.cuda(), (60, 100), "bilinear", "zeros", False))
