@@ -163,7 +163,7 @@ def kernel_roofline(sets, size, iters):
     # per LAUNCH: the bytes that launch itself must move (every tensor it reads once + every tensor it writes once)
     kernels = {}
     launches = [
-        ("km_warp_fwd_lean_kernel", warp_fwd, 2 * e * n_el, "read src, write out"),
+        ("km_warp_fwd_box_kernel", warp_fwd, 2 * e * n_el, "read src, write out"),
         ("km_blur_reg_kernel<fwd>", blur_fwd, 2 * e * n_el, "read x, write y"),
         ("km_blur_reg_kernel<bwd>", blur_bwd, 2 * e * n_el, "read grad_y, write grad_x"),
         ("km_warp_bwd_tiled_kernel", warp_bwd_gsrc, 2 * e * n_el, "read grad_out, write grad_src (the image gradient alone)"),
@@ -178,7 +178,7 @@ def kernel_roofline(sets, size, iters):
     ops = {}
     for name, fn, mult in (("km_warp2d_fwd", warp_fwd, 2), ("km_filter2d_sep_fwd", blur_fwd, 2), ("km_filter2d_sep_bwd_input", blur_bwd, 2),
                            ("km_warp2d_bwd", warp_bwd, 3)):
-        ms = kernels["km_warp_fwd_lean_kernel"]["ms"] if name == "km_warp2d_fwd" else (
+        ms = kernels["km_warp_fwd_box_kernel"]["ms"] if name == "km_warp2d_fwd" else (
             kernels["km_blur_reg_kernel<fwd>"]["ms"] if name == "km_filter2d_sep_fwd" else (
                 kernels["km_blur_reg_kernel<bwd>"]["ms"] if name == "km_filter2d_sep_bwd_input" else event_time_ms(fn, iters)))
         nbytes = mult * e * n_el
@@ -563,7 +563,7 @@ def main():
         if (B, C, S) == (256, 3, 512) and os.path.exists(PMC_FILE):
             pmc = json.load(open(PMC_FILE)).get("kernels", {})
             fused = "one read" in ops["km_warp2d_bwd"].get("form", "")
-            want = {"km_warp2d_bwd": ("km_warp_bwd_fused_kernel",) if fused else ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_lean_kernel",),
+            want = {"km_warp2d_bwd": ("km_warp_bwd_fused_kernel",) if fused else ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_box_kernel",),
                     "km_filter2d_sep_fwd": ("km_blur_reg_kernel<float, 5, false",), "km_filter2d_sep_bwd_input": ("km_blur_reg_kernel<float, 5, true",)}[dom_op]
             tot = 0
             for frag in want:

@@ -713,19 +713,25 @@ static bool km_fwd_generic_forced() {
 //   * lane = output column (ds_read2_b32 of neighbouring lanes hit neighbouring banks, stores are whole 128 / 256-byte runs).
 // Same positions, same fma chain (nw, ne, sw, se from 0), zeros staged outside the image (fma(0, w, acc) == acc for the finite
 // weights of a finite position): bit-identical to the other forwards and to the oracle.
-// A block whose box does not fit (rotation, minification, the vanishing line: block-uniform) runs the gather rows of the kernel above
-// - same speed as that kernel plus the box computation; a wave with a footprint outside its box (box estimate off, NaN position)
-// gathers its rows one at a time.  The result never depends on the box estimate.
-// Shapes: KmbWide (64 x 32 tile, box up to 80 x 40: axis-aligned maps, +-7 degrees - the flagship homographies) and KmbSquare
-// (32 x 32 tile, box up to 52 x 50: ANY rotation at scale ~1; 16-bit storage, where a staged element costs half).
-struct KmbWide   { static constexpr int TW = 64, TH = 32, PITCH = 80, ROWS = 40, WAVES = 4; };
-struct KmbWide16 { static constexpr int TW = 64, TH = 16, PITCH = 80, ROWS = 24, WAVES = 5; };
-struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50, WAVES = 5; };
-#ifndef KMB_SHAPE_F32
-#define KMB_SHAPE_F32 KmbWide
+// A wave with a footprint outside its box (box estimate off, NaN position) gathers its rows one at a time: the result never depends on
+// the box estimate.
+// A block owns a 64 x 32 region of the output and tries, in this order (every decision block-uniform):
+//   1. KmbWide:   the region as ONE tile, box up to 80 x 40 source pixels - axis-aligned maps up to ~7 degrees, the flagship homographies;
+//   2. KmbSquare: its two 32 x 32 halves one after the other, box up to 52 x 50 each - ANY rotation at scale ~1 (measured at 5 / 20 / 45
+//                 degrees: 0.37 - 0.39 ms where the gather kernel takes 0.47 / 0.71 / 0.92);
+//   3. the gather rows of km_warp_fwd_lean_kernel: for a half whose box still does not fit, and - before the squares are tried - for a region
+//      whose output rows stay nearly horizontal in the source (its wide box was too large because the map minifies: gathers are fine there).
+struct KmbWide   { static constexpr int TW = 64, TH = 32, PITCH = 80, ROWS = 40; };
+struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50; };
+#define KMB_LDS_FLOATS(NC) ((KmbWide::ROWS * KmbWide::PITCH > KmbSquare::ROWS * KmbSquare::PITCH ? KmbWide::ROWS * KmbWide::PITCH : KmbSquare::ROWS * KmbSquare::PITCH) * (NC))
+#ifndef KMB_WAVES_PER_EU
+#define KMB_WAVES_PER_EU 4   // what the LDS of a block allows (38 KB: 4 blocks of 4 waves per CU)
 #endif
-#ifndef KMB_SHAPE_16
-#define KMB_SHAPE_16 KmbSquare
+#ifndef KMB_TRY_WIDE
+#define KMB_TRY_WIDE 1       // 0: squares only (A/B)
+#endif
+#ifndef KMB_TILT_ROWS
+#define KMB_TILT_ROWS 4      // a region whose output rows span at most this many source rows takes the gather rows when its wide box does not fit
 #endif
 
 // the rows of a thread by gathers, one row at a time (plain IEEE divisions: any operands; every tap predicated): what a wave with a
@@ -765,52 +771,39 @@ __device__ __forceinline__ void kmb_gather_rows(const KmWarpArgs<T>& a, const fl
     }
 }
 
+// One output tile of shape SH with its upper left corner at (j0, i0), by the whole block.  Returns false - block-uniform, nothing written,
+// one barrier passed - when the tile's box does not fit SH's capacity.  The caller has a barrier between two calls (s_rv, s_info, s_src).
+// fast_out: the division operands of every row of the tile are in the safe range (what a gather fallback of the caller wants to know).
 template <typename T, int CM, int NC, int ALIGN, bool STREAM, typename SH>
-__global__ __launch_bounds__(256, SH::WAVES) void km_warp_fwd_box_kernel(const KmWarpArgs<T> a) {
+__device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const float (&m)[9], uint32_t b, int j0, int i0, const KmfBox& bx, const float4* s_rv, float* s_src);
+
+template <typename T, int CM, int NC, int ALIGN, bool STREAM, typename SH>
+__device__ __forceinline__ bool kmb_tile(const KmWarpArgs<T>& a, const float (&m)[9], uint32_t b, int j0, int i0, float4* s_rv, int* s_info, float* s_src,
+                                         bool& fast_out) {
+    kmf_tile_setup<CM, ALIGN, 0, SH::TW, SH::TH, SH::PITCH, SH::ROWS>(a.g, m, j0, i0, s_rv, s_info, false);
+    __syncthreads();
+    const KmfBox bx = kmf_read_box(s_info);
+    fast_out = bx.fast;
+    if (!bx.staged) return false;  // block-uniform
+    kmb_tile_body<T, CM, NC, ALIGN, STREAM, SH>(a, m, b, j0, i0, bx, s_rv, s_src);
+    return true;
+}
+
+// the tile once its box is known to fit (bx.staged): fill, positions, sample.  One barrier inside.
+template <typename T, int CM, int NC, int ALIGN, bool STREAM, typename SH>
+__device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const float (&m)[9], uint32_t b, int j0, int i0, const KmfBox& bx, const float4* s_rv, float* s_src) {
     constexpr int TW = SH::TW, TH = SH::TH, PITCH = SH::PITCH, ROWS = SH::ROWS;
     constexpr int RSLOTS = 256 / TW;       // threads per output column
     constexpr int RPT = TH / RSLOTS;       // output rows per thread (consecutive)
     constexpr int NCHK = PITCH / 4;        // 16-byte chunks per staged row of one channel
     constexpr int RCPP = 256 / NCHK;       // (row, channel) pairs filled per pass of the block
     static_assert(TW == 64 || TW == 32, "lane = output column");
-    static_assert(RPT % KM_ROWS == 0, "the gather rows walk KM_ROWS rows at a time");
     static_assert(TH <= 64 && PITCH % 4 == 0, "one wave fills the row table; whole chunks");
     const KmWarpGeom<float>& g = a.g;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
-    const uint32_t tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const uint32_t ty = bid % a.tiles_y;
-    const uint32_t b = bid / a.tiles_y;
     const int tid = threadIdx.x;
-    const int j = (int)tx * TW + (tid % TW);
+    const int j = j0 + (tid % TW);
     const int li_base = (tid / TW) * RPT;             // this thread's rows: li_base + r
-    const int i_base = (int)ty * TH + li_base;
-    __shared__ float4 s_rv[TH];
-    __shared__ int s_info[8];
-    __shared__ __attribute__((aligned(16))) float s_src[ROWS * NC * PITCH];  // [row][channel][x]
-
-    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
-        km_fwd_copy_rows<T>(a, b, j, i_base, 1, RPT);
-        return;
-    }
-    float m[9];
-    {
-        const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[k])));
-    }
-    kmf_tile_setup<CM, ALIGN, 0, TW, TH, PITCH, ROWS>(g, m, (int)tx * TW, (int)ty * TH, s_rv, s_info, false);
-    __syncthreads();
-    const KmfBox bx = kmf_read_box(s_info);
-    if (!bx.staged) {  // block-uniform: the gather rows of km_warp_fwd_lean_kernel
-        if (j >= g.w) return;
-#pragma unroll
-        for (int q = 0; q < RPT / KM_ROWS; ++q) {
-            if (bx.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, 1, STREAM>(a, m, s_rv, b, j, li_base + q * KM_ROWS, i_base + q * KM_ROWS);
-            else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, 1, STREAM>(a, m, s_rv, b, j, li_base + q * KM_ROWS, i_base + q * KM_ROWS);
-        }
-        return;
-    }
+    const int i_base = i0 + li_base;
     const int W = g.W, H = g.H;
     const size_t src_plane = (size_t)H * W, dst_plane = (size_t)g.h * g.w;
     const T* __restrict__ src_b = a.src + (size_t)b * NC * src_plane;
@@ -823,21 +816,23 @@ __global__ __launch_bounds__(256, SH::WAVES) void km_warp_fwd_box_kernel(const K
     const bool filler = (rq < RCPP) && (ck < bx.nch);
     const bool col_in = (xg >= 0) && (xg + 3 < W);  // W % 4 == 0 and xs % 4 == 0: a chunk is inside or outside as a whole
     const int nrc = bx.nrows * NC;
+    // (UNCONDITIONAL loads - a chunk outside the image or beyond the box reads the first chunk of the image and is replaced by zeros on its
+    // way to LDS: with `v = 0; if (inside) load` the compiler keeps the whole array as one register tuple and copies - or spills - all of
+    // it at every conditional definition)
     float v[NPASS][4];
+    uint32_t inmask = 0u;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int rc = ps * RCPP + rq, r = rc / NC, c = rc - r * NC, y = bx.ys + r;
         const bool inb = filler && col_in && (rc < nrc) && (y >= 0) && (y < H);
-        v[ps][0] = 0.f; v[ps][1] = 0.f; v[ps][2] = 0.f; v[ps][3] = 0.f;
-        if (ps * RCPP < nrc) {  // block-uniform
-            if (inb) km_ld4(km_at(src_b + c * src_plane, (uint32_t)y * (uint32_t)W + (uint32_t)xg), v[ps]);
-        }
+        inmask |= inb ? (1u << ps) : 0u;
+        km_ld4(km_at(src_b + (inb ? c : 0) * src_plane, inb ? (uint32_t)y * (uint32_t)W + (uint32_t)xg : 0u), v[ps]);
     }
 
     // ---- this thread's positions, while the requests fly ----
     const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
     const KmlHalf cu = kml_col_half<CM>(m, km_base_x<float, CM>(g, j));
-    KmlTaps t[RPT];
+    float xs[RPT], ys[RPT];  // (positions only: the footprints are formed again at the sampling - 6 registers per row would not fit beside the fill)
     bool inbox = true;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -847,9 +842,12 @@ __global__ __launch_bounds__(256, SH::WAVES) void km_warp_fwd_box_kernel(const K
         KmlPos p;
         if (bx.fast) kml_position<CM, true>(m, cu, rv, p);
         else kml_position<CM, false>(m, cu, rv, p);
-        kml_taps(kml_unnormalize<ALIGN>(p.gx, Wm1, hW), kml_unnormalize<ALIGN>(p.gy, Hm1, hH), t[r]);
+        xs[r] = kml_unnormalize<ALIGN>(p.gx, Wm1, hW);
+        ys[r] = kml_unnormalize<ALIGN>(p.gy, Hm1, hH);
+        KmlTaps t;
+        kml_taps(xs[r], ys[r], t);
         // (rows of the tile below the image bottom and columns right of it are not stored: no constraint)
-        inbox = inbox & (kmf_in_box(t[r], bx) | (i_base + r >= g.h) | (j >= g.w));
+        inbox = inbox & (kmf_in_box(t, bx) | (i_base + r >= g.h) | (j >= g.w));
     }
 
     // ---- requests -> LDS ----
@@ -859,34 +857,107 @@ __global__ __launch_bounds__(256, SH::WAVES) void km_warp_fwd_box_kernel(const K
         if (filler && rc < nrc) {
             float* q = s_src + rc * PITCH + 4 * ck;
             KM_CHECK_ALIGNED(q, 16);
-            *reinterpret_cast<float4*>(q) = make_float4(v[ps][0], v[ps][1], v[ps][2], v[ps][3]);
+            const bool inb = (inmask >> ps) & 1u;
+            *reinterpret_cast<float4*>(q) = make_float4(inb ? v[ps][0] : 0.f, inb ? v[ps][1] : 0.f, inb ? v[ps][2] : 0.f, inb ? v[ps][3] : 0.f);
         }
     }
     __syncthreads();
-    if (j >= g.w) return;
-    if (!__all(inbox)) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
-        kmb_gather_rows<T, CM, NC, ALIGN, RPT>(a, m, s_rv, b, j, li_base, i_base);
+    if (j < g.w) {
+        if (!__all(inbox)) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
+            kmb_gather_rows<T, CM, NC, ALIGN, RPT>(a, m, s_rv, b, j, li_base, i_base);
+        } else {
+            // ---- sample ----
+            T* __restrict__ dp[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dp[c] = dst_b + c * dst_plane;
+            const uint32_t out0 = (uint32_t)i_base * (uint32_t)g.w + (uint32_t)j;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (i_base + r >= g.h) break;  // (the tile hangs over the bottom edge; the rows that follow do too)
+                KmlTaps t;
+                kml_taps(xs[r], ys[r], t);
+                const int xi = KM_F2I(t.xf) - bx.xs, yi = KM_F2I(t.yf) - bx.ys;
+                const float* q0 = s_src + __mul24(yi, NC * PITCH) + xi;
+                const float* q1 = q0 + NC * PITCH;
+                const float w00 = t.wx1 * t.wy1, w01 = t.wx0 * t.wy1, w10 = t.wx1 * t.wy0, w11 = t.wx0 * t.wy0;
+                const uint32_t oo = out0 + (uint32_t)r * (uint32_t)g.w;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float v00 = q0[c * PITCH], v01 = q0[c * PITCH + 1], v10 = q1[c * PITCH], v11 = q1[c * PITCH + 1];
+                    const float acc = km_fma(v11, w11, km_fma(v10, w10, km_fma(v01, w01, km_fma(v00, w00, 0.0f))));
+                    km_st_c<STREAM>(km_at_mut(dp[c], oo), acc);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int CM, int NC, int ALIGN, bool STREAM>
+__global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(const KmWarpArgs<T> a) {
+    static_assert(KmbWide::TH == KmbSquare::TH && KmbWide::TW == 2 * KmbSquare::TW, "a wide tile is two square ones side by side");
+    static_assert(KmbSquare::TH / (256 / KmbSquare::TW) == KM_ROWS, "the gather rows walk KM_ROWS rows of a square half per thread");
+    const KmWarpGeom<float>& g = a.g;
+    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
+    const uint32_t tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const uint32_t ty = bid % a.tiles_y;
+    const uint32_t b = bid / a.tiles_y;
+    const int tid = threadIdx.x;
+    const int J0 = (int)tx * KmbWide::TW, I0 = (int)ty * KmbWide::TH;
+    __shared__ float4 s_rv[KmbWide::TH];
+    __shared__ int s_info[8];
+    __shared__ __attribute__((aligned(16))) float s_src[KMB_LDS_FLOATS(NC)];  // [row][channel][x]
+
+    if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
+        km_fwd_copy_rows<T>(a, b, J0 + (tid % KmbWide::TW), I0 + (tid / KmbWide::TW) * (KmbWide::TH / 4), 1, KmbWide::TH / 4);
         return;
     }
-
-    // ---- sample ----
-    T* __restrict__ dp[NC];
+    float m[9];
+    {
+        // (block-uniform, into scalar registers HERE: left in flight, the wait for them lands behind the fill's requests - which sit
+        // under lane predicates the compiler cannot count - and becomes a wait for the whole fill in front of the positions)
+        const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) dp[c] = dst_b + c * dst_plane;
-    const uint32_t out0 = (uint32_t)i_base * (uint32_t)g.w + (uint32_t)j;
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        if (i_base + r >= g.h) break;  // (the tile hangs over the bottom edge; the rows that follow do too)
-        const int xi = KM_F2I(t[r].xf) - bx.xs, yi = KM_F2I(t[r].yf) - bx.ys;
-        const float* q0 = s_src + __mul24(yi, NC * PITCH) + xi;
-        const float* q1 = q0 + NC * PITCH;
-        const float w00 = t[r].wx1 * t[r].wy1, w01 = t[r].wx0 * t[r].wy1, w10 = t[r].wx1 * t[r].wy0, w11 = t[r].wx0 * t[r].wy0;
-        const uint32_t oo = out0 + (uint32_t)r * (uint32_t)g.w;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float v00 = q0[c * PITCH], v01 = q0[c * PITCH + 1], v10 = q1[c * PITCH], v11 = q1[c * PITCH + 1];
-            const float acc = km_fma(v11, w11, km_fma(v10, w10, km_fma(v01, w01, km_fma(v00, w00, 0.0f))));
-            km_st_c<STREAM>(km_at_mut(dp[c], oo), acc);
+        for (int k = 0; k < 9; ++k) m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[k])));
+    }
+    // ---- 1. the region as one wide tile ----
+    kmf_tile_setup<CM, ALIGN, 0, KmbWide::TW, KmbWide::TH, KmbWide::PITCH, KmbWide::ROWS>(g, m, J0, I0, s_rv, s_info, false);
+    __syncthreads();
+    const KmfBox bxw = kmf_read_box(s_info);
+    const int tilt = __builtin_amdgcn_readfirstlane(s_info[6]);  // source rows spanned by one output row of the region
+    if (KMB_TRY_WIDE && bxw.staged) {
+        kmb_tile_body<T, CM, NC, ALIGN, STREAM, KmbWide>(a, m, b, J0, I0, bxw, s_rv, s_src);
+        return;
+    }
+    // ---- 3 before 2. output rows that stay (nearly) horizontal in the source - the box is too large because the map MINIFIES, not because
+    //      it rotates: the gather rows do not suffer there (scale 0.8 / 0.5: 0.37 / 0.48 ms against 0.43 / 0.61 through the squares), in
+    //      the very shape of km_warp_fwd_lean_kernel (32 x 2 patches per wave instruction, two groups of 64 x 16) ----
+    if (tilt <= KMB_TILT_ROWS) {
+        constexpr int PW = KM_PATCH_W, PH = 64 / PW, WA = 64 / PW;
+        const int lane = tid & 63, wave = tid >> 6;
+        const int j = J0 + (wave % WA) * PW + (lane % PW);
+        const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;
+        if (j < g.w) {
+#pragma unroll 1
+            for (int gr = 0; gr < KmbWide::TH / KM_TILE_H; ++gr) {
+                if (I0 + gr * KM_TILE_H >= g.h) break;
+                if (bxw.fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, PH, STREAM>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, I0 + li_base + gr * KM_TILE_H);
+                else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, PH, STREAM>(a, m, s_rv, b, j, li_base + gr * KM_TILE_H, I0 + li_base + gr * KM_TILE_H);
+            }
+        }
+        return;
+    }
+    // ---- 2. the two square halves, one after the other ----
+    bool fast = false;
+    for (int half = 0; half < 2; ++half) {
+        const int j0 = J0 + half * KmbSquare::TW;
+        if (j0 >= g.w) break;  // block-uniform
+        __syncthreads();  // the previous attempt's readers are done with s_info, s_rv and s_src
+        if (kmb_tile<T, CM, NC, ALIGN, STREAM, KmbSquare>(a, m, b, j0, I0, s_rv, s_info, s_src, fast)) continue;
+        const int j = j0 + (tid % KmbSquare::TW), li_base = (tid / KmbSquare::TW) * KM_ROWS;
+        if (j < g.w) {
+            if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, 1, STREAM>(a, m, s_rv, b, j, li_base, I0 + li_base);
+            else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, 1, STREAM>(a, m, s_rv, b, j, li_base, I0 + li_base);
         }
     }
 }
@@ -913,38 +984,31 @@ static void km_warp_fwd_lean_launch_nc(const KmWarpArgs<T>& a0, hipStream_t s) {
     else
         hipLaunchKernelGGL((km_warp_fwd_lean_kernel<T, CM, NC, 0>), dim3(a.nblocks), dim3(256), 0, s, a);
 }
-template <typename T, int CM, int NC, typename SH>
-static void km_warp_fwd_box_launch_sh(const KmWarpArgs<T>& a, hipStream_t s) {
+template <typename T, int CM, int NC>
+static void km_warp_fwd_box_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
     KmWarpArgs<T> b = a;
-    b.tiles_x = (uint32_t)((a.g.w + SH::TW - 1) / SH::TW);
-    b.tiles_y = (uint32_t)((a.g.h + SH::TH - 1) / SH::TH);
+    b.tiles_x = (uint32_t)((a.g.w + KmbWide::TW - 1) / KmbWide::TW);
+    b.tiles_y = (uint32_t)((a.g.h + KmbWide::TH - 1) / KmbWide::TH);
     b.nblocks = b.tiles_x * b.tiles_y * (uint32_t)a.g.B;
     b.reverse = km_traversal_next(s);
     b.stream_out = km_stream_stores((uint64_t)a.g.B * a.g.C * a.g.h * a.g.w * sizeof(T));
     if (a.g.align) {
-        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, true, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, false, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
+        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, true>), dim3(b.nblocks), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, false>), dim3(b.nblocks), dim3(256), 0, s, b);
     } else {
-        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, true, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, false, SH>), dim3(b.nblocks), dim3(256), 0, s, b);
+        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, true>), dim3(b.nblocks), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, false>), dim3(b.nblocks), dim3(256), 0, s, b);
     }
-}
-// the shape by storage type: a staged element of a 16-bit image costs half the requests, so the square, rotation-proof tile pays there
-template <typename T, int CM, int NC>
-static void km_warp_fwd_box_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) km_warp_fwd_box_launch_sh<T, CM, NC, KMB_SHAPE_16>(a, s);
-    else km_warp_fwd_box_launch_sh<T, CM, NC, KMB_SHAPE_F32>(a, s);
 }
 template <typename T>
 static uint64_t km_warp_fwd_box_blocks(const KmWarpArgs<T>& a) {
-    const int tw = sizeof(T) == 2 ? KMB_SHAPE_16::TW : KMB_SHAPE_F32::TW, th = sizeof(T) == 2 ? KMB_SHAPE_16::TH : KMB_SHAPE_F32::TH;
-    return (uint64_t)((a.g.w + tw - 1) / tw) * (uint64_t)((a.g.h + th - 1) / th) * (uint64_t)a.g.B;
+    return (uint64_t)((a.g.w + KmbWide::TW - 1) / KmbWide::TW) * (uint64_t)((a.g.h + KmbWide::TH - 1) / KmbWide::TH) * (uint64_t)a.g.B;
 }
 #ifndef KM_FWD_BOX_DEFAULT
 #define KM_FWD_BOX_DEFAULT 1      // fp32 storage: the box forward is what the hot configuration runs (KM_WARP_FWD_ALGO=rows: the gather kernel)
 #endif
 #ifndef KM_FWD_BOX_DEFAULT_16
-#define KM_FWD_BOX_DEFAULT_16 0   // 16-bit storage
+#define KM_FWD_BOX_DEFAULT_16 1   // 16-bit storage (config 3, 224^2 bf16 under +-15 degrees: 97 -> 73 us through the square tiles)
 #endif
 template <typename T, int CM>
 static void km_warp_fwd_lean_launch(const KmWarpArgs<T>& a, hipStream_t s) {

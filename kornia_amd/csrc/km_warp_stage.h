@@ -87,6 +87,10 @@ __device__ __forceinline__ void kmf_tile_setup(const KmWarpGeom<float>& g, const
             s_info[4] = (wcols + 3) >> 2;
             s_info[5] = nrows;
         }
+        // tilt: source rows spanned by the tile's first OUTPUT row (lanes 0 and 1 hold its two ends) - what a gather kernel whose wave
+        // instructions cover output rows pays for under rotation
+        const float ytilt = km_fabs(__shfl_down(y, 1, 64) - y);  // (meaningful in lane 0)
+        if (lane == 0) s_info[6] = (ytilt == ytilt && ytilt < 1.0e6f) ? (int)ytilt : 1000000;
     }
 }
 
