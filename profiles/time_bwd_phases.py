@@ -26,13 +26,15 @@ def f():
                                  ws.data_ptr(), nbytes, stream), "bwd")
 t = bench.event_time_ms(f, 10)
 torch.cuda.synchronize()
-NW, PH = 16, 8
-workers = 256
+NW, PH = 16, 8   # (the table always has 16 wave slots per worker)
+workers = int(os.environ.get("LAB_WORKERS", 256))   # persistent workgroups of the launch (256 CUs x KMO_WG_PER_CU)
+waves = int(os.environ.get("LAB_WAVES", 16))         # waves per workgroup (KMO_NT / 64)
+TH = int(os.environ.get("LAB_TH", 64))               # KMO_TH
 out = (ctypes.c_ulonglong * (512 * NW * PH))()
 raw.km_debug_fused_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = raw.km_debug_fused_profile(out, 512 * NW * PH)
-a = np.frombuffer(out, dtype=np.uint64).reshape(512, NW, PH)[:workers].astype(np.float64)
-tiles_per_worker = B * 64 / workers
+a = np.frombuffer(out, dtype=np.uint64).reshape(512, NW, PH)[:workers, :waves].astype(np.float64)
+tiles_per_worker = B * (S // 64) * ((S + TH - 1) // TH) / workers
 names = ["wait for requests", "stage (src->LDS, max, tables)", "flush of previous tile", "barrier B1 (+ box records)", "describe next, gm commit, scale",
          "scatter (+ next requests)", "barrier B2", "loop tail (image end sums)"]
 tot = a.sum(axis=2)
