@@ -1016,7 +1016,10 @@ static void km_warp_fwd_lean_launch(const KmWarpArgs<T>& a, hipStream_t s) {
         {
             const uint64_t nbb = km_warp_fwd_box_blocks(a);
             const int algo = km_config().warp_fwd_algo;  // 0 default, 3 "box", 4 "rows"
-            const bool want_box = algo == 3 || ((sizeof(T) == 2 ? KM_FWD_BOX_DEFAULT_16 : KM_FWD_BOX_DEFAULT) && algo == 0);
+            // (an output with fewer pixels than the source is, as a rule, a map that MINIFIES - warp to a smaller dsize: the boxes would not fit
+            // and the kernel would end in its gather rows after paying for the attempt, 7 - 10 % behind the gather kernel; that one is launched then)
+            const bool shrinks = (uint64_t)a.g.H * (uint64_t)a.g.W * 10u > (uint64_t)a.g.h * (uint64_t)a.g.w * 13u;
+            const bool want_box = algo == 3 || ((sizeof(T) == 2 ? KM_FWD_BOX_DEFAULT_16 : KM_FWD_BOX_DEFAULT) && algo == 0 && !shrinks);
             if (want_box && (a.g.C == 3 || a.g.C == 1) && (a.g.W & 3) == 0 && ((uintptr_t)a.src % (4 * sizeof(T))) == 0 && nbb < (1ull << 31)) {
                 if (a.g.C == 3) km_warp_fwd_box_launch_nc<T, CM, 3>(a, s);
                 else km_warp_fwd_box_launch_nc<T, CM, 1>(a, s);
