@@ -927,7 +927,11 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     if (ntiles == 0) return 0;
     a.ntiles = (uint32_t)ntiles;
     const int cus = km_device_cus();
+#ifdef KMO_WORKERS_OVERRIDE  // (variant libraries only: fewer persistent workgroups than CUs - what the clock does when part of the chip idles)
+    const uint32_t workers_max = KMO_WORKERS_OVERRIDE;
+#else
     const uint32_t workers_max = cus > 0 ? (uint32_t)cus * KMO_WG_PER_CU : 3u;  // (the host build of the kernels reports 0 CUs: a few workers, several tiles each)
+#endif
     // a run = a row of tiles of one image when that still gives every CU several runs; single tiles otherwise
     const uint64_t rows = (uint64_t)a.tiles_y * (uint64_t)B;
     a.run_len = (rows >= 4ull * workers_max) ? a.tiles_x : 1u;
