@@ -85,7 +85,7 @@ def test_emulator_schedules_expose_a_missing_barrier():
 @pytest.mark.parametrize("schedule", ["reverse", "random", "lanes"])
 def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
     """The kernels that communicate through LDS (tile-owner scatter, matrix gradient, fused loss, colour statistics, large
-    separable filter) give the same results when their waves / work-items resume in another order."""
+    separable filter, box forward) give the same results when their waves / work-items resume in another order."""
     import emu_lib
     import test_gpu_color
     import test_gpu_filters
@@ -99,6 +99,7 @@ def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
         reg.test_single_level_loss_vs_reference("l1", torch.nn.functional.l1_loss)
         test_gpu_color.test_all_orders_vs_restatement((3, 3, 37, 53))
         test_gpu_filters.test_large_separable_kernels(oracle, "reflect", (23, 23), (2, 3, 70, 90))
+        test_gpu_warp.test_box_forward_is_bit_identical(oracle, 1, torch.float32)  # fill -> barrier -> sample through LDS, three tile attempts per block
     finally:
         emu_lib.set_schedule("forward")
 
