@@ -862,8 +862,9 @@ __device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const floa
         }
     }
     __syncthreads();
+    const bool all_in = __all(inbox);  // (by every lane of the wave: columns right of the image count as inside)
     if (j < g.w) {
-        if (!__all(inbox)) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
+        if (!all_in) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
             kmb_gather_rows<T, CM, NC, ALIGN, RPT>(a, m, s_rv, b, j, li_base, i_base);
         } else {
             // ---- sample ----
@@ -937,7 +938,8 @@ __global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(
         const int lane = tid & 63, wave = tid >> 6;
         const int j = J0 + (wave % WA) * PW + (lane % PW);
         const int li_base = (wave / WA) * (PH * KM_ROWS) + lane / PW;
-        if (j < g.w) {
+        if (j >= g.w) return;  // (the kernel ends in this branch: lanes right of the image leave, as in km_warp_fwd_lean_kernel)
+        {
 #pragma unroll 1
             for (int gr = 0; gr < KmbWide::TH / KM_TILE_H; ++gr) {
                 if (I0 + gr * KM_TILE_H >= g.h) break;
@@ -954,11 +956,11 @@ __global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(
         if (j0 >= g.w) break;  // block-uniform
         __syncthreads();  // the previous attempt's readers are done with s_info, s_rv and s_src
         if (kmb_tile<T, CM, NC, ALIGN, STREAM, KmbSquare>(a, m, b, j0, I0, s_rv, s_info, s_src, fast)) continue;
-        const int j = j0 + (tid % KmbSquare::TW), li_base = (tid / KmbSquare::TW) * KM_ROWS;
-        if (j < g.w) {
-            if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, 1, STREAM>(a, m, s_rv, b, j, li_base, I0 + li_base);
-            else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, 1, STREAM>(a, m, s_rv, b, j, li_base, I0 + li_base);
-        }
+        // (every lane takes part - the rows exchange registers between neighbouring lanes and vote as a wave, and this block still has a
+        // barrier ahead: a lane right of the image computes the image's last column again and stores the same values to the same places)
+        const int j = min(j0 + (tid % KmbSquare::TW), g.w - 1), li_base = (tid / KmbSquare::TW) * KM_ROWS;
+        if (fast) km_warp_fwd_lean_rows<T, CM, NC, ALIGN, true, 1, STREAM>(a, m, s_rv, b, j, li_base, I0 + li_base);
+        else km_warp_fwd_lean_rows<T, CM, NC, ALIGN, false, 1, STREAM>(a, m, s_rv, b, j, li_base, I0 + li_base);
     }
 }
 

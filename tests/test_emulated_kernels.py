@@ -99,7 +99,8 @@ def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
         reg.test_single_level_loss_vs_reference("l1", torch.nn.functional.l1_loss)
         test_gpu_color.test_all_orders_vs_restatement((3, 3, 37, 53))
         test_gpu_filters.test_large_separable_kernels(oracle, "reflect", (23, 23), (2, 3, 70, 90))
-        test_gpu_warp.test_box_forward_is_bit_identical(oracle, 1, torch.float32)  # fill -> barrier -> sample through LDS, three tile attempts per block
+        if schedule != "lanes":  # (its gather rows exchange registers between lanes - wave_shl / wave_shr - which only means something in wave order)
+            test_gpu_warp.test_box_forward_is_bit_identical(oracle, 1, torch.float32)  # fill -> barrier -> sample through LDS, three tile attempts per block
     finally:
         emu_lib.set_schedule("forward")
 
