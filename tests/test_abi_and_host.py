@@ -189,3 +189,49 @@ def test_product_never_references_the_checkers():
                     offenders.append(os.path.join(base, f))
     assert not offenders, offenders
     assert _native.library_path().endswith(os.path.join("kornia_amd", "lib", "libkornia_amd.so")) or os.environ.get("KORNIA_AMD_LIB")
+
+
+def test_streaming_store_helper_keeps_the_non_temporal_mark(tmp_path):
+    """km_st_c<STREAM> (csrc/km_common.h) must compile to `global_store_dword ... nt` for STREAM = true and to a plain store for false, in the
+    shape the forward uses it (restrict plane pointers + 32-bit offsets, rows and channels unrolled).  Round 2's bool-argument form compiled to
+    plain stores in EVERY instantiation - its if / else was merged before the constant arrived and the merge dropped the mark - and nobody
+    noticed for a round: this reads the ISA (hipcc cross-compiles without a GPU)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    csrc = os.path.join(ROOT, "kornia_amd", "csrc")
+    src = tmp_path / "nt_probe.hip"
+    src.write_text('''
+#include "km_common.h"
+template <bool STREAM>
+__global__ void probe(float* p, const float* __restrict__ q, uint32_t w, size_t plane) {
+    float* __restrict__ dp[3];
+    for (int c = 0; c < 3; ++c) dp[c] = p + c * plane;
+    const uint32_t off = blockIdx.x * 256 + threadIdx.x;
+    const float v = q[off];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) km_st_c<STREAM>(km_at_mut(dp[c], off + r * w), v + r + c);
+}
+template __global__ void probe<true>(float*, const float*, uint32_t, size_t);
+template __global__ void probe<false>(float*, const float*, uint32_t, size_t);
+''')
+    out = tmp_path / "nt_probe.s"
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", f"-I{csrc}", str(src), "-o", str(out)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.read_text().splitlines():
+        if line.startswith("_Z5probeILb"):
+            cur = "stream" if "ILb1E" in line else "plain"
+            kernels[cur] = []
+        elif cur and "global_store_dword" in line:
+            kernels[cur].append(line.strip())
+        elif ".end_amdhsa_kernel" in line:
+            cur = None
+    assert len(kernels["stream"]) == 12 and all(s.endswith(" nt") for s in kernels["stream"]), kernels["stream"]
+    assert len(kernels["plain"]) == 12 and not any(" nt" in s for s in kernels["plain"]), kernels["plain"]
