@@ -98,3 +98,58 @@ def test_random_filters_against_oracle(oracle, seed):
     assert torch.equal(K.filter2d(x.cuda(), k2.cuda(), border).cpu(), oracle.filter2d(x, k2, border))
     mode, order = ("sobel", "diff")[ri(0, 1)], ri(1, 2)
     assert torch.equal(K.spatial_gradient(x.cuda(), mode, order).cpu(), oracle.spatial_gradient(x, mode, order, True))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_box_forward_against_the_gather_kernel(seed):
+    """The box forward (one wide tile / gather rows under minification / two square halves / gather rows) against the gather kernel, bit for bit,
+    on inputs nobody hand-picked: widths that are multiples of 4 from 4 to 132, heights from 1, output sizes around the tile sizes, fp32 / bf16 / f16
+    storage, near-identity, rotated-and-scaled, projective and wild matrices (NaN compares equal to NaN), shared matrices, the three entry points."""
+    import random
+
+    import kornia_amd as K
+    from kornia_amd import _native as N
+
+    lib = N.lib()
+    rnd = random.Random(100 + seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    for _ in range(10):
+        B, C = rnd.choice([1, 2, 3]), rnd.choice([1, 3])
+        H, W = rnd.choice([1, 2, 3, 5, 8, 17, 33, 64, 65, 100]), 4 * rnd.choice([1, 2, 3, 5, 8, 16, 17, 25, 33])
+        h, w = rnd.choice([1, 2, 7, 16, 31, 32, 33, 64, 70, 97]), rnd.choice([1, 3, 4, 31, 32, 33, 63, 64, 65, 96, 130])
+        dtype = rnd.choice([torch.float32, torch.float32, torch.bfloat16, torch.float16])
+        x = torch.rand(B, C, H, W, generator=g).to(dtype)
+        kind = rnd.choice(["near", "rot", "proj", "wild", "shared"])
+        M = torch.eye(3).repeat(B, 1, 1)
+        if kind in ("near", "shared"):
+            M[:, :2, :] += 0.05 * torch.randn(B, 2, 3, generator=g)
+            M[:, :2, 2] += 3 * torch.randn(B, 2, generator=g)
+        elif kind == "rot":
+            th, s = torch.rand(B, generator=g) * 6.28, 0.3 + 2.5 * torch.rand(B, generator=g)
+            M[:, 0, 0], M[:, 0, 1], M[:, 1, 0], M[:, 1, 1] = s * th.cos(), s * th.sin(), -s * th.sin(), s * th.cos()
+            M[:, :2, 2] = torch.randn(B, 2, generator=g) * max(H, W) / 3
+        elif kind == "proj":
+            M[:, :2, :] += 0.1 * torch.randn(B, 2, 3, generator=g)
+            M[:, 2, :2] = 0.01 * torch.randn(B, 2, generator=g)
+        else:
+            M = torch.randn(B, 3, 3, generator=g) * torch.tensor([1.0, 1.0, 30.0])
+            M[:, 2] *= 0.02
+            M[:, 2, 2] = 1 + 0.5 * torch.randn(B, generator=g)
+        align = rnd.choice([True, False])
+        fn = rnd.choice(["persp", "affine", "homog"])
+        if kind == "shared":
+            fn, M = "affine", M[:1]  # (only warp_affine takes a shared matrix, like the reference)
+        outs = []
+        for algo in (3, 4):
+            prev = lib.km_config_set(b"warp_fwd_algo", algo)
+            try:
+                if fn == "persp":
+                    o = K.warp_perspective(x.cuda(), M.cuda(), (h, w), "bilinear", "zeros", align)
+                elif fn == "affine":
+                    o = K.warp_affine(x.cuda(), M[:, :2].contiguous().cuda(), (h, w), "bilinear", "zeros", align)
+                else:
+                    o = K.homography_warp(x.cuda(), M.cuda(), (h, w), "bilinear", "zeros", align)
+            finally:
+                lib.km_config_set(b"warp_fwd_algo", prev)
+            outs.append(torch.nan_to_num(o.float(), nan=12345.0, posinf=23456.0, neginf=-23456.0))
+        assert torch.equal(outs[0], outs[1]), (kind, fn, (B, C, H, W), (h, w), dtype, align, (outs[0] - outs[1]).abs().max().item())
