@@ -51,7 +51,7 @@ struct KmVec4<km_f16> {
 
 __device__ __forceinline__ float km_round_store(float v, const float*) { return v; }
 __device__ __forceinline__ float km_round_store(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
-__device__ __forceinline__ float km_round_store(float v, const km_f16*) { return (float)(_Float16)v; }
+__device__ __forceinline__ float km_round_store(float v, const km_f16*) { KM_OPAQUE(v); return (float)(_Float16)v; }  // (never fused into the fma before it: km_common.h)
 
 
 template <typename T>

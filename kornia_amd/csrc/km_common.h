@@ -128,6 +128,11 @@ __device__ __forceinline__ uint32_t km_f32x2_to_bf16x2_bits(float lo, float hi) 
     return (uint32_t)km_f32_to_bf16_bits_sw(lo) | ((uint32_t)km_f32_to_bf16_bits_sw(hi) << 16);
 }
 #endif
+// An opaque copy of a per-lane value: what is computed from it stays where it is written (not hoisted out of a loop, not merged with
+// the same computation elsewhere).  No code is emitted (the host build of the kernels defines it away).
+#ifndef KM_OPAQUE
+#define KM_OPAQUE(v) asm volatile("" : "+v"(v))
+#endif
 // Outputs are written once and read by the NEXT kernel, after ~0.8 GB of other traffic at the hot sizes: streaming (non-temporal)
 // stores keep them from displacing the lines the running kernel still needs in L2.  Measured on MI355X, config 2, same box: step
 // 1.798 -> 1.744 ms (forward 0.384 -> 0.370, blur 0.332 -> 0.319, blur adjoint 0.332 -> 0.323, scatter 0.398 -> 0.391 ms).
@@ -165,7 +170,10 @@ __device__ __forceinline__ void km_st_c(float* p, float v) {
 }
 __device__ __forceinline__ void km_st(double* p, double v) { *p = v; }
 __device__ __forceinline__ void km_st(km_bf16* p, float v) { p->bits = km_f32_to_bf16_bits(v); }
-__device__ __forceinline__ void km_st(km_f16* p, float v) { *p = (km_f16)v; }
+// (the fp32 result is made opaque before it is converted: left visible, the compiler fuses the last fma of an accumulation chain with the
+// conversion into v_fma_mixlo_f16, which rounds the exact product-sum to f16 ONCE - a result that is not "the fp32 result rounded to the
+// storage type" at ties, and differed between kernels that got the fusion and kernels that did not: 1 f16 ulp at ~1e-5 of the pixels)
+__device__ __forceinline__ void km_st(km_f16* p, float v) { KM_OPAQUE(v); *p = (km_f16)v; }
 template <bool STREAM>
 __device__ __forceinline__ void km_st_c(double* p, double v) { *p = v; }
 template <bool STREAM>
@@ -177,7 +185,7 @@ __device__ __forceinline__ void km_st_c(km_f16* p, float v) { km_st(p, v); }
 __device__ __forceinline__ float km_round_as(float v, const float*) { return v; }
 __device__ __forceinline__ double km_round_as(double v, const double*) { return v; }
 __device__ __forceinline__ float km_round_as(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
-__device__ __forceinline__ float km_round_as(float v, const km_f16*) { return (float)(km_f16)v; }
+__device__ __forceinline__ float km_round_as(float v, const km_f16*) { KM_OPAQUE(v); return (float)(km_f16)v; }
 
 // two horizontally adjacent pixels with ONE load (8 bytes for fp32 / fp64 pairs, 4 bytes for 16-bit types).
 // The address is only element-aligned: gfx950 global loads handle that in hardware; the packed structs
@@ -275,11 +283,6 @@ __device__ __forceinline__ uint32_t km_xcd_remap(uint32_t bid, uint32_t nblocks,
 // bodies whose interleaving would raise the register count (the host build of the kernels defines it away).
 #ifndef KM_SCHED_FENCE
 #define KM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-// An opaque copy of a per-lane value: what is computed from it stays where it is written (not hoisted out of a loop, not merged with
-// the same computation elsewhere).  No code is emitted (the host build of the kernels defines it away).
-#ifndef KM_OPAQUE
-#define KM_OPAQUE(v) asm volatile("" : "+v"(v))
 #endif
 
 // Direction of the next launch of a streaming kernel on stream s (host side, km_runtime.hip).  The kernels of the hot step each stream

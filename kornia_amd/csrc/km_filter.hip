@@ -59,7 +59,7 @@ struct KmSepArgs {
 __device__ __forceinline__ float km_round_to(float v, const float*) { return v; }
 __device__ __forceinline__ double km_round_to(double v, const double*) { return v; }
 __device__ __forceinline__ float km_round_to(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
-__device__ __forceinline__ float km_round_to(float v, const km_f16*) { return (float)(km_f16)v; }
+__device__ __forceinline__ float km_round_to(float v, const km_f16*) { KM_OPAQUE(v); return (float)(km_f16)v; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void km_filter_sep_fwd_kernel(const KmSepArgs<T> a) {

@@ -30,7 +30,7 @@ struct KmSepBigArgs {
 
 __device__ __forceinline__ float kms_round_to(float v, const float*) { return v; }
 __device__ __forceinline__ float kms_round_to(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
-__device__ __forceinline__ float kms_round_to(float v, const km_f16*) { return (float)(km_f16)v; }
+__device__ __forceinline__ float kms_round_to(float v, const km_f16*) { KM_OPAQUE(v); return (float)(km_f16)v; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void km_filter_sep_big_fwd_kernel(const KmSepBigArgs<T> a) {

@@ -31,7 +31,7 @@
 __device__ __forceinline__ float kmp_round(float v, const float*) { return v; }
 __device__ __forceinline__ double kmp_round(double v, const double*) { return v; }
 __device__ __forceinline__ float kmp_round(float v, const km_bf16*) { return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16); }
-__device__ __forceinline__ float kmp_round(float v, const km_f16*) { return (float)(km_f16)v; }
+__device__ __forceinline__ float kmp_round(float v, const km_f16*) { KM_OPAQUE(v); return (float)(km_f16)v; }
 
 // ATen area_pixel_compute_scale / area_pixel_compute_source_index (bilinear: negative sources clamp to 0)
 template <typename R>

@@ -62,10 +62,12 @@ __device__ __forceinline__ void km_st4(km_bf16* p, const float (&o)[4]) {
     *reinterpret_cast<uint2*>(p) = v;
 #endif
 }
+// fp32 result -> f16, never fused with the arithmetic that produced it (km_common.h, km_st(km_f16*, float))
+__device__ __forceinline__ _Float16 km_f16_of(float v) { KM_OPAQUE(v); return (_Float16)v; }
 __device__ __forceinline__ void km_st4(km_f16* p, const float (&o)[4]) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    v.x = km_f16_of(o[0]); v.y = km_f16_of(o[1]); v.z = km_f16_of(o[2]); v.w = km_f16_of(o[3]);
     KM_CHECK_ALIGNED(p, 8);
 #ifdef KM_NT_ST
     __builtin_nontemporal_store(v, reinterpret_cast<h4*>(p));
@@ -91,7 +93,7 @@ __device__ __forceinline__ void km_st4_pol(km_f16* p, const float (&o)[4], bool 
     if (stream) { km_st4(p, o); return; }
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 v;
-    v.x = (_Float16)o[0]; v.y = (_Float16)o[1]; v.z = (_Float16)o[2]; v.w = (_Float16)o[3];
+    v.x = km_f16_of(o[0]); v.y = km_f16_of(o[1]); v.z = km_f16_of(o[2]); v.w = km_f16_of(o[3]);
     KM_CHECK_ALIGNED(p, 8);
     *reinterpret_cast<h4*>(p) = v;
 }
@@ -117,7 +119,7 @@ __device__ __forceinline__ void km_st2(km_bf16* p, float a, float b) {
 __device__ __forceinline__ void km_st2(km_f16* p, float a, float b) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     h2 v;
-    v.x = (_Float16)a; v.y = (_Float16)b;
+    v.x = km_f16_of(a); v.y = km_f16_of(b);
     KM_CHECK_ALIGNED(p, 4);
 #ifdef KM_NT_ST
     __builtin_nontemporal_store(v, reinterpret_cast<h2*>(p));
