@@ -245,7 +245,11 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
             if isinstance(bp, torch.Tensor) and bp.numel() == B:  # (inverse_inputs may call with a subset of the batch: no switch then)
                 apply = torch.atleast_1d(bp.to(input.device) > 0.5)
         mode = flags["resample"].name.lower()
-        if kind == "affine":
+        if kind == "rotation":
+            # RandomRotation.apply_transform (_2d/geometric/rotation.py:112-124): affine(input, transform[..., :2, :3], resample, "zeros",
+            # align_corners) = warp_affine to the input's own size (affwarp.py:136-193)
+            out = _warp(input, transform[:, :2, :].contiguous(), (height, width), COORD_AFFINE, 1, mode, "zeros", flags["align_corners"], None, apply)
+        elif kind == "affine":
             padding_mode = flags["padding_mode"].name.lower()
             fill_value = flags.get("fill_value")
             if padding_mode == "fill" and fill_value is None:
@@ -301,13 +305,18 @@ def patch() -> int:
     gb_mod.RandomGaussianBlur.apply_transform = _gaussian_blur_apply(original)
     _patched_methods.append((gb_mod.RandomGaussianBlur, "apply_transform", original))
     # the geometric leg of the same layer: the probability switch rides in the warp's own launch
+    # (RandomShear / RandomTranslate apply exactly like RandomAffine - _2d/geometric/shear.py:113-131, translate.py:102-120 -, RandomRotation
+    # through `affine` with zeros padding)
     for mod_name, cls_name, kind in (("kornia.augmentation._2d.geometric.affine", "RandomAffine", "affine"),
-                                     ("kornia.augmentation._2d.geometric.perspective", "RandomPerspective", "perspective")):
+                                     ("kornia.augmentation._2d.geometric.perspective", "RandomPerspective", "perspective"),
+                                     ("kornia.augmentation._2d.geometric.shear", "RandomShear", "affine"),
+                                     ("kornia.augmentation._2d.geometric.translate", "RandomTranslate", "affine"),
+                                     ("kornia.augmentation._2d.geometric.rotation", "RandomRotation", "rotation")):
         cls = getattr(importlib.import_module(mod_name), cls_name)
         original = cls.apply_transform
         cls.apply_transform = _geometric_apply(original, kind)
         _patched_methods.append((cls, "apply_transform", original))
-    return count + 6
+    return count + 9
 
 
 def unpatch() -> int:

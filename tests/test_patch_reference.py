@@ -237,3 +237,64 @@ def test_reference_own_tests_pass_on_the_native_path():
     passed = int(re.search(r"(\d+) passed", text).group(1))
     launches = int(re.search(r"kernel launches during the run: (\d+)", text).group(1))
     assert passed >= 820 and " failed" not in text and launches >= 2000, text[-1500:]
+
+
+def test_rotation_shear_translate_hooks_on_the_host_build():
+    """RandomRotation / RandomShear / RandomTranslate under patch(): their apply steps are RandomAffine's (warp_affine to the input's own size; the
+    rotation through `affine` with zeros padding: kornia/augmentation/_2d/geometric/rotation.py:112-124, shear.py:113-131, translate.py:102-120), so
+    they take the same hook - the per-sample probability switch inside the warp's launch, no select pass.  Each module runs once unpatched on the
+    CPU with p < 1, then its sampled parameters are replayed through the patched module on "device" tensors (the host build of the kernels)."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("host build of the kernels needs ROCm's clang++")
+    K = ref_shim.import_reference()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from mode import emulated_device
+
+    import kornia_amd.augmentation as native_aug
+    import kornia_amd.kornia_patch as P
+
+    A = K.augmentation
+    base_mod = sys.modules["kornia.augmentation.base"]
+    x = torch.rand(8, 3, 40, 56, generator=torch.Generator().manual_seed(6))
+    cases = []
+    torch.manual_seed(12)
+    for make in (lambda: A.RandomRotation(35.0, p=0.6), lambda: A.RandomShear((-12.0, 12.0, -6.0, 6.0), p=0.6), lambda: A.RandomTranslate((-0.15, 0.15), (-0.1, 0.1), p=0.6),
+                 lambda: A.RandomRotation(20.0, resample="nearest", align_corners=True, p=0.6)):
+        aug = make()
+        ref = aug(x)
+        params = aug._params
+        mask = torch.as_tensor(params["batch_prob"]) > 0.5
+        assert 0 < int(mask.sum()) < 8, "the draw must mix transformed and untouched samples"
+        cases.append((make, params, ref, mask))
+    selects = []
+    real_select = native_aug.select_samples
+    with emulated_device():
+        n = P.patch()
+        try:
+            blend_fn = base_mod._AugmentationBase.__dict__["_blend_by_prob"].__func__
+            cell = [c for c in blend_fn.__closure__ if c.cell_contents is real_select]
+            assert len(cell) == 1
+            cell[0].cell_contents = lambda t_, o_, a_: (selects.append(tuple(t_.shape)), real_select(t_, o_, a_))[1]
+            for make, params, ref, mask in cases:
+                aug = make()
+                cls = type(aug)
+                orig = cls.apply_transform.__wrapped__
+                fell = [0]
+
+                def fell_through(self, *a, _o=orig, **k):
+                    fell[0] += 1
+                    return _o(self, *a, **k)
+
+                cells = [c for c in cls.apply_transform.__closure__ if c.cell_contents is orig]
+                assert len(cells) == 1
+                cells[0].cell_contents = fell_through
+                try:
+                    out = aug(x.cuda(), params={k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in params.items()})
+                finally:
+                    cells[0].cell_contents = orig
+                assert fell[0] == 0, f"{cls.__name__}: the hook fell through to the reference's own method"
+                assert torch.allclose(out, ref, atol=2e-5, rtol=0), (cls.__name__, (out - ref).abs().max())
+                assert torch.equal(out[~mask], x[~mask]), cls.__name__   # untouched samples bit for bit
+        finally:
+            assert P.unpatch() == n
+    assert selects == [], selects   # the switch rode inside every warp launch
