@@ -84,16 +84,19 @@ def flagship_homographies(B, H, W, gen):
 
 
 def device_clocks(index):
-    """Shader clock / power / temperature of the device from sysfs, read OUTSIDE the timed groups (None where the box does not expose it)."""
+    """Shader clock / power / temperature of torch device `index` from sysfs, read OUTSIDE the timed groups.  The device is found by its PCI
+    address (a box may expose the sysfs nodes of GPUs this process cannot use: card0 is not necessarily cuda:0); None where the box does
+    not expose it."""
     import glob
 
     out = {}
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
-        if not cards:
-            return None
-        c = cards[min(index, len(cards) - 1)]
+        pr = torch.cuda.get_device_properties(index)
+        addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        c = os.path.join("/sys/bus/pci/devices", addr)
+        if not os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+            return {"pci": addr, "note": "no pp_dpm_sclk under this PCI address"}
+        out["pci"] = addr
         for line in open(os.path.join(c, "pp_dpm_sclk")):
             if "*" in line:
                 out["sclk"] = line.split(":", 1)[1].replace("*", "").strip()
@@ -102,7 +105,7 @@ def device_clocks(index):
                 out["mclk"] = line.split(":", 1)[1].replace("*", "").strip()
         for hw in glob.glob(os.path.join(c, "hwmon", "hwmon*")):
             for name, key, scale in (("power1_average", "power_W", 1e-6), ("power1_input", "power_W", 1e-6), ("temp1_input", "temp_C", 1e-3),
-                                     ("freq1_input", "sclk_MHz_hwmon", 1e-6)):
+                                     ("freq1_input", "sclk_MHz_hwmon", 1e-6), ("power1_cap", "power_cap_W", 1e-6)):
                 f = os.path.join(hw, name)
                 if os.path.exists(f) and key not in out:
                     try:
@@ -113,7 +116,7 @@ def device_clocks(index):
             out["busy_percent"] = int(open(os.path.join(c, "gpu_busy_percent")).read().strip())
         except (OSError, ValueError):
             pass
-    except OSError:
+    except (OSError, AttributeError, RuntimeError):
         return out or None
     return out or None
 

@@ -90,7 +90,9 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
 /* The same with a caller-owned workspace.  When both gsrc and gmat are wanted and workspace_bytes >= km_warp2d_bwd_workspace_bytes(...)
  * (16-byte aligned device memory, contents irrelevant, not used after the launches it is passed to), both gradients come from ONE read
  * of grad_out (a persistent tile-owner kernel that keeps its source tile in LDS: 3e bytes per element instead of 4e).  With a null /
- * short workspace it is km_warp2d_bwd.  Same results to the rounding of the fixed-point scale (both within the tolerances of tests/). */
+ * short workspace it is km_warp2d_bwd.  Same results to the rounding of the fixed-point scale (both within the tolerances of tests/).
+ * On that path (both gradients wanted, km_warp2d_bwd_workspace_bytes(...) > 0 and a workspace of at least that size) gmat need NOT be
+ * zeroed by the caller: the first launch of the sequence does it (ABI version 2; zeroing it anyway is harmless). */
 int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
                      int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align_corners,
                      const void* fill, int dtype, void* workspace, long long workspace_bytes, void* stream);

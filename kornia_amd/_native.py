@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KORNIA_AMD_LIB") or os.path.join(_PKG, "lib", "libkornia_amd.so")  # env override: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KM_F32, KM_F64, KM_BF16, KM_F16 = 0, 1, 2, 3
 _DTYPE_CODES = {torch.float32: KM_F32, torch.float64: KM_F64, torch.bfloat16: KM_BF16, torch.float16: KM_F16}

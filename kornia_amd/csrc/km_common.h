@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define KM_ABI_VERSION 1
+#define KM_ABI_VERSION 2
 
 // dtype codes of the C ABI (include/kornia_amd.h)
 enum { KM_F32 = 0, KM_F64 = 1, KM_BF16 = 2, KM_F16 = 3 };

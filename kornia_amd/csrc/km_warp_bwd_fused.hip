@@ -139,6 +139,8 @@ template <typename T, int CM>
 __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFusedArgs<T> a) {
     const KmWarpGeom<float>& g = a.g;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    // the fp64 accumulators of the matrix gradient start at zero: this launch precedes every atomic on them (the caller need not zero)
+    for (uint32_t k = t; k < (uint32_t)g.B_M * 9u; k += gridDim.x * 256u) a.gmat[k] = 0.0;
     if (t >= a.ntiles) return;
     int b, tx, ty;
     kmo_tile_coords(a, t, b, tx, ty);
@@ -302,14 +304,16 @@ __device__ __forceinline__ void kmo_pix(const KmtPix& q, const float (&go)[CC], 
         const bool num = (q.x == q.x) & (q.y == q.y);  // a NaN position touches nothing (ATen: the converted index is out of bounds)
         t00 = t00 && num; t01 = t01 && num; t10 = t10 && num; t11 = t11 && num;
     }
-    const int l00 = (int)(uy * (uint32_t)KMT_TW + ux);
-    // scale = 2^k: (wx * wy) * scale == wx * (wy * scale) bit for bit.  Tap-outer order: one exec-mask region per tap.
+    // scale = 2^k: (wx * wy) * scale == wx * (wy * scale) bit for bit.  Tap-outer order: one exec-mask region per tap (the four taps
+    // without exec-mask regions - zero weights, non-owned taps parked on a cell of the lane's own - and a wave-uniform skip of pixels that
+    // own no tap measured the same time: profiles/r04/bwd_fused_per_pixel_variants.txt).
     const float wy0s = FIXED ? t.wy0 * scale : t.wy0, wy1s = FIXED ? t.wy1 * scale : t.wy1;
     const float w00 = t.wx1 * wy1s, w01 = t.wx0 * wy1s, w10 = t.wx1 * wy0s, w11 = t.wx0 * wy0s;
     float gix = 0.f, giy = 0.f;
 #ifndef KMO_ABL
 #define KMO_ABL 0  // timing experiments only (wrong results): 1 no matrix-gradient work, 2 no LDS atomics, 4 no per-pixel work
 #endif
+    const int l00 = (int)(uy * (uint32_t)KMT_TW + ux);
 #define KMO_TAP(pred, OFF, W, SX, WX, SY, WY)                                                        \
     if (pred) {                                                                                       \
         float dot = 0.f;                                                                              \
@@ -924,7 +928,7 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     a.tiles_y = (uint32_t)((H + KMO_TH - 1) / KMO_TH);
     const uint64_t ntiles = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
     KM_REQUIRE(ntiles < (1ull << 26), "km_warp2d_bwd: grid too large");
-    if (ntiles == 0) return 0;
+    if (ntiles == 0) return (int)hipMemsetAsync(gmat, 0, (size_t)B_M * 9 * sizeof(double), s);  // (nothing to add: the accumulators are still this path's to zero)
     a.ntiles = (uint32_t)ntiles;
     const int cus = km_device_cus();
 #ifdef KMO_WORKERS_OVERRIDE  // (variant libraries only: fewer persistent workgroups than CUs - what the clock does when part of the chip idles)

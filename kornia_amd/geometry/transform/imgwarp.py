@@ -4,8 +4,9 @@ Same signatures, defaults, argument meaning and error behaviour as the reference
 (kornia/geometry/transform/imgwarp.py:69-174, :177-290, :323-353, :1476-1549).  What differs is the
 execution: one HIP launch for the 3x3 chain and one for coordinate generation + sampling, instead
 of ~25 elementwise launches that build a (B,h,w,2) grid in HBM followed by ``F.grid_sample``; the
-backward is one launch per gradient (image: tile-owner scatter; matrix: forward-shaped reduction) plus the tiny chain
-adjoint.
+backward takes both gradients from ONE read of grad_out when both are wanted (persistent tile-owner kernel,
+csrc/km_warp_bwd_fused.hip: bilinear, zeros / border / reflection / fill padding), otherwise one launch per gradient
+(image: tile-owner scatter; matrix: forward-shaped reduction), plus the tiny chain adjoint.
 
 There is no PyTorch/CPU fallback: tensors must live on a HIP device.
 """
@@ -101,7 +102,6 @@ class _Warp2dFunction(torch.autograd.Function):
         if need_src:
             zero = lib.km_warp2d_bwd_needs_zero_init(cfg.interp, cfg.pad, N.dtype_code(x.dtype))
             gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
-        gm = torch.zeros(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
         gmat = None
         # both gradients wanted: a workspace lets the library take them from one read of grad_out (include/kornia_amd.h)
         ws, ws_bytes = None, 0
@@ -109,6 +109,8 @@ class _Warp2dFunction(torch.autograd.Function):
             ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, cfg.interp, cfg.pad, N.dtype_code(x.dtype)))
             if ws_bytes > 0:
                 ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        # (on the one-read path the first launch zeroes the fp64 accumulators itself: one fill launch less per step)
+        gm = (torch.empty if ws is not None else torch.zeros)(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
         with N.device_guard(dev):
             N.check(lib.km_warp2d_bwd_ws(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
                                          B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),

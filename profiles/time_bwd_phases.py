@@ -46,3 +46,10 @@ for k in range(PH):
 # the slowest / fastest wave of a workgroup in the scatter
 sc = a[:, :, 5] / tiles_per_worker
 print(f"  scatter: per-workgroup spread (max - min over its 16 waves), mean over workgroups: {(sc.max(axis=1)-sc.min(axis=1)).mean():.0f} cycles")
+# per-WORKER totals (a persistent workgroup = a CU): the launch ends when the slowest worker does
+wt = tot.max(axis=1)  # a workgroup ends with its slowest wave
+order = np.argsort(wt)
+print(f"  per worker (max over its waves), cycles: min {wt.min():.0f}  median {np.median(wt):.0f}  mean {wt.mean():.0f}  max {wt.max():.0f}   max / median {wt.max()/np.median(wt):.3f}")
+print("  slowest workers: " + ", ".join(f"#{int(i)}: {wt[i]:.0f}" for i in order[-6:][::-1]) + "   fastest: " + ", ".join(f"#{int(i)}: {wt[i]:.0f}" for i in order[:4]))
+xcd = np.array([wt[i::8].mean() for i in range(8)])
+print("  mean per XCD (worker index mod 8): " + " ".join(f"{v:.0f}" for v in xcd))
