@@ -25,7 +25,7 @@
 // Three launches, so that the persistent loop carries nothing it rarely needs (inlined, the general path and the box computation cost
 // the loop 250 spilled registers; as function calls, more):
 //   1. km_warp_bwd_boxes_kernel   one THREAD per tile: its box (kmt_tile_box, ~400 dependent instructions), head-room bits and
-//                                 class -> 32 bytes of the caller's workspace;
+//                                 class -> an 80-byte record of the caller's workspace;
 //   2. km_warp_bwd_fused_kernel   the persistent loop over the REGULAR tiles (box fits the registers, fixed point accurate, division
 //                                 operands in range).  A regular tile that meets a non-finite gradient marks itself and leaves;
 //   3. km_warp_bwd_general_kernel the remaining tiles (minification beyond ~1.2x, the vanishing line, > 7x magnification, NaN / inf in
@@ -39,6 +39,8 @@
 // shaped by where the compiler's waits land (it cannot count loads issued under a branch, and it orders every write of a register
 // after the loads in flight): see the comments at kmo_stage, kmo_issue_src and kmo_process.
 #include <stdlib.h>
+
+#include <atomic>
 
 #include "km_warp_gm_rows.h"
 #include "km_warp_tile.h"
@@ -194,7 +196,7 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
     d.bw = bw;
     d.nq = (bw > 0 && bh > 0) ? bw * bh : 0;
     d.p = 0;
-    d.npass = max(1, (d.nq + KMO_CAP - 1) / KMO_CAP);
+    d.npass = d.regular ? max(1, (d.nq + KMO_CAP - 1) / KMO_CAP) : 1;  // (a tile of the general launch is ONE item of the persistent loop, whatever its box)
     // 16-byte rows of the source tile / of the tile flush
     d.svec = (sizeof(T) == 4) && d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.src & 15) == 0;
     d.fvec = d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0;
@@ -838,6 +840,111 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
     if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
 }
 
+// ---- launch 3, first part: non-finite gradients at output pixels NO tile visits ---------------------------------------------------
+// The tiles' boxes cover every output pixel whose footprint touches the source image; a pixel that samples entirely outside it is read by
+// nobody.  In the reference such a pixel still multiplies grad_out into the matrix gradient - 0 * inf, 0 * NaN (ATen's backward takes
+// the out-of-bounds taps as zeros and multiplies) - so an image whose grad_out holds an inf or NaN ANYWHERE has a non-finite matrix
+// gradient (every pixel's term is a finite factor times its grad_out).  Visited pixels produce theirs through the IEEE path of this
+// launch; this scan finds the rest: 16 x 16 blocks of the output are classified by their corners (a projective map with a denominator of
+// one sign sends the block to a convex quad), blocks that may hold an unvisited pixel are tested pixel by pixel with an APPROXIMATE
+// position and a margin (testing a visited pixel as well changes nothing: its gradient already made the result non-finite), and an image
+// with a hit gets NaN added to its accumulators.
+struct KmoScanMap {
+    float au, bu, av, bv;  // base coordinates: u = au * j + bu, v = av * i + bv
+    float sx, ox, sy, oy;  // source pixel = s * normalised + o
+};
+template <int CM, int ALIGN>
+__device__ __forceinline__ KmoScanMap kmo_scan_map(const KmWarpGeom<float>& g) {
+    KmoScanMap k;
+    if (CM == KM_COORD_AFFINE) { k.au = g.lin_step_x; k.bu = g.lin_lo_x; k.av = g.lin_step_y; k.bv = g.lin_lo_y; }
+    else if (CM == KM_COORD_HOMOGRAPHY && !g.norm_coords) { k.au = 1.f; k.bu = 0.f; k.av = 1.f; k.bv = 0.f; }
+    else { k.au = g.w > 1 ? 2.f / (float)(g.w - 1) : 0.f; k.bu = -1.f; k.av = g.h > 1 ? 2.f / (float)(g.h - 1) : 0.f; k.bv = -1.f; }
+    k.sx = ALIGN ? 0.5f * (float)(g.W - 1) : 0.5f * (float)g.W; k.ox = ALIGN ? k.sx : k.sx - 0.5f;
+    k.sy = ALIGN ? 0.5f * (float)(g.H - 1) : 0.5f * (float)g.H; k.oy = ALIGN ? k.sy : k.sy - 0.5f;
+    return k;
+}
+// approximate source position of output pixel (j, i) (a few ulps and one v_rcp away from the forward's) and the sign of its denominator
+template <int CM>
+__device__ __forceinline__ void kmo_scan_pos(const KmoScanMap& k, const float (&m)[9], float j, float i, float& x, float& y, float& den) {
+    const float u = km_fma(k.au, j, k.bu), v = km_fma(k.av, i, k.bv);
+    const float nx = km_fma(m[0], u, km_fma(m[1], v, m[2])), ny = km_fma(m[3], u, km_fma(m[4], v, m[5]));
+    den = (CM == KM_COORD_AFFINE) ? 1.f : km_fma(m[6], u, km_fma(m[7], v, m[8]));
+    const float r = (CM == KM_COORD_AFFINE) ? 1.f : __builtin_amdgcn_rcpf(den);
+    x = km_fma(nx * r, k.sx, k.ox);
+    y = km_fma(ny * r, k.sy, k.oy);
+}
+// true unless the pixel is certain to have a tap inside the image (NaN positions: true)
+__device__ __forceinline__ bool kmo_scan_maybe_unvisited(float x, float y, float W, float H) {
+    const float e = 0.03125f;  // far above the error of the approximate position, far below a pixel
+    return !((x > -1.f + e) && (x < W - e) && (y > -1.f + e) && (y < H - e));
+}
+#define KMO_SCAN_BLK 16
+template <typename T, int CM, int ALIGN, int CC>
+__device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a) {
+    const KmWarpGeom<float>& g = a.g;
+    const int lane = threadIdx.x & 63;
+    const KmoScanMap k = kmo_scan_map<CM, ALIGN>(g);
+    const uint32_t bx = (uint32_t)(g.w + KMO_SCAN_BLK - 1) / KMO_SCAN_BLK, by = (uint32_t)(g.h + KMO_SCAN_BLK - 1) / KMO_SCAN_BLK;
+    const uint64_t nblk = (uint64_t)bx * by * (uint64_t)g.B;
+    const uint64_t waves = (uint64_t)gridDim.x * KMO_NW, wave = (uint64_t)blockIdx.x * KMO_NW + (threadIdx.x >> 6);
+    const float Wf = (float)g.W, Hf = (float)g.H;
+    const size_t dst_plane = (size_t)g.h * g.w;
+    for (uint64_t base = wave * 64u; base < nblk; base += waves * 64u) {
+        // lane = block: its four corners
+        const uint64_t e = base + (uint64_t)lane;
+        bool todo = false;
+        uint32_t b = 0, ty = 0, tx = 0;
+        if (e < nblk) {
+            b = (uint32_t)(e / ((uint64_t)bx * by));
+            const uint32_t r = (uint32_t)(e - (uint64_t)b * bx * by);
+            ty = r / bx; tx = r - ty * bx;
+            float m[9];
+            const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0u : b) * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) m[q] = mp[q];
+            const float j0 = (float)(tx * KMO_SCAN_BLK), j1 = (float)min((int)(tx * KMO_SCAN_BLK) + KMO_SCAN_BLK - 1, g.w - 1);
+            const float i0 = (float)(ty * KMO_SCAN_BLK), i1 = (float)min((int)(ty * KMO_SCAN_BLK) + KMO_SCAN_BLK - 1, g.h - 1);
+            float dmin = 3.0e38f, dmax = -3.0e38f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x, y, d;
+                kmo_scan_pos<CM>(k, m, (c & 1) ? j1 : j0, (c & 2) ? i1 : i0, x, y, d);
+                todo = todo || kmo_scan_maybe_unvisited(x, y, Wf, Hf);
+                dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+            }
+            // the corners speak for the block only where the denominator keeps its sign well away from zero
+            todo = todo || !((dmin > 0.f && dmin > 1e-3f * dmax) || (dmax < 0.f && dmax < 1e-3f * dmin));
+        }
+        unsigned long long pend = __ballot(todo);
+        while (pend) {  // (wave-uniform) one 16 x 16 block at a time: lane = column + 16 * (row mod 4), four rows of rows
+            const int src_lane = __builtin_ctzll(pend);
+            pend &= pend - 1ull;
+            const uint32_t bb = (uint32_t)__shfl((int)b, src_lane, 64), tty = (uint32_t)__shfl((int)ty, src_lane, 64), ttx = (uint32_t)__shfl((int)tx, src_lane, 64);
+            float m[9];
+            const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0u : bb) * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) m[q] = mp[q];
+            const int j = (int)(ttx * KMO_SCAN_BLK) + (lane & 15);
+            bool bad = false;
+#pragma unroll
+            for (int rr = 0; rr < KMO_SCAN_BLK / 4; ++rr) {
+                const int i = (int)(tty * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
+                if (j < g.w && i < g.h) {
+                    float x, y, d;
+                    kmo_scan_pos<CM>(k, m, (float)j, (float)i, x, y, d);
+                    if (kmo_scan_maybe_unvisited(x, y, Wf, Hf)) {
+                        const T* gp = a.gout + (size_t)bb * CC * dst_plane + (size_t)i * g.w + (size_t)j;
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) bad = bad || ((__float_as_uint((float)km_ld(gp + (size_t)c * dst_plane)) & 0x7f800000u) == 0x7f800000u);
+                    }
+                }
+            }
+            if (__ballot(bad) != 0ull && lane < (CM == KM_COORD_AFFINE ? 6 : 9))
+                km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0u : bb) * 9 + lane, (double)__int_as_float(0x7fc00000));
+        }
+    }
+}
+
 // ---- launch 3: the tiles the persistent loop left (class "general", or a non-finite gradient met at run time) ---------------------
 // Workgroup w looks at the records of tiles general_tiles * w ... (lane = tile, one ballot; up to 64 of them, fewer for small problems so
 // that a batch of a few images whose every tile is marked still spreads over the chip) and walks the marked ones.
@@ -854,6 +961,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
 #pragma unroll
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
     const uint32_t t0 = blockIdx.x * a.general_tiles;
+    kmo_scan_unvisited<T, CM, ALIGN, CC>(a);  // (every workgroup of the launch takes its share first: most have nothing else to do)
     if (wave == 0) {
         const uint32_t t = t0 + (uint32_t)lane;
         int fl = KMO_F_REGULAR;
@@ -898,12 +1006,16 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
 template <typename T, int CM, int ALIGN, int CC>
 static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
     constexpr int lds = kmo_lds_bytes(CC);
-    static bool attr_set = false;  // (idempotent: a race sets the same values twice)
-    if (!attr_set) {
+    // (the attribute is kept per DEVICE by the runtime: one flag per device ordinal; idempotent - a race sets the same values twice)
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<bool>* attr_set_p = (dev >= 0 && dev < 64) ? &attr_done[dev] : nullptr;
+    if (!attr_set_p || !attr_set_p->load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)km_warp_bwd_general_kernel<T, CM, ALIGN, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { km_set_error("km_warp2d_bwd(fused): hipFuncSetAttribute(%d bytes of LDS) failed: %s", lds, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
+        if (attr_set_p) attr_set_p->store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((km_warp_bwd_boxes_kernel<T, CM>), dim3((a.ntiles + 255u) / 256u), dim3(256), 0, s, a);
     hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
@@ -963,7 +1075,7 @@ int km_warp_bwd_fused_supported(int interp, int pad, int dtype, int C, int H, in
     return ((uint64_t)H * W * 4 < (1ull << 32) && (uint64_t)h * w * 4 < (1ull << 32)) ? 1 : 0;
 }
 
-// bytes of workspace the one-read backward needs for these sizes (one 32-byte record per 64 x 64 tile of the source)
+// bytes of workspace the one-read backward needs for these sizes (one KMO_BOX_INTS * 4 = 80-byte record per 64 x 64 tile of the source)
 size_t km_warp_bwd_fused_workspace(int B, int H, int W) {
     const uint64_t ntiles = (uint64_t)((W + KMT_TW - 1) / KMT_TW) * (uint64_t)((H + KMO_TH - 1) / KMO_TH) * (uint64_t)B;
     return (size_t)(ntiles * KMO_BOX_INTS * sizeof(int));

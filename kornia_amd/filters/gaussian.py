@@ -81,6 +81,7 @@ def gaussian_blur2d(input: torch.Tensor, kernel_size: Union[tuple[int, int], int
     else:
         sigma = _check_tensor_sigma(sigma, input)
         if (separable and N.on_device(input) and N.on_device(sigma) and input.dtype in (torch.float32, torch.bfloat16, torch.float16) and kx <= 64 and ky <= 64
+                and sigma.dim() == 2 and sigma.shape[-1] == 2 and sigma.shape[0] in (1, input.shape[0])  # (what gaussian_taps takes; anything else: the tensor path below)
                 and not (torch.is_grad_enabled() and sigma.requires_grad)):
             # per-sample sigma already on the device: both tap vectors in ONE launch (km_gaussian_taps_fwd) instead of the ~16
             # elementwise launches of two get_gaussian_kernel1d calls - the call was host-bound on them (265 us of enqueue for

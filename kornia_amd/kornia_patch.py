@@ -13,6 +13,7 @@ from __future__ import annotations
 import functools
 import importlib
 import sys
+import threading
 import weakref
 from typing import Callable
 
@@ -120,7 +121,7 @@ def _color_jitter_apply(original: Callable) -> Callable:
         # the per-sample probability switch of transform_inputs (augmentation/base.py:380-393) inside the same launch: a sample whose
         # draw failed is passed through untouched, and the torch.where pass that follows finds nothing to do (_blend_by_prob below)
         apply = None
-        if not (getattr(self, "p", 1.0) == 1.0 and getattr(self, "p_batch", 1.0) == 1.0) and not (torch.is_grad_enabled() and input.requires_grad):
+        if _switch_allowed() and not (getattr(self, "p", 1.0) == 1.0 and getattr(self, "p_batch", 1.0) == 1.0) and not (torch.is_grad_enabled() and input.requires_grad):
             bp = params.get("batch_prob")
             if isinstance(bp, torch.Tensor) and bp.numel() == input.shape[0]:
                 apply = torch.atleast_1d(bp.to(input.device) > 0.5)
@@ -160,6 +161,31 @@ def _registrator_level_loss(original: Callable) -> Callable:
 
     get_single_level_loss.__wrapped__ = original
     return get_single_level_loss
+
+
+_tls = threading.local()  # .blend_follows > 0: the caller is transform_inputs, whose _blend_by_prob call comes right after apply_transform
+
+
+def _transform_inputs(original: Callable) -> Callable:
+    """_AugmentationBase.transform_inputs (kornia/augmentation/base.py:363-400) unchanged, except that the apply_transform hooks below
+    know they were called from it: only there is ``params['batch_prob']`` the draw of THIS call and is the result blended afterwards, so
+    only there may the per-sample switch ride inside the op's launch.  A direct call of ``apply_transform`` or ``inverse_transform``
+    (which hands over ``self._params``) transforms every sample it is given, as in the reference."""
+
+    @functools.wraps(original)
+    def transform_inputs(self, *args, **kwargs):
+        _tls.blend_follows = getattr(_tls, "blend_follows", 0) + 1
+        try:
+            return original(self, *args, **kwargs)
+        finally:
+            _tls.blend_follows -= 1
+
+    transform_inputs.__wrapped__ = original
+    return transform_inputs
+
+
+def _switch_allowed() -> bool:
+    return getattr(_tls, "blend_follows", 0) > 0
 
 
 def _blend_by_prob(original: Callable) -> Callable:
@@ -240,7 +266,7 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
             return original(self, input, params, flags, transform)
         B, _, height, width = input.shape
         apply = None
-        if not (getattr(self, "p", 1.0) == 1.0 and getattr(self, "p_batch", 1.0) == 1.0):
+        if _switch_allowed() and not (getattr(self, "p", 1.0) == 1.0 and getattr(self, "p_batch", 1.0) == 1.0):
             bp = params.get("batch_prob") if hasattr(params, "get") else None
             if isinstance(bp, torch.Tensor) and bp.numel() == B:  # (inverse_inputs may call with a subset of the batch: no switch then)
                 apply = torch.atleast_1d(bp.to(input.device) > 0.5)
@@ -297,6 +323,9 @@ def patch() -> int:
     _patched_methods.append((ir_mod.ImageRegistrator, "get_single_level_loss", original))
     # the augmentation layer: the probability blend of every augmentation and RandomGaussianBlur's apply step
     base_mod = importlib.import_module("kornia.augmentation.base")
+    original = base_mod._AugmentationBase.transform_inputs
+    base_mod._AugmentationBase.transform_inputs = _transform_inputs(original)
+    _patched_methods.append((base_mod._AugmentationBase, "transform_inputs", original))
     original = base_mod._AugmentationBase.__dict__["_blend_by_prob"]  # the staticmethod object itself
     base_mod._AugmentationBase._blend_by_prob = _blend_by_prob(original.__func__)
     _patched_methods.append((base_mod._AugmentationBase, "_blend_by_prob", original))
@@ -316,7 +345,7 @@ def patch() -> int:
         original = cls.apply_transform
         cls.apply_transform = _geometric_apply(original, kind)
         _patched_methods.append((cls, "apply_transform", original))
-    return count + 9
+    return count + 10
 
 
 def unpatch() -> int:

@@ -462,6 +462,15 @@ void KO(ko_warp2d_bwd)(const REAL* gout, const REAL* src, const REAL* mat, REAL*
                         if (bne) { if (gi) gi[y0 * (long)W + x1] += ne * g; REAL v = img[y0 * (long)W + x1] - f; gix += v * wy1 * g; giy -= v * wx0 * g; }
                         if (bsw) { if (gi) gi[y1 * (long)W + x0] += sw * g; REAL v = img[y1 * (long)W + x0] - f; gix -= v * wy0 * g; giy += v * wx1 * g; }
                         if (bse) { if (gi) gi[y1 * (long)W + x1] += se * g; REAL v = img[y1 * (long)W + x1] - f; gix += v * wy0 * g; giy += v * wx0 * g; }
+                        /* An out-of-bounds tap is a ZERO that is still multiplied: ATen's CPU kernel (GridSamplerKernel.cpp, ApplyGridSample<..., Bilinear,
+                         * ...>::backward) gathers masked-out taps as 0 and forms ((ne - nw) * s + (se - sw) * n) * gOut, so an inf / NaN grad_out at a
+                         * pixel that samples outside the image makes the grid - hence the matrix - gradient NaN there (checked against
+                         * torch.nn.functional.grid_sample on CPU in the build container).  For finite values the terms below are +-0. */
+                        { const REAL z = (REAL)0;
+                          if (!bnw) { gix -= z * wy1 * g; giy -= z * wx1 * g; }
+                          if (!bne) { gix += z * wy1 * g; giy -= z * wx0 * g; }
+                          if (!bsw) { gix -= z * wy0 * g; giy += z * wx1 * g; }
+                          if (!bse) { gix += z * wy0 * g; giy += z * wx0 * g; } }
                     }
                     gix = gix * (mx * gdx);
                     giy = giy * (my * gdy);

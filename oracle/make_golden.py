@@ -456,6 +456,36 @@ def main():
                 dg[f"{name}__{k}"] = v
     save("geometric_aug", **dg)
 
+    # ---- inf / NaN in grad_out at a pixel that samples ENTIRELY outside the source (own generator: appended in round 4) -------------------
+    # ATen's CPU backward multiplies the zeros it gathered for out-of-bounds taps by grad_out, so the matrix gradient of that image is NaN
+    # while grad wrt the image stays finite; the one-read backward of the HIP path visits no such pixel and must find it by other means.
+    import math
+
+    g2 = torch.Generator().manual_seed(404)
+    dn = {}
+    Bn, Cn, Hn_, Wn = 3, 3, 70, 65
+    c_, s_ = math.cos(math.radians(45.0)), math.sin(math.radians(45.0))
+    cx, cy = (Wn - 1) / 2.0, (Hn_ - 1) / 2.0
+    Mn = torch.tensor([[c_, s_, (1 - c_) * cx - s_ * cy], [-s_, c_, s_ * cx + (1 - c_) * cy]]).repeat(Bn, 1, 1)
+    xn = torch.rand(Bn, Cn, Hn_, Wn, generator=g2)
+    for tag, bad in (("nan", float("nan")), ("inf", float("inf"))):
+        gon = torch.rand(Bn, Cn, Hn_, Wn, generator=g2) - 0.5
+        gon[2, :, Hn_ - 1, Wn - 1] = bad  # a corner of the output: rotated out of the source
+        xr, Mr = xn.clone().requires_grad_(), Mn.clone().requires_grad_()
+        T.warp_affine(xr, Mr, (Hn_, Wn)).backward(gon)
+        dn[f"affine_{tag}__go"], dn[f"affine_{tag}__gx"], dn[f"affine_{tag}__gM"] = gon, xr.grad, Mr.grad
+    dn["affine__x"], dn["affine__M"] = xn, Mn
+    Bp, Hp, Wp = 2, 96, 160
+    Mpn = flagship_homographies(Bp, Hp, Wp, Hp, Wp, g2, jitter=3.0)
+    Mpn[:, 0, 2] += 40.0  # 40 px to the right: the left columns of the output sample outside
+    xp = torch.rand(Bp, 3, Hp, Wp, generator=g2)
+    gop = torch.rand(Bp, 3, Hp, Wp, generator=g2) - 0.5
+    gop[0, :, 50, 2] = float("inf")
+    xr, Mr = xp.clone().requires_grad_(), Mpn.clone().requires_grad_()
+    T.warp_perspective(xr, Mr, (Hp, Wp)).backward(gop)
+    dn.update(persp__x=xp, persp__M=Mpn, persp__go=gop, persp__gx=xr.grad, persp__gM=Mr.grad)
+    save("nonfinite_outside", **dn)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

@@ -157,6 +157,17 @@ template <typename T> inline T __shfl_down(T v, unsigned off, int width = 64) {
     memcpy(&r, &got, sizeof(T));
     return ok ? r : v;
 }
+// ds_bpermute-style read of lane `src` (0 .. 63): every live lane must reach it; a lane that has exited gives the caller's own value
+template <typename T> inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    bool ok = false;
+    const uint64_t got = emu::wave_exchange(bits, src & (width - 1), &ok);
+    T r;
+    memcpy(&r, &got, sizeof(T));
+    return ok ? r : v;
+}
 // DPP row_shl:1 (km_common.h km_next16): lane i of a row of 16 reads lane i + 1, the last lane of the row its own value
 #define KM_NEXT16 1
 inline uint32_t km_next16(uint32_t v) { return __shfl_down(v, 1, 16); }

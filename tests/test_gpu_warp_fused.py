@@ -154,6 +154,69 @@ def test_tiles_of_the_general_launch(oracle, case):
         assert _rel(gM, gM2) <= 2e-4
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+@pytest.mark.parametrize("case", ["affine_45deg", "affine_wide", "perspective_shift"])
+def test_non_finite_gradient_at_a_pixel_no_tile_visits(oracle, case, bad):
+    """A pixel that samples entirely outside the source is in no tile's box, yet the reference multiplies its grad_out into the matrix
+    gradient (zeros for the out-of-bounds taps times inf / NaN): the matrix gradient of THAT image is not finite, the others' are
+    untouched, grad wrt the image stays finite.  One-read backward == two launches == oracle in which entries are finite."""
+    import kornia_amd as K
+
+    g = torch.Generator().manual_seed(3)
+    if case == "affine_45deg":
+        B, C, H, W, h, w = 3, 3, 70, 65, 70, 65
+        import math
+
+        c_, s_ = math.cos(math.radians(45.0)), math.sin(math.radians(45.0))
+        cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+        M = torch.tensor([[c_, s_, (1 - c_) * cx - s_ * cy], [-s_, c_, s_ * cx + (1 - c_) * cy]]).repeat(B, 1, 1)
+        fn = lambda a, m: K.warp_affine(a, m, (h, w))
+        bwd = lambda go_, x_, M_: oracle.warp_affine_backward(go_, x_, M_, (h, w))
+        hit = (2, slice(None), h - 1, w - 1)  # a corner of the output: rotated out of the source
+    elif case == "affine_wide":
+        B, C, H, W, h, w = 2, 1, 3, 130, 9, 70
+        M = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]).repeat(B, 1, 1)
+        fn = lambda a, m: K.warp_affine(a, m, (h, w))
+        bwd = lambda go_, x_, M_: oracle.warp_affine_backward(go_, x_, M_, (h, w))
+        hit = (1, slice(None), h - 1, 5)      # rows 3.. of the output are below the 3-row source
+    else:
+        B, C, H, W, h, w = 2, 3, 96, 160, 96, 160
+        M = flagship_homographies(B, H, W, h, w, g, jitter=3.0)
+        M[:, 0, 2] += 40.0                     # 40 px to the right: the left columns of the output sample outside
+        fn = lambda a, m: K.warp_perspective(a, m, (h, w))
+        bwd = lambda go_, x_, M_: oracle.warp_perspective_backward(go_, x_, M_, (h, w))
+        hit = (0, slice(None), 50, 2)
+    x = torch.rand(B, C, H, W, generator=g)
+    go = torch.rand(B, C, h, w, generator=g) - 0.5
+    go[hit] = bad
+    gx, gM = _run(fn, x, M, go, True)
+    gx2, gM2 = _run(fn, x, M, go, False)
+    gxo, gMo = bwd(go, x, M)
+    b = hit[0]
+    assert not torch.isfinite(gMo[b]).any() or not torch.isfinite(gMo[b]).all(), "the case must make the oracle's matrix gradient non-finite"
+    for name, m_ in (("one-read", gM), ("two launches", gM2)):
+        assert torch.equal(torch.isfinite(m_), torch.isfinite(gMo)), f"{name}: finite entries differ from the oracle's\n{m_}\n{gMo}"
+    others = [i for i in range(B) if i != b]
+    assert _rel(gM[others], gMo[others]) <= 5e-5
+    assert torch.isfinite(gx).all() and torch.allclose(gx, gxo, atol=1e-5, rtol=0)  # the pixel touches no source pixel
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_non_finite_gradient_outside_the_source_reference_fixture(fused):
+    """The same against the reference's own result (tests/golden/nonfinite_outside.npz, oracle/make_golden.py)."""
+    import kornia_amd as K
+    from _util import golden
+
+    d = {k: torch.from_numpy(v) for k, v in golden("nonfinite_outside").items()}
+    for tag in ("nan", "inf"):
+        gx, gM = _run(lambda a, m: K.warp_affine(a, m, (70, 65)), d["affine__x"], d["affine__M"], d[f"affine_{tag}__go"], fused)
+        assert torch.equal(torch.isfinite(gM), torch.isfinite(d[f"affine_{tag}__gM"])), gM
+        assert torch.isfinite(gx).all() and torch.allclose(gx, d[f"affine_{tag}__gx"], atol=1e-5)
+    gx, gM = _run(lambda a, m: K.warp_perspective(a, m, (96, 160)), d["persp__x"], d["persp__M"], d["persp__go"], fused)
+    assert torch.equal(torch.isfinite(gM), torch.isfinite(d["persp__gM"])), gM
+    assert torch.isfinite(gx).all() and torch.allclose(gx, d["persp__gx"], atol=1e-5)
+
+
 @pytest.mark.parametrize("case", ["growing", "zero_top", "nonfinite_bottom", "shrinking"])
 @pytest.mark.parametrize("angle", [0.0, 30.0])
 def test_fixed_point_scale_follows_the_gradients_of_the_box(oracle, case, angle):

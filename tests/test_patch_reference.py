@@ -198,6 +198,14 @@ def test_augmentation_hooks_with_probabilities_on_the_host_build():
             yg = cj(xg, params=params[2].data)
             yg.sum().backward()
             xr = x.clone().requires_grad_()
+            # a DIRECT call of apply_transform (or inverse_transform, which hands over self._params) is no transform_inputs call: no
+            # blend follows it, so the switch must not ride in the launch - every sample given is transformed, as in the reference
+            ra = aug[0]
+            pa = params[0].data
+            fl = ra.flags
+            tm = ra.compute_transformation(x.cuda(), pa, fl)
+            direct = ra.apply_transform(x.cuda(), pa, fl, transform=tm)
+            assert not hasattr(direct, "_kornia_amd_blended_with")
         finally:
             assert P.unpatch() == n
     # one select pass only - the blur's (its switch cannot ride in the taps bit for bit, kornia_amd/augmentation.py); the warps and
@@ -214,6 +222,10 @@ def test_augmentation_hooks_with_probabilities_on_the_host_build():
     assert torch.equal(out[untouched], x[untouched])
     blend_after = base_mod._AugmentationBase.__dict__["_blend_by_prob"]
     assert blend_after is blend_before and isinstance(blend_after, staticmethod)
+    # the direct call against the unpatched module's own apply_transform: all eight samples warped, whatever batch_prob says
+    direct_ref = aug[0].apply_transform(x, pa, fl, transform=aug[0].compute_transformation(x, pa, fl))
+    assert torch.allclose(direct, direct_ref, atol=2e-5, rtol=0), (direct - direct_ref).abs().max()
+    assert not torch.equal(direct[~probs[0]], x[~probs[0]])
 
 
 def test_reference_own_tests_pass_on_the_native_path():
