@@ -1124,7 +1124,7 @@ int km_warp_gm_run(const void* gout, const void* src, const void* mat, double* g
 
 // both gradients from one read of grad_out (km_warp_bwd_fused.hip)
 int km_warp_bwd_fused_supported(int interp, int pad, int dtype, int C, int H, int W, int h, int w);
-size_t km_warp_bwd_fused_workspace(int B, int H, int W);
+size_t km_warp_bwd_fused_workspace(int B, int C, int H, int W);
 int km_warp_bwd_fused_run(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, void* ws, int B, int C, int H, int W, int h, int w,
                           int B_M, int coord_mode, int norm_coords, int pad, int align, const void* fill, int dtype, hipStream_t s);
 
@@ -1182,7 +1182,7 @@ int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* g
         if (km_warp_bwd_tiled_dims_ok(h, w)) {
             // both gradients wanted: one persistent launch that reads grad_out once (3e bytes per element instead of 4e)
             if (gmat && workspace && km_warp_bwd_fused_supported(interp, pad, dtype, C, H, W, h, w) &&
-                (unsigned long long)workspace_bytes >= (unsigned long long)km_warp_bwd_fused_workspace(B, H, W) && ((uintptr_t)workspace & 15) == 0)
+                (unsigned long long)workspace_bytes >= (unsigned long long)km_warp_bwd_fused_workspace(B, C, H, W) && ((uintptr_t)workspace & 15) == 0)
                 return km_warp_bwd_fused_run(gout, src, mat, gsrc, gmat, workspace, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
             // scatter first, matrix gradient second: with the alternating batch traversal (km_traversal_next) the second launch starts on the
             // part of grad_out the first one read last.  (The other order measured 1.868 against 1.845 ms per step - no better than a fixed direction.)
@@ -1221,7 +1221,7 @@ long long km_warp2d_bwd_workspace_bytes(int B, int C, int H, int W, int h, int w
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return 0;
     if (!km_warp_bwd_tiled_supported(interp, pad, dtype, &dummy) || !km_warp_bwd_tiled_dims_ok(h, w)) return 0;
     if (!km_warp_bwd_fused_supported(interp, pad, dtype, C, H, W, h, w)) return 0;
-    return (long long)km_warp_bwd_fused_workspace(B, H, W);
+    return (long long)km_warp_bwd_fused_workspace(B, C, H, W);
 }
 
 // ---- explicit sampling grid: replaces F.grid_sample(input, grid) as called by remap (imgwarp.py:702) and

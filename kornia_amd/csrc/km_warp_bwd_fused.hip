@@ -80,7 +80,7 @@ __device__ unsigned long long kmo_prof_out[512 * 16 * KMO_PROF_PHASES];
 #define KMO_SRC_AT 0       // slot of the scatter after which the next tile's source tile is requested
 #endif
 #define KMO_RUN 64         // records wave 0 fetches from the workspace at once (lane = tile), into alternating halves of a 2 x 64 ring
-#define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, -, -, the 9 matrix entries, -, -, -
+#define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, first plane, matrix row, the 9 matrix entries, -, -, -
 enum { KMO_F_FIXED = 1, KMO_F_REGULAR = 4, KMO_F_NONFINITE = 8 };
 
 template <typename T>
@@ -98,6 +98,11 @@ struct KmWarpFusedArgs {
     uint32_t general_tiles;  // tiles a workgroup of the general launch looks at (1 .. 64)
     uint32_t reverse;    // the launch walks the batch backwards (km_traversal_next)
     uint32_t stream_out; // streaming stores of the tile flush (km_stream_stores)
+    // Channel groups.  A launch covers channels c0 .. c0 + ngrp * cc - 1 of every image in groups of cc (= the kernel's CC: 3 or 1): an "image"
+    // of the tile sequence is an (image, group) pair, so any channel count runs through the same LDS tiles as RGB / grey - C = 3 a + r takes one
+    // launch sequence with CC = 3 (a groups) and one with CC = 1 (r groups).  All groups of an image add to the same matrix gradient.
+    uint32_t c0, ngrp, cc;
+    uint32_t first;      // the first launch sequence of the call: it zeroes gmat (boxes) and scans for unvisited non-finite gradients (general)
 };
 
 __host__ __device__ constexpr int kmo_lds_bytes(int cc) {
@@ -107,7 +112,8 @@ __host__ __device__ constexpr int kmo_lds_bytes(int cc) {
 // One tile (everything block-uniform)
 struct KmoTile {
     int t;             // linear tile index (b, ty, tx), < 0: the sequence has ended
-    int b, X0, Y0, TWc, THc;
+    int b, X0, Y0, TWc, THc;   // b: (image, channel group) index of the sequence
+    int plane0, bm;    // plane index of the group's first channel in src / gsrc / grad_out; row of mat / gmat
     int j0, j1, i0, i1, hb;
     bool fixed_ok, regular, svec, fvec;
     int bw, nq;
@@ -142,10 +148,12 @@ __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFuse
     const KmWarpGeom<float>& g = a.g;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // the fp64 accumulators of the matrix gradient start at zero: this launch precedes every atomic on them (the caller need not zero)
-    for (uint32_t k = t; k < (uint32_t)g.B_M * 9u; k += gridDim.x * 256u) a.gmat[k] = 0.0;
+    if (a.first)
+        for (uint32_t k = t; k < (uint32_t)g.B_M * 9u; k += gridDim.x * 256u) a.gmat[k] = 0.0;
     if (t >= a.ntiles) return;
-    int b, tx, ty;
-    kmo_tile_coords(a, t, b, tx, ty);
+    int bg, tx, ty;
+    kmo_tile_coords(a, t, bg, tx, ty);
+    const int b = bg / (int)a.ngrp, grp = bg - b * (int)a.ngrp;  // (image, channel group)
     float m[9];
     const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0 : b) * 9;
 #pragma unroll
@@ -163,7 +171,8 @@ __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFuse
     o[0] = bx.j0; o[1] = bx.j1; o[2] = bx.i0; o[3] = bx.i1;
     o[4] = (int)ceilf(log2f(fmaxf(bx.mult, 1.f))) + 1;  // head-room bits
     o[5] = (bx.fixed_ok ? KMO_F_FIXED : 0) | ((fits && fast && bx.fixed_ok) ? KMO_F_REGULAR : 0);
-    o[6] = 0; o[7] = 0;
+    o[6] = b * g.C + (int)a.c0 + grp * (int)a.cc;  // plane index of the group's first channel (< 2^31: checked by the host)
+    o[7] = g.B_M == 1 ? 0 : b;                      // row of mat / gmat
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[8 + k] = __float_as_int(m[k]);  // (the tile loop reads its matrix from LDS, not through a vector load)
     o[17] = 0; o[18] = 0; o[19] = 0;
@@ -190,6 +199,7 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
     d.TWc = min(d.X0 + KMT_TW, g.W) - d.X0; d.THc = min(d.Y0 + KMO_TH, g.H) - d.Y0;
     d.j0 = kmt_uniform(rec[0]); d.j1 = kmt_uniform(rec[1]); d.i0 = kmt_uniform(rec[2]); d.i1 = kmt_uniform(rec[3]);
     d.hb = kmt_uniform(rec[4]);
+    d.plane0 = kmt_uniform(rec[6]); d.bm = kmt_uniform(rec[7]);
     const int fl = kmt_uniform(rec[5]);
     d.fixed_ok = (fl & KMO_F_FIXED) != 0; d.regular = (fl & KMO_F_REGULAR) != 0;
     const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
@@ -236,7 +246,7 @@ __device__ __forceinline__ void kmo_issue_src(const KmWarpFusedArgs<T>& a, const
     static_assert(CC * KMO_PLANE % (4 * KMO_NT) == 0, "whole 16-byte pieces per thread");
     const KmWarpGeom<float>& g = a.g;
     const size_t src_plane = (size_t)g.H * g.W;
-    const T* src_b = a.src + (size_t)d.b * g.C * src_plane;
+    const T* src_b = a.src + (size_t)d.plane0 * src_plane;
     const int tid = threadIdx.x;
     if (d.svec) {
 #pragma unroll
@@ -463,7 +473,7 @@ __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, co
     const size_t dst_plane = (size_t)g.h * g.w;
     const T* gout_c[CC];
 #pragma unroll
-    for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)d.b * g.C + (size_t)c) * dst_plane;
+    for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)d.plane0 + (size_t)c) * dst_plane;
     const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
     const bool empty = (bw <= 0 || bh <= 0);
     finite = false;
@@ -558,7 +568,7 @@ __device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const Kmo
     const KmWarpGeom<float>& g = a.g;
     const int tid = threadIdx.x;
     const size_t src_plane = (size_t)g.H * g.W;
-    float* gsrc_b = a.gsrc + (size_t)d.b * g.C * src_plane;
+    float* gsrc_b = a.gsrc + (size_t)d.plane0 * src_plane;
     if (d.fvec) {
         // full-width tile, 16-byte aligned rows: 16 lanes x 16 bytes cover a tile row, a wave writes 4 rows per store
         const int col4 = (tid & 15) * 4, row0 = tid >> 4;
@@ -695,7 +705,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         kmo_walk_init(a, cur, w0);
         if (cur.t >= 0 && cur.regular) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)cur.b * g.C + (size_t)c) * dst_plane;
+            for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)cur.plane0 + (size_t)c) * dst_plane;
             kmo_issue_src<T, CC>(a, cur, S);
         } else {
             w0.nq = 0;
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         for (int s = 0; s < KMO_SLOTS; ++s) kmo_request_slot<T, CC>(gout_c, g.w, s, w0, G[s]);
     }
     float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int pending_b = -1;      // image whose matrix-gradient partials sit in s_gm
+    int pending_b = -1;      // row of gmat whose matrix-gradient partials sit in s_gm
     KmoTile prev = KmoTile{};  // the tile whose accumulators wait to be flushed (prev_discard: zeroed without being written)
     prev.t = -1;
     float prev_inv_scale = 1.f;
@@ -756,12 +766,12 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         kmo_walk_init(a, nxt, wn);
         if (nxt.t >= 0 && nxt.regular) {
 #pragma unroll
-            for (int c = 0; c < CC; ++c) gout_n[c] = a.gout + ((size_t)nxt.b * g.C + (size_t)c) * dst_plane;
+            for (int c = 0; c < CC; ++c) gout_n[c] = a.gout + ((size_t)nxt.plane0 + (size_t)c) * dst_plane;
         } else {
             wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
         }
         // matrix-gradient partials of the image finished before this tile
-        if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
+        if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)pending_b * 9, tid);
         pending_b = -1;
 
         // ---- the fixed-point scale: from the exact maximum of the first pass; a later pass with a larger one rescales the accumulators ----
@@ -810,14 +820,14 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 
         if (last_pass) {
             // ---- an image that ends here publishes its matrix-gradient partials ----
-            if (nxt.t < 0 || nxt.b != cur.b) {
+            if (nxt.t < 0 || nxt.b != cur.b) {  // (per (image, group): the groups of an image meet in gmat's atomics)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const double s = km_wave_sum((double)A[k]);
                     if (lane == 0) l.s_gm[wave * 9 + k] = s;
                     A[k] = 0.f;
                 }
-                pending_b = cur.b;
+                pending_b = cur.bm;
             }
             if (cur.regular) {  // flushed (or, after a non-finite gradient, only zeroed) after the next item's stage
                 prev = cur;
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 #endif
     // ---- epilogue: the last image's partials ----
     __syncthreads();
-    if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : pending_b) * 9, tid);
+    if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)pending_b * 9, tid);
 }
 
 // ---- launch 3, first part: non-finite gradients at output pixels NO tile visits ---------------------------------------------------
@@ -933,9 +943,8 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a) 
                     float x, y, d;
                     kmo_scan_pos<CM>(k, m, (float)j, (float)i, x, y, d);
                     if (kmo_scan_maybe_unvisited(x, y, Wf, Hf)) {
-                        const T* gp = a.gout + (size_t)bb * CC * dst_plane + (size_t)i * g.w + (size_t)j;
-#pragma unroll
-                        for (int c = 0; c < CC; ++c) bad = bad || ((__float_as_uint((float)km_ld(gp + (size_t)c * dst_plane)) & 0x7f800000u) == 0x7f800000u);
+                        const T* gp = a.gout + (size_t)bb * g.C * dst_plane + (size_t)i * g.w + (size_t)j;
+                        for (int c = 0; c < g.C; ++c) bad = bad || ((__float_as_uint((float)km_ld(gp + (size_t)c * dst_plane)) & 0x7f800000u) == 0x7f800000u);
                     }
                 }
             }
@@ -961,7 +970,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
 #pragma unroll
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
     const uint32_t t0 = blockIdx.x * a.general_tiles;
-    kmo_scan_unvisited<T, CM, ALIGN, CC>(a);  // (every workgroup of the launch takes its share first: most have nothing else to do)
+    if (a.first) kmo_scan_unvisited<T, CM, ALIGN, CC>(a);  // (every workgroup of the launch takes its share first: most have nothing else to do)
     if (wave == 0) {
         const uint32_t t = t0 + (uint32_t)lane;
         int fl = KMO_F_REGULAR;
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
             if (lane == 0) l.s_gm[wave * 9 + i] = s;
         }
         __syncthreads();
-        kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)(g.B_M == 1 ? 0 : d.b) * 9, tid);
+        kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)d.bm * 9, tid);
     }
 }
 
@@ -1024,8 +1033,36 @@ static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
 }
 template <typename T, int CM>
 static int kmo_launch(const KmWarpFusedArgs<T>& a, hipStream_t s) {
-    if (a.g.C == 3) return a.g.align ? kmo_launch_k<T, CM, 1, 3>(a, s) : kmo_launch_k<T, CM, 0, 3>(a, s);
+    if (a.cc == 3) return a.g.align ? kmo_launch_k<T, CM, 1, 3>(a, s) : kmo_launch_k<T, CM, 0, 3>(a, s);
     return a.g.align ? kmo_launch_k<T, CM, 1, 1>(a, s) : kmo_launch_k<T, CM, 0, 1>(a, s);
+}
+
+// one launch sequence (boxes, persistent loop, general) over channels c0 .. c0 + ngrp * cc - 1 of every image
+template <typename T>
+static int kmo_run_groups(KmWarpFusedArgs<T>& a, int B, uint32_t c0, uint32_t ngrp, uint32_t cc, bool first, int coord_mode, hipStream_t s) {
+    a.c0 = c0; a.ngrp = ngrp; a.cc = cc; a.first = first ? 1u : 0u;
+    const uint64_t ntiles = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B * ngrp;
+    a.ntiles = (uint32_t)ntiles;
+    const int cus = km_device_cus();
+#ifdef KMO_WORKERS_OVERRIDE  // (variant libraries only: fewer persistent workgroups than CUs - what the clock does when part of the chip idles)
+    const uint32_t workers_max = KMO_WORKERS_OVERRIDE;
+#else
+    const uint32_t workers_max = cus > 0 ? (uint32_t)cus * KMO_WG_PER_CU : 3u;  // (the host build of the kernels reports 0 CUs: a few workers, several tiles each)
+#endif
+    // a run = a row of tiles of one image when that still gives every CU several runs; single tiles otherwise
+    const uint64_t rows = (uint64_t)a.tiles_y * (uint64_t)B * ngrp;
+    a.run_len = (rows >= 4ull * workers_max) ? a.tiles_x : 1u;
+    a.nruns = (uint32_t)(ntiles / a.run_len);
+    a.nworkers = (uint32_t)((uint64_t)a.nruns < (uint64_t)workers_max ? a.nruns : workers_max);
+    {   // the general launch: about 4 workgroups per CU when every tile needs it, 64 tiles per workgroup at most (one ballot)
+        const uint64_t per = (ntiles + 4ull * workers_max - 1) / (4ull * workers_max);
+        a.general_tiles = (uint32_t)(per < 1 ? 1 : (per > 64 ? 64 : per));
+    }
+    switch (coord_mode) {
+        case KM_COORD_PERSPECTIVE: return kmo_launch<T, KM_COORD_PERSPECTIVE>(a, s);
+        case KM_COORD_AFFINE: return kmo_launch<T, KM_COORD_AFFINE>(a, s);
+        default: return kmo_launch<T, KM_COORD_HOMOGRAPHY>(a, s);
+    }
 }
 
 template <typename T>
@@ -1038,46 +1075,34 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     km_geom_init(g, B, C, H, W, h, w, B_M, coord_mode, norm_coords, KM_INTERP_BILINEAR, pad, align);
     a.tiles_x = (uint32_t)((W + KMT_TW - 1) / KMT_TW);
     a.tiles_y = (uint32_t)((H + KMO_TH - 1) / KMO_TH);
-    const uint64_t ntiles = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B;
-    KM_REQUIRE(ntiles < (1ull << 26), "km_warp2d_bwd: grid too large");
-    if (ntiles == 0) return (int)hipMemsetAsync(gmat, 0, (size_t)B_M * 9 * sizeof(double), s);  // (nothing to add: the accumulators are still this path's to zero)
-    a.ntiles = (uint32_t)ntiles;
-    const int cus = km_device_cus();
-#ifdef KMO_WORKERS_OVERRIDE  // (variant libraries only: fewer persistent workgroups than CUs - what the clock does when part of the chip idles)
-    const uint32_t workers_max = KMO_WORKERS_OVERRIDE;
-#else
-    const uint32_t workers_max = cus > 0 ? (uint32_t)cus * KMO_WG_PER_CU : 3u;  // (the host build of the kernels reports 0 CUs: a few workers, several tiles each)
-#endif
-    // a run = a row of tiles of one image when that still gives every CU several runs; single tiles otherwise
-    const uint64_t rows = (uint64_t)a.tiles_y * (uint64_t)B;
-    a.run_len = (rows >= 4ull * workers_max) ? a.tiles_x : 1u;
-    a.nruns = (uint32_t)(ntiles / a.run_len);
-    a.nworkers = (uint32_t)((uint64_t)a.nruns < (uint64_t)workers_max ? a.nruns : workers_max);
+    // C = 3 a3 + r1: the groups of three through the RGB instantiation, the rest one channel at a time through the grey one
+    const uint32_t a3 = (uint32_t)C / 3u, r1 = (uint32_t)C % 3u;
+    const uint64_t per_image = (uint64_t)a.tiles_x * a.tiles_y;
+    KM_REQUIRE(per_image * (uint64_t)B * (a3 > r1 ? a3 : r1) < (1ull << 26) && (uint64_t)B * (uint64_t)C < (1ull << 31), "km_warp2d_bwd: grid too large");
+    if (per_image * (uint64_t)B == 0 || C == 0) return (int)hipMemsetAsync(gmat, 0, (size_t)B_M * 9 * sizeof(double), s);  // (nothing to add: the accumulators are still this path's to zero)
     a.reverse = km_traversal_next(s);
     a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(float));
-    {   // the general launch: about 4 workgroups per CU when every tile needs it, 64 tiles per workgroup at most (one ballot)
-        const uint64_t per = (ntiles + 4ull * workers_max - 1) / (4ull * workers_max);
-        a.general_tiles = (uint32_t)(per < 1 ? 1 : (per > 64 ? 64 : per));
-    }
-    switch (coord_mode) {
-        case KM_COORD_PERSPECTIVE: return kmo_launch<T, KM_COORD_PERSPECTIVE>(a, s);
-        case KM_COORD_AFFINE: return kmo_launch<T, KM_COORD_AFFINE>(a, s);
-        default: return kmo_launch<T, KM_COORD_HOMOGRAPHY>(a, s);
-    }
+    int rc = 0;
+    if (a3) rc = kmo_run_groups(a, B, 0u, a3, 3u, true, coord_mode, s);
+    if (rc == 0 && r1) rc = kmo_run_groups(a, B, 3u * a3, r1, 1u, a3 == 0, coord_mode, s);
+    return rc;
 }
 
-// 1 if the one-read kernel computes both gradients for these modes (bilinear, zeros / fill padding, fp32 compute, grey or RGB)
+// 1 if the one-read kernel computes both gradients for these modes (bilinear, zeros / fill padding, fp32 compute; any channel count - fill
+// values are per channel of an RGB / grey image, so `fill` keeps C in {1, 3})
 int km_warp_bwd_fused_supported(int interp, int pad, int dtype, int C, int H, int W, int h, int w) {
     if (!km_config().warp_bwd_fused) return 0;
     if (!(interp == KM_INTERP_BILINEAR && (pad == KM_PAD_ZEROS || pad == KM_PAD_FILL) && dtype != KM_F64)) return 0;
-    if (!(C == 1 || C == 3)) return 0;
+    if (C < 1 || (pad == KM_PAD_FILL && !(C == 1 || C == 3))) return 0;
     // 32-bit byte offsets inside a plane
     return ((uint64_t)H * W * 4 < (1ull << 32) && (uint64_t)h * w * 4 < (1ull << 32)) ? 1 : 0;
 }
 
-// bytes of workspace the one-read backward needs for these sizes (one KMO_BOX_INTS * 4 = 80-byte record per 64 x 64 tile of the source)
-size_t km_warp_bwd_fused_workspace(int B, int H, int W) {
-    const uint64_t ntiles = (uint64_t)((W + KMT_TW - 1) / KMT_TW) * (uint64_t)((H + KMO_TH - 1) / KMO_TH) * (uint64_t)B;
+// bytes of workspace the one-read backward needs for these sizes: one KMO_BOX_INTS * 4 = 80-byte record per 64 x 64 tile of the source and
+// channel group of the larger of its (at most two) launch sequences
+size_t km_warp_bwd_fused_workspace(int B, int C, int H, int W) {
+    const uint64_t a3 = (uint64_t)C / 3u, r1 = (uint64_t)C % 3u;
+    const uint64_t ntiles = (uint64_t)((W + KMT_TW - 1) / KMT_TW) * (uint64_t)((H + KMO_TH - 1) / KMO_TH) * (uint64_t)B * (a3 > r1 ? a3 : r1);
     return (size_t)(ntiles * KMO_BOX_INTS * sizeof(int));
 }
 
