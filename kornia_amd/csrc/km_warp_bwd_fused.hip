@@ -50,6 +50,7 @@
 #ifdef KMO_PROFILE
 #define KMO_PROF_PHASES 8
 __device__ unsigned long long kmo_prof_out[512 * 16 * KMO_PROF_PHASES];
+__device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end on the constant-rate counter (s_memrealtime, 100 MHz), XCC id, -
 #define KMO_T(k)                                                              \
     {                                                                         \
         KM_SCHED_FENCE();                                                     \
@@ -727,6 +728,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 #ifdef KMO_PROFILE
     unsigned long long prof[KMO_PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // A work item is (tile, pass): a box larger than the registers of the workgroup (KMO_CAP pixels: rotations beyond ~10 degrees,
     // magnification) is walked in several passes, the next pass requested slot by slot during the current one like a next tile.
@@ -843,6 +845,13 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
     if (lane == 0 && blockIdx.x < 512u) {
 #pragma unroll
         for (int k = 0; k < KMO_PROF_PHASES; ++k) kmo_prof_out[((size_t)blockIdx.x * 16 + (wave & 15)) * KMO_PROF_PHASES + k] = prof[k];
+        if (wave == 0) {
+            unsigned xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            kmo_prof_rt[blockIdx.x * 4 + 0] = rt0;
+            kmo_prof_rt[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            kmo_prof_rt[blockIdx.x * 4 + 2] = xcc;
+        }
     }
 #endif
     // ---- epilogue: the last image's partials ----
@@ -1121,6 +1130,9 @@ int km_warp_bwd_fused_run(const void* gout, const void* src, const void* mat, vo
 
 #ifdef KMO_PROFILE
 // (variant libraries only) the per-wave phase table of the last persistent launch: [worker][wave][phase] shader cycles
+extern "C" int km_debug_fused_profile_rt(unsigned long long* host_out, int n_entries) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(kmo_prof_rt), (size_t)n_entries * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
 extern "C" int km_debug_fused_profile(unsigned long long* host_out, int n_entries) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(kmo_prof_out), (size_t)n_entries * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }

@@ -53,3 +53,16 @@ print(f"  per worker (max over its waves), cycles: min {wt.min():.0f}  median {n
 print("  slowest workers: " + ", ".join(f"#{int(i)}: {wt[i]:.0f}" for i in order[-6:][::-1]) + "   fastest: " + ", ".join(f"#{int(i)}: {wt[i]:.0f}" for i in order[:4]))
 xcd = np.array([wt[i::8].mean() for i in range(8)])
 print("  mean per XCD (worker index mod 8): " + " ".join(f"{v:.0f}" for v in xcd))
+# wall time per worker on the constant-rate counter (100 MHz): equal CYCLES on a slower-clocked XCD are a longer TIME
+rt = (ctypes.c_ulonglong * (512 * 4))()
+raw.km_debug_fused_profile_rt.argtypes = [ctypes.c_void_p, ctypes.c_int]
+if raw.km_debug_fused_profile_rt(rt, 512 * 4) == 0:
+    r = np.frombuffer(rt, dtype=np.uint64).reshape(512, 4)[:workers].astype(np.float64)
+    dur = (r[:, 1] - r[:, 0]) / 100.0  # microseconds
+    start = (r[:, 0] - r[:, 0].min()) / 100.0
+    end = (r[:, 1] - r[:, 0].min()) / 100.0
+    xcc = (r[:, 2].astype(np.int64) & 0xf)
+    print(f"  wall time per worker (us): min {dur.min():.1f}  median {np.median(dur):.1f}  max {dur.max():.1f}   last start {start.max():.1f}  first end {end.min():.1f}  last end {end.max():.1f}")
+    for xid in sorted(set(xcc.tolist())):
+        sel = xcc == xid
+        print(f"    XCC {xid}: {int(sel.sum()):3d} workers  duration mean {dur[sel].mean():7.1f} us  min {dur[sel].min():7.1f}  max {dur[sel].max():7.1f}   effective clock {wt[sel].mean() / dur[sel].mean() / 1e3:.3f} GHz")
