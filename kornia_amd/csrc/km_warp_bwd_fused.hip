@@ -96,7 +96,8 @@ struct KmWarpFusedArgs {
     KmWarpGeom<float> g;
     uint32_t tiles_x, tiles_y, ntiles, nruns, run_len;  // a run = run_len horizontally adjacent tiles (run_len == tiles_x or 1)
     uint32_t nworkers;   // == gridDim.x of the persistent launch
-    uint32_t general_tiles;  // tiles a workgroup of the general launch looks at (1 .. 64)
+    uint32_t general_tiles;  // tiles per group of the general launch (1 .. 64: one ballot)
+    uint32_t general_grid;   // workgroups of the general launch (each walks its share of the groups)
     uint32_t reverse;    // the launch walks the batch backwards (km_traversal_next)
     uint32_t stream_out; // streaming stores of the tile flush (km_stream_stores)
     // Channel groups.  A launch covers channels c0 .. c0 + ngrp * cc - 1 of every image in groups of cc (= the kernel's CC: 3 or 1): an "image"
@@ -898,25 +899,29 @@ __device__ __forceinline__ bool kmo_scan_maybe_unvisited(float x, float y, float
     return !((x > -1.f + e) && (x < W - e) && (y > -1.f + e) && (y < H - e));
 }
 #define KMO_SCAN_BLK 16
+// One workgroup classifies KMO_NT blocks at a time (thread = block: its four corners), compacts the candidates into an LDS list and deals
+// them to its 16 waves - the candidates are the blocks along the image's borders, i.e. whole rows of blocks: left with the wave that
+// classified them, a few waves walked 30 - 60 blocks each while the rest had none (180 us for the launch; profiles/r04/bwd_general_launch_grid.txt).
 template <typename T, int CM, int ALIGN, int CC>
-__device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a) {
+__device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, uint32_t* s_list, uint32_t* s_count) {
     const KmWarpGeom<float>& g = a.g;
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const KmoScanMap k = kmo_scan_map<CM, ALIGN>(g);
     const uint32_t bx = (uint32_t)(g.w + KMO_SCAN_BLK - 1) / KMO_SCAN_BLK, by = (uint32_t)(g.h + KMO_SCAN_BLK - 1) / KMO_SCAN_BLK;
-    const uint64_t nblk = (uint64_t)bx * by * (uint64_t)g.B;
-    const uint64_t waves = (uint64_t)gridDim.x * KMO_NW, wave = (uint64_t)blockIdx.x * KMO_NW + (threadIdx.x >> 6);
+    const uint32_t per_image = bx * by;
+    const uint64_t nblk = (uint64_t)per_image * (uint64_t)g.B;
     const float Wf = (float)g.W, Hf = (float)g.H;
     const size_t dst_plane = (size_t)g.h * g.w;
-    for (uint64_t base = wave * 64u; base < nblk; base += waves * 64u) {
-        // lane = block: its four corners
-        const uint64_t e = base + (uint64_t)lane;
+    for (uint64_t base = (uint64_t)blockIdx.x * KMO_NT; base < nblk; base += (uint64_t)gridDim.x * KMO_NT) {
+        if (tid == 0) *s_count = 0u;
+        __syncthreads();
+        // ---- thread = block: its four corners ----
+        const uint64_t e = base + (uint64_t)tid;
         bool todo = false;
-        uint32_t b = 0, ty = 0, tx = 0;
         if (e < nblk) {
-            b = (uint32_t)(e / ((uint64_t)bx * by));
-            const uint32_t r = (uint32_t)(e - (uint64_t)b * bx * by);
-            ty = r / bx; tx = r - ty * bx;
+            const uint32_t b = (uint32_t)(e / per_image);
+            const uint32_t r = (uint32_t)(e - (uint64_t)b * per_image);
+            const uint32_t ty = r / bx, tx = r - ty * bx;
             float m[9];
             const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0u : b) * 9;
 #pragma unroll
@@ -934,32 +939,62 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a) 
             // the corners speak for the block only where the denominator keeps its sign well away from zero
             todo = todo || !((dmin > 0.f && dmin > 1e-3f * dmax) || (dmax < 0.f && dmax < 1e-3f * dmin));
         }
-        unsigned long long pend = __ballot(todo);
-        while (pend) {  // (wave-uniform) one 16 x 16 block at a time: lane = column + 16 * (row mod 4), four rows of rows
-            const int src_lane = __builtin_ctzll(pend);
-            pend &= pend - 1ull;
-            const uint32_t bb = (uint32_t)__shfl((int)b, src_lane, 64), tty = (uint32_t)__shfl((int)ty, src_lane, 64), ttx = (uint32_t)__shfl((int)tx, src_lane, 64);
-            float m[9];
-            const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0u : bb) * 9;
+        // ---- compaction: one LDS atomic per wave ----
+        const unsigned long long vote = __ballot(todo);
+        uint32_t wbase = 0u;
+        if (lane == 0 && vote) wbase = atomicAdd(s_count, (uint32_t)__popcll(vote));
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (todo) s_list[wbase + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull))] = (uint32_t)tid;
+        __syncthreads();
+        const uint32_t n = *s_count;
+        // ---- wave w takes candidates w, w + 16, ... TWO at a time (their matrix loads, then their grad_out loads, fly together):
+        //      64 lanes = 16 columns x 4 rows of a block, four steps ----
+        for (uint32_t it = (uint32_t)wave; it < n; it += 2 * KMO_NW) {
+            constexpr int NB = 2, NS = KMO_SCAN_BLK / 4;
+            uint32_t bb[NB], tty[NB], ttx[NB];
+            float m[NB][9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) m[q] = mp[q];
-            const int j = (int)(ttx * KMO_SCAN_BLK) + (lane & 15);
-            bool bad = false;
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t iu = min(it + (uint32_t)u * KMO_NW, n - 1u);  // (the last pair of an odd list repeats its candidate: a max is idempotent)
+                const uint64_t eb = base + (uint64_t)s_list[iu];
+                bb[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(eb / per_image));
+                const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(eb - (uint64_t)bb[u] * per_image));
+                tty[u] = rb / bx; ttx[u] = rb - tty[u] * bx;
+                const float* mp = a.mat + (size_t)(g.B_M == 1 ? 0u : bb[u]) * 9;  // (wave-uniform address)
 #pragma unroll
-            for (int rr = 0; rr < KMO_SCAN_BLK / 4; ++rr) {
-                const int i = (int)(tty * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
-                if (j < g.w && i < g.h) {
+                for (int q = 0; q < 9; ++q) m[u][q] = mp[q];
+            }
+            bool need[NB][NS];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int j = (int)(ttx[u] * KMO_SCAN_BLK) + (lane & 15);
+#pragma unroll
+                for (int rr = 0; rr < NS; ++rr) {
+                    const int i = (int)(tty[u] * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
                     float x, y, d;
-                    kmo_scan_pos<CM>(k, m, (float)j, (float)i, x, y, d);
-                    if (kmo_scan_maybe_unvisited(x, y, Wf, Hf)) {
-                        const T* gp = a.gout + (size_t)bb * g.C * dst_plane + (size_t)i * g.w + (size_t)j;
-                        for (int c = 0; c < g.C; ++c) bad = bad || ((__float_as_uint((float)km_ld(gp + (size_t)c * dst_plane)) & 0x7f800000u) == 0x7f800000u);
+                    kmo_scan_pos<CM>(k, m[u], (float)j, (float)i, x, y, d);
+                    need[u][rr] = (j < g.w) && (i < g.h) && kmo_scan_maybe_unvisited(x, y, Wf, Hf);
+                }
+            }
+            uint32_t worst[NB] = {0u, 0u};  // largest exponent field seen
+            for (int c = 0; c < g.C; ++c) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const T* gp = a.gout + ((size_t)bb[u] * g.C + (size_t)c) * dst_plane + (size_t)((int)(ttx[u] * KMO_SCAN_BLK) + (lane & 15));
+#pragma unroll
+                    for (int rr = 0; rr < NS; ++rr) {
+                        const int i = (int)(tty[u] * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
+                        const uint32_t bits = __float_as_uint((float)km_ld(need[u][rr] ? gp + (size_t)i * g.w : a.gout)) & 0x7f800000u;
+                        worst[u] = max(worst[u], need[u][rr] ? bits : 0u);
                     }
                 }
             }
-            if (__ballot(bad) != 0ull && lane < (CM == KM_COORD_AFFINE ? 6 : 9))
-                km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0u : bb) * 9 + lane, (double)__int_as_float(0x7fc00000));
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (__ballot(worst[u] == 0x7f800000u) != 0ull && lane < (CM == KM_COORD_AFFINE ? 6 : 9))
+                    km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0u : bb[u]) * 9 + lane, (double)__int_as_float(0x7fc00000));
         }
+        __syncthreads();  // (the list is rewritten by the next chunk)
     }
 }
 
@@ -978,8 +1013,17 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
     float fillv[CC];
 #pragma unroll
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
-    const uint32_t t0 = blockIdx.x * a.general_tiles;
-    if (a.first) kmo_scan_unvisited<T, CM, ALIGN, CC>(a);  // (every workgroup of the launch takes its share first: most have nothing else to do)
+    // (every workgroup of the launch takes its share first: most have nothing else to do; the list borrows the coordinate tables' LDS)
+    static_assert((KMT_BAND_W + KMT_TAB) * 16 >= KMO_NT * 4, "the candidate list fits the tables");
+    if (a.first) kmo_scan_unvisited<T, CM, ALIGN, CC>(a, (uint32_t*)l.s_u4, l.s_red);
+    // A workgroup of this launch holds a CU's LDS: the grid is one workgroup per persistent worker, each walking its share of the tile
+    // groups (a grid of one workgroup per group - 1024 at config 2, four rounds of dispatch with 114 KB of LDS each - cost 45 us per
+    // round on some boxes, whatever the workgroups then did: profiles/r04/bwd_general_launch_grid.txt)
+    bool zeroed = false;
+    const uint32_t ngroups = (a.ntiles + a.general_tiles - 1u) / a.general_tiles;
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const uint32_t t0 = grp * a.general_tiles;
+    __syncthreads();  // (s_todo of the previous group has been read by everyone)
     if (wave == 0) {
         const uint32_t t = t0 + (uint32_t)lane;
         int fl = KMO_F_REGULAR;
@@ -989,8 +1033,11 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
     }
     __syncthreads();
     unsigned long long todo = s_todo;
-    if (todo == 0ull) return;  // (block-uniform)
-    for (int e = tid; e < CC * KMO_PLANE / 4; e += KMO_NT) ((int4*)l.s_acc)[e] = make_int4(0, 0, 0, 0);
+    if (todo == 0ull) continue;  // (block-uniform)
+    if (!zeroed) {
+        for (int e = tid; e < CC * KMO_PLANE / 4; e += KMO_NT) ((int4*)l.s_acc)[e] = make_int4(0, 0, 0, 0);
+        zeroed = true;  // (every flush leaves the accumulators zeroed)
+    }
     for (int k = 0; k < 64; ++k) {
         if (!((todo >> k) & 1ull)) continue;
         const int t = (int)t0 + k;
@@ -1019,6 +1066,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
         __syncthreads();
         kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)d.bm * 9, tid);
     }
+    }
 }
 
 template <typename T, int CM, int ALIGN, int CC>
@@ -1037,7 +1085,17 @@ static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((km_warp_bwd_boxes_kernel<T, CM>), dim3((a.ntiles + 255u) / 256u), dim3(256), 0, s, a);
     hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
-    hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC>), dim3((a.ntiles + a.general_tiles - 1u) / a.general_tiles), dim3(KMO_NT), (size_t)lds, s, a);
+#ifndef KMO_NO_GENERAL  // (variant libraries only: what the launch itself costs)
+    {
+        const uint32_t ngroups = (a.ntiles + a.general_tiles - 1u) / a.general_tiles;
+#ifdef KMO_GENERAL_FULL_GRID
+        const uint32_t ggrid = ngroups;
+#else
+        const uint32_t ggrid = ngroups < a.general_grid ? ngroups : a.general_grid;
+#endif
+        hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC>), dim3(ggrid), dim3(KMO_NT), (size_t)lds, s, a);
+    }
+#endif
     return km_check_launch("km_warp2d_bwd(fused)");
 }
 template <typename T, int CM>
@@ -1063,9 +1121,11 @@ static int kmo_run_groups(KmWarpFusedArgs<T>& a, int B, uint32_t c0, uint32_t ng
     a.run_len = (rows >= 4ull * workers_max) ? a.tiles_x : 1u;
     a.nruns = (uint32_t)(ntiles / a.run_len);
     a.nworkers = (uint32_t)((uint64_t)a.nruns < (uint64_t)workers_max ? a.nruns : workers_max);
-    {   // the general launch: about 4 workgroups per CU when every tile needs it, 64 tiles per workgroup at most (one ballot)
-        const uint64_t per = (ntiles + 4ull * workers_max - 1) / (4ull * workers_max);
+    {   // the general launch: groups of up to 64 tiles (one ballot), one workgroup per persistent worker walking its share of them
+        // (one group per workgroup when the persistent workers' count of them covers the tiles: one ballot, one pair of barriers)
+        const uint64_t per = (ntiles + (uint64_t)workers_max - 1) / (uint64_t)workers_max;
         a.general_tiles = (uint32_t)(per < 1 ? 1 : (per > 64 ? 64 : per));
+        a.general_grid = workers_max;
     }
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmo_launch<T, KM_COORD_PERSPECTIVE>(a, s);

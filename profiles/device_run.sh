@@ -7,6 +7,7 @@
 #   benchlite:N    the same without cpu baseline / other configs (A/B of libraries: KORNIA_AMD_LIB is honoured)
 #   prof           rocprofv3 --kernel-trace --stats of the bench command, then FETCH_SIZE / WRITE_SIZE in separate --pmc passes
 #   py:<script>    python <script> (a profiles/time_*.py), output appended to the run log
+#   rocprof:<script>   the same under rocprofv3 --kernel-trace --stats, per-kernel table appended to the run log
 #   ab:<script>:<lib1>,<lib2>,...   python <script> once per library under kornia_amd/lib/var (name without lib_/.so; "default" = the shipped one)
 # Everything goes to gpurun_out/<round-tag>/<run-name>.txt (+ JSON lines in <run-name>_bench.jsonl, profiler output in <run-name>_prof/).
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -53,6 +54,17 @@ for stage in "$@"; do
       ;;
     py:*)
       run python ${stage#py:}
+      ;;
+    rocprof:*)   # rocprofv3 --kernel-trace --stats of python <script>; the km_* rows of the stats table go to the run log
+      script=${stage#rocprof:}; P=$D/${RUN}_rocprof_$(basename $script .py); rm -rf $P; mkdir -p $P
+      ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o f -- python $R/$script > $P/out.log 2>&1; echo "rocprofv3 rc $?" >> $O )
+      grep "^lib=" $P/out.log >> $O
+      find $P -name "*kernel_stats.csv" | head -1 | xargs -r python3 -c "
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    print(r['Name'][:64].ljust(64), r['Calls'].rjust(6), ('%.1f us' % (float(r['AverageNs']) / 1e3)).rjust(12), ('min %.1f' % (float(r['MinNs']) / 1e3)).rjust(12), ('max %.1f' % (float(r['MaxNs']) / 1e3)).rjust(12))
+" >> $O 2>&1
+      find $P -name "*_kernel_trace.csv" -delete; find $P -name "*agent_info.csv" -delete
       ;;
     ab:*)
       rest=${stage#ab:}; script=${rest%%:*}; libs=${rest#*:}

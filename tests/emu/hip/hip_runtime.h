@@ -200,6 +200,7 @@ inline int emu_readfirstlane(int v) {
 }
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred != 0); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __all(int pred) { return emu::wave_ballot(pred == 0) == 0ull; }  // no live lane with a false predicate
 inline int __any(int pred) { return emu::wave_ballot(pred != 0) != 0ull; }
 inline int __syncthreads_or(int pred) { return emu::syncthreads_or(pred); }
