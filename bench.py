@@ -394,6 +394,45 @@ def other_configs(dev):
         del P
     except Exception as e:
         out["error_cfg45"] = f"{type(e).__name__}: {e}"
+    try:  # the fused warp + blur op (csrc/km_warp_blur.hip), config 2's shapes: a SEPARATE public op, never part of `value`
+        B, S = 256, 512
+        g = torch.Generator().manual_seed(5)
+        gg = torch.Generator(device=dev).manual_seed(5)
+        fsets = [(torch.rand(B, 3, S, S, device=dev, generator=gg), flagship_homographies(B, S, S, g).to(dev), torch.rand(B, 3, S, S, device=dev, generator=gg)) for _ in range(2)]
+        T = K.geometry.transform
+        kk = [0]
+
+        def fstep(fn):
+            def f():
+                kk[0] += 1
+                xs, Ms, gos = fsets[kk[0] % 2]
+                xs, Ms = xs.detach().requires_grad_(), Ms.detach().requires_grad_()
+                fn(xs, Ms).backward(gos)
+            return f
+
+        def ffwd(fn):
+            def f():
+                kk[0] += 1
+                xs, Ms, gos = fsets[kk[0] % 2]
+                with torch.no_grad():
+                    fn(xs, Ms)
+            return f
+
+        fused = lambda a_, m_: T.warp_perspective_blur(a_, m_, (S, S), (5, 5), (1.5, 1.5))
+        two = lambda a_, m_: K.gaussian_blur2d(K.warp_perspective(a_, m_, (S, S)), (5, 5), (1.5, 1.5))
+        ms_f, ms_t = t(fstep(fused)), t(fstep(two))
+        n_el = B * 3 * S * S
+        out["fused_warp_blur_256x3x512x512"] = {
+            "op": "kornia_amd.geometry.transform.warp_perspective_blur: one forward launch (the warped image never reaches HBM), backward = blur adjoint + one-read warp backward",
+            "fwd+bwd_ms": ms_f, "Mpix_s": round(B * S * S / ms_f / 1e3, 1), "two_ops_same_loop_ms": ms_t,
+            "forward_only_ms": t(ffwd(fused)), "forward_only_two_ops_ms": t(ffwd(two)),
+            "alg_bytes": 7 * 4 * n_el, "accounting": "fused forward 2e + blur adjoint 2e + warp backward 3e = 7e (a fused adjoint would make it 5e; the two ops: 9e)",
+            "GBps": round(7 * 4 * n_el / ms_f / 1e6, 1), "frac_of_hbm_peak": round(7 * 4 * n_el / ms_f / 1e6 / HBM_PEAK_GBS, 4),
+            "bit_identical_to_two_ops": bool(torch.equal(fused(fsets[0][0][:4], fsets[0][1][:4]), two(fsets[0][0][:4], fsets[0][1][:4]))),
+        }
+        del fsets
+    except Exception as e:  # informational only
+        out["error_fused_warp_blur"] = f"{type(e).__name__}: {e}"
     try:  # the pyramid / registration stack and the remaining callers
         T = K.geometry.transform
         with torch.no_grad():

@@ -99,6 +99,17 @@ int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* g
 /* bytes of workspace the one-read backward uses for these sizes and modes; 0: it does not apply (pass no workspace) */
 long long km_warp2d_bwd_workspace_bytes(int B, int C, int H, int W, int h, int w, int interp, int pad, int dtype);
 
+/* ---- warp + separable blur, fused (forward) ------------------------------------------------------
+ * y = filter2d_separable(warp(src, mat), kx, ky, border): kornia/geometry/transform/imgwarp.py:143-174 / :246-290 / :1539-1546 followed by
+ * kornia/filters/filter.py:155-207 (GaussianBlur2d: kornia/filters/gaussian.py:32-120) in ONE launch that never writes the warped image
+ * (5e instead of 9e bytes per element over forward + backward).  Bit-identical to the two calls.  Bilinear + zeros, C in {1, 3},
+ * square odd K in {3, 5, 7}, 'same' output; km_warp2d_blur_supported() tells (1 / 0), anything else: the two calls.
+ *   src (B,C,H,W) dtype   mat (B_M,9) float32 as for km_warp2d_fwd   kx, ky (Bk,K) float32, Bk in {1,B}   dst (B,C,h,w) dtype
+ *   border: KM_BORDER_* of the blur (F.pad's modes) */
+int km_warp2d_blur_supported(int C, int H, int W, int h, int w, int interp, int pad, int K, int border, int dtype);
+int km_warp2d_blur_fwd(const void* src, const void* mat, const void* kx, const void* ky, void* dst, int B, int C, int H, int W, int h,
+                       int w, int B_M, int Bk, int coord_mode, int norm_coords, int align_corners, int K, int border, int dtype, void* stream);
+
 /* 1 if km_warp2d_bwd with these modes accumulates with atomics and needs gsrc zeroed by the caller,
  * 0 if it overwrites gsrc completely (tile-owner path: bilinear, zeros/fill padding, dtype != f64). */
 int km_warp2d_bwd_needs_zero_init(int interp, int pad, int dtype);

@@ -62,6 +62,8 @@ _PROTOTYPES = {
     "km_select_samples_fwd": [_P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P],
     "km_canny_nms_fwd": [_P, _P, _P, _I, _I, _I, c_double, c_double, c_double, _P],
     "km_canny_hysteresis_sweep": [_P, _P, _P, _I, _I, _I, _P],
+    "km_warp2d_blur_fwd": [_P, _P, _P, _P, _P] + [_I] * 14 + [_P],
+    "km_warp2d_blur_supported": [_I] * 10,
     "km_transform_points_fwd": [_P, _P, _P] + [_I] * 4 + [_I, _P],
     "km_transform_points_bwd": [_P, _P, _P, _P, _P] + [_I] * 4 + [_I, _P],
 }

@@ -13,8 +13,11 @@ from .homography_warper import HomographyWarper
 from .pyramid import PyrDown, PyrUp, ScalePyramid, build_laplacian_pyramid, build_pyramid, pyrdown, pyrup, resize_bilinear
 from .image_registrator import BaseModel, Homography, ImageRegistrator, Similarity, masked_warp_loss
 from .imgwarp import grid_sample, homography_warp, remap, warp_affine, warp_grid, warp_perspective
+from .warp_blur import warp_affine_blur, warp_perspective_blur
 
 __all__ = [
+    "warp_affine_blur",
+    "warp_perspective_blur",
     "BaseModel",
     "Homography",
     "ImageRegistrator",

@@ -88,44 +88,49 @@ class _Warp2dFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout: torch.Tensor):
         x, Mc, m, fill = ctx.saved_tensors
-        cfg: _WarpCfg = ctx.cfg
-        lib = N.lib()
-        dev = x.device
-        cdt = Mc.dtype
-        B, C, H, W = x.shape
-        h, w = cfg.dsize
-        B_M = Mc.shape[0]
-        need_src, need_mat = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g = gout.detach().to(x.dtype).contiguous()
-        stream = N.stream_ptr(dev)
-        gsrc = None
-        if need_src:
-            zero = lib.km_warp2d_bwd_needs_zero_init(cfg.interp, cfg.pad, N.dtype_code(x.dtype))
-            gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
-        gmat = None
-        # both gradients wanted: a workspace lets the library take them from one read of grad_out (include/kornia_amd.h)
-        ws, ws_bytes = None, 0
-        if need_src and need_mat:
-            ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, cfg.interp, cfg.pad, N.dtype_code(x.dtype)))
-            if ws_bytes > 0:
-                ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        # (on the one-read path the first launch zeroes the fp64 accumulators itself: one fill launch less per step)
-        gm = (torch.empty if ws is not None else torch.zeros)(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
-        with N.device_guard(dev):
-            N.check(lib.km_warp2d_bwd_ws(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
-                                         B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),
-                                         N.dtype_code(x.dtype), N.ptr(ws), ws_bytes, stream), "km_warp2d_bwd_ws")
-            if need_mat:
-                if cfg.coord_mode == COORD_HOMOGRAPHY:
-                    gmat = gm.view(B_M, 3, 3).to(ctx.mat_dtype)
-                else:
-                    gM = torch.empty_like(Mc)
-                    N.check(lib.km_homography_chain_bwd(Mc.data_ptr(), Mc.shape[1], gm.data_ptr(), gM.data_ptr(), B_M, H,
-                                                        W, h, w, N.dtype_code(cdt), stream), "km_homography_chain_bwd")
-                    gmat = gM.to(ctx.mat_dtype)
-        if gsrc is not None and gsrc.dtype != x.dtype:
-            gsrc = gsrc.to(x.dtype)
+        gsrc, gmat = _warp2d_backward(gout, x, Mc, m, fill, ctx.cfg, ctx.mat_dtype, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gsrc, gmat, None, None, None
+
+
+def _warp2d_backward(gout: torch.Tensor, x: torch.Tensor, Mc: torch.Tensor, m: torch.Tensor, fill, cfg: _WarpCfg, mat_dtype, need_src: bool, need_mat: bool):
+    """(grad wrt src, grad wrt the caller's matrix) of a 2-D warp: km_warp2d_bwd_ws (+ the chain adjoint).  Shared by ``_Warp2dFunction`` and
+    the fused warp + blur op (warp_blur.py)."""
+    lib = N.lib()
+    dev = x.device
+    cdt = Mc.dtype
+    B, C, H, W = x.shape
+    h, w = cfg.dsize
+    B_M = Mc.shape[0]
+    g = gout.detach().to(x.dtype).contiguous()
+    stream = N.stream_ptr(dev)
+    gsrc = None
+    if need_src:
+        zero = lib.km_warp2d_bwd_needs_zero_init(cfg.interp, cfg.pad, N.dtype_code(x.dtype))
+        gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
+    gmat = None
+    # both gradients wanted: a workspace lets the library take them from one read of grad_out (include/kornia_amd.h)
+    ws, ws_bytes = None, 0
+    if need_src and need_mat:
+        ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, cfg.interp, cfg.pad, N.dtype_code(x.dtype)))
+        if ws_bytes > 0:
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    # (on the one-read path the first launch zeroes the fp64 accumulators itself: one fill launch less per step)
+    gm = (torch.empty if ws is not None else torch.zeros)(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
+    with N.device_guard(dev):
+        N.check(lib.km_warp2d_bwd_ws(g.data_ptr(), x.data_ptr(), m.data_ptr(), N.ptr(gsrc), N.ptr(gm), B, C, H, W, h, w,
+                                     B_M, cfg.coord_mode, cfg.norm_coords, cfg.interp, cfg.pad, cfg.align, N.ptr(fill),
+                                     N.dtype_code(x.dtype), N.ptr(ws), ws_bytes, stream), "km_warp2d_bwd_ws")
+        if need_mat:
+            if cfg.coord_mode == COORD_HOMOGRAPHY:
+                gmat = gm.view(B_M, 3, 3).to(mat_dtype)
+            else:
+                gM = torch.empty_like(Mc)
+                N.check(lib.km_homography_chain_bwd(Mc.data_ptr(), Mc.shape[1], gm.data_ptr(), gM.data_ptr(), B_M, H,
+                                                    W, h, w, N.dtype_code(cdt), stream), "km_homography_chain_bwd")
+                gmat = gM.to(mat_dtype)
+    if gsrc is not None and gsrc.dtype != x.dtype:
+        gsrc = gsrc.to(x.dtype)
+    return gsrc, gmat
 
 
 class _GridSampleFunction(torch.autograd.Function):
