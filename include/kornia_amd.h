@@ -92,7 +92,9 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
  * of grad_out (a persistent tile-owner kernel that keeps its source tile in LDS: 3e bytes per element instead of 4e).  With a null /
  * short workspace it is km_warp2d_bwd.  Same results to the rounding of the fixed-point scale (both within the tolerances of tests/).
  * On that path (both gradients wanted, km_warp2d_bwd_workspace_bytes(...) > 0 and a workspace of at least that size) gmat need NOT be
- * zeroed by the caller: the first launch of the sequence does it (ABI version 2; zeroing it anyway is harmless). */
+ * zeroed by the caller: the first launch of the sequence does it (ABI version 2; zeroing it anyway is harmless).
+ * Border / reflection padding (fp32 storage): with such a workspace the same tile-owner kernel also serves gsrc alone (gmat == NULL) and
+ * writes every element of gsrc - no zeroing by the caller then, whatever km_warp2d_bwd_needs_zero_init() says about the path without one. */
 int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* gsrc, double* gmat, int B, int C, int H,
                      int W, int h, int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align_corners,
                      const void* fill, int dtype, void* workspace, long long workspace_bytes, void* stream);

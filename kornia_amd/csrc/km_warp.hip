@@ -1178,6 +1178,12 @@ int km_warp2d_bwd_ws(const void* gout, const void* src, const void* mat, void* g
     hipStream_t s = (hipStream_t)stream;
     // bilinear + zeros/fill: grad_src by the tile-owner scatter, the matrix gradient by its own forward-shaped kernel
     const bool gm_fast = gmat && km_warp_gm_supported(interp, pad, dtype, H, W, h, w);
+    // border / reflection padding: the tile-owner kernel of the one-read backward is the only scatter without global atomics for these
+    // modes, so it also serves a call that wants the image gradient alone (gmat == nullptr: nothing is committed)
+    if (gsrc && workspace && (pad == KM_PAD_BORDER || pad == KM_PAD_REFLECTION) && km_warp_bwd_tiled_dims_ok(h, w) && !km_config().warp_bwd_generic &&
+        km_warp_bwd_fused_supported(interp, pad, dtype, C, H, W, h, w) &&
+        (unsigned long long)workspace_bytes >= (unsigned long long)km_warp_bwd_fused_workspace(B, C, H, W) && ((uintptr_t)workspace & 15) == 0)
+        return km_warp_bwd_fused_run(gout, src, mat, gsrc, gmat, workspace, B, C, H, W, h, w, B_M, coord_mode, norm_coords, pad, align, fill, dtype, s);
     if (km_warp_bwd_tiled_supported(interp, pad, dtype, gsrc)) {
         if (km_warp_bwd_tiled_dims_ok(h, w)) {
             // both gradients wanted: one persistent launch that reads grad_out once (3e bytes per element instead of 4e)
@@ -1219,7 +1225,9 @@ int km_warp2d_bwd(const void* gout, const void* src, const void* mat, void* gsrc
 long long km_warp2d_bwd_workspace_bytes(int B, int C, int H, int W, int h, int w, int interp, int pad, int dtype) {
     int dummy = 0;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return 0;
-    if (!km_warp_bwd_tiled_supported(interp, pad, dtype, &dummy) || !km_warp_bwd_tiled_dims_ok(h, w)) return 0;
+    const bool in_image_pad = (pad == KM_PAD_BORDER || pad == KM_PAD_REFLECTION);  // (served by the one-read kernel alone)
+    if (km_config().warp_bwd_generic || !km_warp_bwd_tiled_dims_ok(h, w)) return 0;
+    if (!in_image_pad && !km_warp_bwd_tiled_supported(interp, pad, dtype, &dummy)) return 0;
     if (!km_warp_bwd_fused_supported(interp, pad, dtype, C, H, W, h, w)) return 0;
     return (long long)km_warp_bwd_fused_workspace(B, C, H, W);
 }

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFuse
     const KmWarpGeom<float>& g = a.g;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // the fp64 accumulators of the matrix gradient start at zero: this launch precedes every atomic on them (the caller need not zero)
-    if (a.first)
+    if (a.first && a.gmat)
         for (uint32_t k = t; k < (uint32_t)g.B_M * 9u; k += gridDim.x * 256u) a.gmat[k] = 0.0;
     if (t >= a.ntiles) return;
     int bg, tx, ty;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFuse
     for (int k = 0; k < 9; ++k) m[k] = mp[k];
     const int X0 = tx * KMT_TW, Y0 = ty * KMO_TH;
     const int X1 = min(X0 + KMT_TW, g.W), Y1 = min(Y0 + KMO_TH, g.H);
-    const KmtBox bx = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
+    const KmtBox bx = kmt_tile_box_padded<CM>(g, m, X0, X1, Y0, Y1);
     const int bw = bx.j1 - bx.j0 + 1, bh = bx.i1 - bx.i0 + 1;
     const bool empty = bw <= 0 || bh <= 0;
     // one band of the coordinate tables; larger boxes than the registers hold are walked in several passes (rotations, magnification)
@@ -390,7 +390,7 @@ __device__ __forceinline__ void kmo_request_slot(const T* const (&gout_c)[CC], i
 // The pixels a thread holds in registers (regular tiles): element e = s * KMO_NT + tid of the box walked as a linear list.  As soon
 // as slot s has been consumed its registers are REFILLED with slot s of the next tile (wn, gout_n): one register set holds both tiles,
 // and the next tile's requests are spread over the whole scatter instead of issued in one burst.
-template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED>
+template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED, int PADX>
 __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& d, const KmoConsts& k, float (&G)[KMO_SLOTS][CC], const float4* s_u4,
                                             const float4* s_v4, int* s_acc, const float* s_src, float scale, float (&A)[9], int w, KmoWalk& wn,
                                             const T* const (&gout_n)[CC], bool mine, const KmWarpFusedArgs<T>& a, const KmoTile& nxt,
@@ -410,8 +410,9 @@ __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& 
             const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
             const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
             KmtPix q;
-            kmt_pix_position<CM, ALIGN, FAST>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
-            kmo_pix<CM, CC, FAST, FIXED>(q, G[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+            float gdx, gdy;
+            kmt_pix_position_pad<CM, ALIGN, FAST, PADX>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, a.g.W, a.g.H, q, gdx, gdy);
+            kmo_pix<CM, CC, FAST, FIXED>(q, G[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
             kmt_advance(qi, qj, di, dj, bw);
         }
         kmo_request_slot<T, CC>(gout_n, w, s, wn, G[s]);
@@ -467,7 +468,7 @@ __device__ __forceinline__ void kmo_scale(float M, int hb, float& scale, float& 
 
 // The general path of one tile (launch 3): exact maximum over the box, bands of the box through the tables, one pixel per thread and
 // pass; IEEE float accumulation when fixed point is not accurate enough or the gradients are not finite.
-template <typename T, int CM, int ALIGN, int CC>
+template <typename T, int CM, int ALIGN, int CC, int PADX>
 __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, const float (&m)[9], const KmoTile& d, const KmoConsts& k, float4* s_u4, float4* s_v4,
                                                  int* s_acc, const float* s_src, uint32_t* s_red, float (&A)[9], float& inv_scale, bool& finite) {
     const KmWarpGeom<float>& g = a.g;
@@ -536,8 +537,9 @@ __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, co
                     for (int s = 0; s < GS; ++s) {
                         const float4 c0 = s_u4[pqj[s]], r0 = s_v4[pqi[s]];
                         KmtPix q;
-                        kmt_pix_position<CM, ALIGN, true>(m, kmt_half(c0), kmt_half(r0), true, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
-                        kmo_pix<CM, CC, true, true>(q, go4[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                        float gdx, gdy;
+                        kmt_pix_position_pad<CM, ALIGN, true, PADX>(m, kmt_half(c0), kmt_half(r0), true, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, g.W, g.H, q, gdx, gdy);
+                        kmo_pix<CM, CC, true, true>(q, go4[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
                     }
                 }
             }
@@ -549,14 +551,17 @@ __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, co
                 const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
                 KmtPix q;
                 if (!finite) {
-                    kmt_pix_position<CM, ALIGN, false>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
-                    kmo_pix<CM, CC, false, false>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                    float gdx, gdy;
+                    kmt_pix_position_pad<CM, ALIGN, false, PADX>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, g.W, g.H, q, gdx, gdy);
+                    kmo_pix<CM, CC, false, false>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
                 } else if (fast) {
-                    kmt_pix_position<CM, ALIGN, true>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
-                    kmo_pix<CM, CC, true, true>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                    float gdx, gdy;
+                    kmt_pix_position_pad<CM, ALIGN, true, PADX>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, g.W, g.H, q, gdx, gdy);
+                    kmo_pix<CM, CC, true, true>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
                 } else {
-                    kmt_pix_position<CM, ALIGN, false>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, q);
-                    kmo_pix<CM, CC, false, true>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, k.mx, k.my, A);
+                    float gdx, gdy;
+                    kmt_pix_position_pad<CM, ALIGN, false, PADX>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, g.W, g.H, q, gdx, gdy);
+                    kmo_pix<CM, CC, false, true>(q, go, s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
                 }
                 kmt_advance(qi, qj, di, dj, bwb);
             }
@@ -644,7 +649,7 @@ __device__ __forceinline__ KmoConsts kmo_consts(const KmWarpGeom<float>& g) {
 // the wave partials of a finished image in s_gm -> 9 fp64 atomics
 template <int CM>
 __device__ __forceinline__ void kmo_gm_commit(const double* s_gm, double* gmat_b, int tid) {
-    if (tid < 9) {
+    if (tid < 9 && gmat_b) {  // (gmat_b == nullptr: the caller wants the image gradient only)
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < KMO_NW; ++w) s += s_gm[w * 9 + tid];
@@ -676,7 +681,7 @@ __device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const Kmo
 }
 
 // ---- launch 2: the persistent loop over the regular tiles -------------------------------------------------------------------------
-template <typename T, int CM, int ALIGN, int CC>
+template <typename T, int CM, int ALIGN, int CC, int PADX>
 __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_bwd_fused_kernel(const KmWarpFusedArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const KmWarpGeom<float>& g = a.g;
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
             wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
         }
         // matrix-gradient partials of the image finished before this tile
-        if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)pending_b * 9, tid);
+        if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
         pending_b = -1;
 
         // ---- the fixed-point scale: from the exact maximum of the first pass; a later pass with a larger one rescales the accumulators ----
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         {
             float m[9];
             kmo_matrix(kmo_ring(l.s_box, q), m);
-            kmo_process<T, CM, ALIGN, CC, true, true>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, l.s_src, scale, A, g.w, wn, gout_n, mine, a, nxt, S);
+            kmo_process<T, CM, ALIGN, CC, true, true, PADX>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, l.s_src, scale, A, g.w, wn, gout_n, mine, a, nxt, S);
         }
         KMO_T(5)  // scatter
         KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 #endif
     // ---- epilogue: the last image's partials ----
     __syncthreads();
-    if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)pending_b * 9, tid);
+    if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
 }
 
 // ---- launch 3, first part: non-finite gradients at output pixels NO tile visits ---------------------------------------------------
@@ -1001,7 +1006,7 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
 // ---- launch 3: the tiles the persistent loop left (class "general", or a non-finite gradient met at run time) ---------------------
 // Workgroup w looks at the records of tiles general_tiles * w ... (lane = tile, one ballot; up to 64 of them, fewer for small problems so
 // that a batch of a few images whose every tile is marked still spreads over the chip) and walks the marked ones.
-template <typename T, int CM, int ALIGN, int CC>
+template <typename T, int CM, int ALIGN, int CC, int PADX>
 __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWarpFusedArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ unsigned long long s_todo;
@@ -1015,7 +1020,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
     // (every workgroup of the launch takes its share first: most have nothing else to do; the list borrows the coordinate tables' LDS)
     static_assert((KMT_BAND_W + KMT_TAB) * 16 >= KMO_NT * 4, "the candidate list fits the tables");
-    if (a.first) kmo_scan_unvisited<T, CM, ALIGN, CC>(a, (uint32_t*)l.s_u4, l.s_red);
+    if (a.first && PADX == 0 && a.gmat) kmo_scan_unvisited<T, CM, ALIGN, CC>(a, (uint32_t*)l.s_u4, l.s_red);  // (border / reflection: every output pixel is some tile's)
     // A workgroup of this launch holds a CU's LDS: the grid is one workgroup per persistent worker, each walking its share of the tile
     // groups (a grid of one workgroup per group - 1024 at config 2, four rounds of dispatch with 114 KB of LDS each - cost 45 us per
     // round on some boxes, whatever the workgroups then did: profiles/r04/bwd_general_launch_grid.txt)
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
         float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         float inv_scale = 1.f;
         bool finite = true;
-        kmo_general_tile<T, CM, ALIGN, CC>(a, m, d, kc, l.s_u4, l.s_v4, l.s_acc, l.s_src, l.s_red, A, inv_scale, finite);
+        kmo_general_tile<T, CM, ALIGN, CC, PADX>(a, m, d, kc, l.s_u4, l.s_v4, l.s_acc, l.s_src, l.s_red, A, inv_scale, finite);
         __syncthreads();
         kmo_flush<T, CC>(a, d, l.s_acc, finite, inv_scale);
 #pragma unroll
@@ -1064,12 +1069,12 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
             if (lane == 0) l.s_gm[wave * 9 + i] = s;
         }
         __syncthreads();
-        kmo_gm_commit<CM>(l.s_gm, a.gmat + (size_t)d.bm * 9, tid);
+        kmo_gm_commit<CM>(l.s_gm, a.gmat ? a.gmat + (size_t)d.bm * 9 : nullptr, tid);
     }
     }
 }
 
-template <typename T, int CM, int ALIGN, int CC>
+template <typename T, int CM, int ALIGN, int CC, int PADX>
 static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
     constexpr int lds = kmo_lds_bytes(CC);
     // (the attribute is kept per DEVICE by the runtime: one flag per device ordinal; idempotent - a race sets the same values twice)
@@ -1078,13 +1083,13 @@ static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
     (void)hipGetDevice(&dev);
     std::atomic<bool>* attr_set_p = (dev >= 0 && dev < 64) ? &attr_done[dev] : nullptr;
     if (!attr_set_p || !attr_set_p->load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)km_warp_bwd_general_kernel<T, CM, ALIGN, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)km_warp_bwd_fused_kernel<T, CM, ALIGN, CC, PADX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)km_warp_bwd_general_kernel<T, CM, ALIGN, CC, PADX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) { km_set_error("km_warp2d_bwd(fused): hipFuncSetAttribute(%d bytes of LDS) failed: %s", lds, hipGetErrorString(e)); return (int)e; }
         if (attr_set_p) attr_set_p->store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((km_warp_bwd_boxes_kernel<T, CM>), dim3((a.ntiles + 255u) / 256u), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
+    hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC, PADX>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
 #ifndef KMO_NO_GENERAL  // (variant libraries only: what the launch itself costs)
     {
         const uint32_t ngroups = (a.ntiles + a.general_tiles - 1u) / a.general_tiles;
@@ -1093,15 +1098,23 @@ static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
 #else
         const uint32_t ggrid = ngroups < a.general_grid ? ngroups : a.general_grid;
 #endif
-        hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC>), dim3(ggrid), dim3(KMO_NT), (size_t)lds, s, a);
+        hipLaunchKernelGGL((km_warp_bwd_general_kernel<T, CM, ALIGN, CC, PADX>), dim3(ggrid), dim3(KMO_NT), (size_t)lds, s, a);
     }
 #endif
     return km_check_launch("km_warp2d_bwd(fused)");
 }
+template <typename T, int CM, int PADX>
+static int kmo_launch_p(const KmWarpFusedArgs<T>& a, hipStream_t s) {
+    if (a.cc == 3) return a.g.align ? kmo_launch_k<T, CM, 1, 3, PADX>(a, s) : kmo_launch_k<T, CM, 0, 3, PADX>(a, s);
+    return a.g.align ? kmo_launch_k<T, CM, 1, 1, PADX>(a, s) : kmo_launch_k<T, CM, 0, 1, PADX>(a, s);
+}
 template <typename T, int CM>
 static int kmo_launch(const KmWarpFusedArgs<T>& a, hipStream_t s) {
-    if (a.cc == 3) return a.g.align ? kmo_launch_k<T, CM, 1, 3>(a, s) : kmo_launch_k<T, CM, 0, 3>(a, s);
-    return a.g.align ? kmo_launch_k<T, CM, 1, 1>(a, s) : kmo_launch_k<T, CM, 0, 1>(a, s);
+    if constexpr (sizeof(T) == 4) {  // (border / reflection: fp32 storage only - km_warp_bwd_fused_supported)
+        if (a.g.pad == KM_PAD_BORDER) return kmo_launch_p<T, CM, KM_PAD_BORDER>(a, s);
+        if (a.g.pad == KM_PAD_REFLECTION) return kmo_launch_p<T, CM, KM_PAD_REFLECTION>(a, s);
+    }
+    return kmo_launch_p<T, CM, 0>(a, s);
 }
 
 // one launch sequence (boxes, persistent loop, general) over channels c0 .. c0 + ngrp * cc - 1 of every image
@@ -1157,11 +1170,13 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     return rc;
 }
 
-// 1 if the one-read kernel computes both gradients for these modes (bilinear, zeros / fill padding, fp32 compute; any channel count - fill
+// 1 if the one-read kernel computes both gradients for these modes (bilinear, every padding mode - border / reflection with fp32 storage -,
+// fp32 compute; any channel count - fill
 // values are per channel of an RGB / grey image, so `fill` keeps C in {1, 3})
 int km_warp_bwd_fused_supported(int interp, int pad, int dtype, int C, int H, int W, int h, int w) {
     if (!km_config().warp_bwd_fused) return 0;
-    if (!(interp == KM_INTERP_BILINEAR && (pad == KM_PAD_ZEROS || pad == KM_PAD_FILL) && dtype != KM_F64)) return 0;
+    if (!(interp == KM_INTERP_BILINEAR && dtype != KM_F64)) return 0;
+    if ((pad == KM_PAD_BORDER || pad == KM_PAD_REFLECTION) && dtype != KM_F32) return 0;  // (these two: fp32 storage)
     if (C < 1 || (pad == KM_PAD_FILL && !(C == 1 || C == 3))) return 0;
     // 32-bit byte offsets inside a plane
     return ((uint64_t)H * W * 4 < (1ull << 32) && (uint64_t)h * w * 4 < (1ull << 32)) ? 1 : 0;

@@ -36,6 +36,7 @@ struct KmtBox {
     int j0, j1, i0, i1;
     float mult;     // bound on the number of output pixels whose footprint covers one source pixel
     bool fixed_ok;  // bounded multiplicity: fixed-point accumulation is accurate enough
+    bool ok;        // the box is the tile's own (false: the whole output - vanishing line, degenerate map)
 };
 
 #ifndef KMT_TIGHT_BOX
@@ -59,6 +60,7 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
     o.j0 = 0; o.j1 = g.w - 1; o.i0 = 0; o.i1 = g.h - 1;
     o.mult = (R)g.w * (R)g.h;  // whole-output scan: no multiplicity bound
     o.fixed_ok = false;
+    o.ok = false;
     R G[9], Ga[9];
     // adjugate of m (un-normalised inverse: the common scale cancels in the projective divide); *a = same with |.|
     const R A0 = m[4] * m[8] - m[5] * m[7], A1 = m[2] * m[7] - m[1] * m[8], A2 = m[1] * m[5] - m[2] * m[4];
@@ -171,9 +173,98 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
     const R ex = jac_j + 0.1f, ey = jac_i + 0.1f;
     o.mult = fminf((2.f * ex + 1.f) * (2.f * ey + 1.f), 1.0e6f);
     o.fixed_ok = o.mult <= 256.f;  // beyond ~7x magnification the head-room would eat the mantissa: float path
+    o.ok = true;
     return o;
 }
 // [host-testable end: tile_box]
+
+// ---- padding modes that bring every sampling position INTO the image ---------------------------------------------------------------
+// border: a position left of the image samples column 0, so the tiles along an edge of the image also own every output pixel that
+// maps beyond that edge; reflection: a position is mirrored about the image's edges (period 2 (W - 1), or 2 W without align_corners)
+// before it is clamped, so a tile also owns the pixels that map into its mirror images.  The box of a tile is the bounding box of the
+// boxes of these "copies" of its rectangle - as far as the output image reaches: the raw positions of all output pixels lie in the hull
+// of its four corners' positions (kmt_output_span; the denominator is affine in the base coordinates, so one sign at the corners is one
+// sign everywhere).  Pixels in the holes of that bounding box are visited and found to touch nothing.
+template <int CM>
+__device__ __forceinline__ bool kmt_output_span(const KmWarpGeom<float>& g, const float (&m)[9], float& sx0, float& sx1, float& sy0, float& sy1) {
+    const float Wm1 = (float)(g.W - 1), Hm1 = (float)(g.H - 1), hW = (float)g.W / 2, hH = (float)g.H / 2;
+    sx0 = 3.0e38f; sx1 = -3.0e38f; sy0 = 3.0e38f; sy1 = -3.0e38f;
+    float dmin = 3.0e38f, dmax = -3.0e38f;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const KmlHalf cu = kml_col_half<CM>(m, km_base_x<float, CM>(g, (k & 1) ? g.w - 1 : 0));
+        const KmlHalf rv = kml_row_half<CM>(m, km_base_y<float, CM>(g, (k & 2) ? g.h - 1 : 0));
+        KmlPos p;
+        kml_position<CM, false>(m, cu, rv, p);
+        const float x = g.align ? kml_unnormalize<1>(p.gx, Wm1, hW) : kml_unnormalize<0>(p.gx, Wm1, hW);
+        const float y = g.align ? kml_unnormalize<1>(p.gy, Hm1, hH) : kml_unnormalize<0>(p.gy, Hm1, hH);
+        const float d = (CM == KM_COORD_AFFINE) ? 1.0f : p.den;
+        finite = finite && (x == x) && (y == y) && (fabsf(x) < 1.0e7f) && (fabsf(y) < 1.0e7f) && (d == d) && (CM != KM_COORD_HOMOGRAPHY || p.live);
+        sx0 = fminf(sx0, x); sx1 = fmaxf(sx1, x); sy0 = fminf(sy0, y); sy1 = fmaxf(sy1, y);
+        dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+    }
+    return finite && ((dmin > 0.f && dmin > 1e-4f * dmax) || (dmax < 0.f && dmax < 1e-4f * dmin));
+}
+// the intervals [a, b) of RAW positions (as cell indices) along one axis that end up in the cells [c0, c1) of an axis of n cells; lo / hi: the
+// cells the output's raw positions span.  Returns the number of intervals (<= 3), or -1 when more would be needed.
+__device__ __forceinline__ int kmt_axis_copies(int pad, int align, int c0, int c1, int n, int lo, int hi, int (&a)[3], int (&b)[3]) {
+    if (pad == KM_PAD_BORDER) {
+        a[0] = (c0 == 0) ? min(c0, lo) : c0;
+        b[0] = (c1 == n) ? max(c1, hi + 1) : c1;
+        return 1;
+    }
+    // reflection (ATen reflect_coordinates): align: about 0 and n - 1 (period 2 (n - 1)); otherwise about -0.5 and n - 0.5 (period 2 n);
+    // one cell of slack on every interval for the clamp that follows the mirror
+    const int P = align ? 2 * (n - 1) : 2 * n;
+    if (P <= 0) return -1;
+    int cnt = 0;
+    const int kmin = (lo - n) / P - 2, kmax = (hi + n) / P + 2;
+    for (int k = kmin; k <= kmax; ++k) {
+        // the copy itself, then its mirror image: x -> -x (align) / -1 - x
+        const int da = c0 + k * P - 1, db = c1 + k * P + 1;
+        const int ma = (align ? -(c1 - 1) : -1 - (c1 - 1)) + k * P - 1, mb = (align ? -c0 : -1 - c0) + k * P + 2;
+        if (db > lo && da <= hi) { if (cnt == 3) return -1; a[cnt] = da; b[cnt] = db; ++cnt; }
+        if (mb > lo && ma <= hi) { if (cnt == 3) return -1; a[cnt] = ma; b[cnt] = mb; ++cnt; }
+    }
+    if (cnt == 0) { a[0] = c0; b[0] = c1; cnt = 1; }  // (nothing of the output reaches the tile: its own rectangle gives an empty or tiny box)
+    return cnt;
+}
+template <int CM>
+__device__ __forceinline__ KmtBox kmt_tile_box_padded(const KmWarpGeom<float>& g, const float (&m)[9], int X0, int X1, int Y0, int Y1) {
+    if (g.pad != KM_PAD_BORDER && g.pad != KM_PAD_REFLECTION) return kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
+    KmtBox whole;
+    whole.j0 = 0; whole.j1 = g.w - 1; whole.i0 = 0; whole.i1 = g.h - 1;
+    whole.mult = (float)g.w * (float)g.h; whole.fixed_ok = false; whole.ok = false;
+    float sx0, sx1, sy0, sy1;
+    if (!kmt_output_span<CM>(g, m, sx0, sx1, sy0, sy1)) return whole;
+    const int lox = (int)floorf(sx0) - 2, hix = (int)ceilf(sx1) + 2, loy = (int)floorf(sy0) - 2, hiy = (int)ceilf(sy1) + 2;
+    int xa[3], xb[3], ya[3], yb[3];
+    const int nx = kmt_axis_copies(g.pad, g.align, X0, X1, g.W, lox, hix, xa, xb);
+    const int ny = kmt_axis_copies(g.pad, g.align, Y0, Y1, g.H, loy, hiy, ya, yb);
+    if (nx < 0 || ny < 0) return whole;
+    KmtBox o;
+    o.j0 = g.w; o.j1 = -1; o.i0 = g.h; o.i1 = -1; o.mult = 0.f; o.fixed_ok = true; o.ok = true;
+    for (int iy = 0; iy < ny; ++iy)
+        for (int ix = 0; ix < nx; ++ix) {
+            const KmtBox c = kmt_tile_box<CM>(g, m, xa[ix], xb[ix], ya[iy], yb[iy]);
+            if (!c.ok) return whole;
+            if (c.j0 <= c.j1 && c.i0 <= c.i1) {
+                o.j0 = min(o.j0, c.j0); o.j1 = max(o.j1, c.j1); o.i0 = min(o.i0, c.i0); o.i1 = max(o.i1, c.i1);
+            }
+            o.mult += c.mult;
+        }
+    if (g.pad == KM_PAD_BORDER) {
+        // every output pixel beyond an edge lands on that edge's cells: the multiplicity grows with the extent of the extension
+        const KmtBox plain = kmt_tile_box<CM>(g, m, X0, X1, Y0, Y1);
+        if (!plain.ok) return whole;
+        const int wp = max(plain.j1 - plain.j0 + 1, 0), hp = max(plain.i1 - plain.i0 + 1, 0);
+        const int we = max(o.j1 - o.j0 + 1, 0), he = max(o.i1 - o.i0 + 1, 0);
+        o.mult = plain.mult * (float)(1 + max(we - wp, 0)) * (float)(1 + max(he - hp, 0));
+    }
+    o.fixed_ok = o.mult <= 4096.f;  // (the sums on the cells many pixels share are large: the quantisation step stays far below their rounding)
+    return o;
+}
 
 // block-uniform values computed with VALU float math live in VGPRs unless moved to SGPRs explicitly
 __device__ __forceinline__ float kmt_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -217,6 +308,24 @@ struct KmtPix {
     float x, y;       // sampling position in source pixels
     uint32_t ux, uy;  // (floor(x), floor(y)) relative to the tile, unsigned
 };
+
+// the same for the padding modes that transform the position first (PADX: KM_PAD_BORDER / KM_PAD_REFLECTION; 0: none): ATen's
+// compute_coordinates on the unnormalised position, gdx / gdy its derivative (0 where clamped, -1 on a mirrored stretch)
+template <int CM, int ALIGN, bool FAST, int PADX>
+__device__ __forceinline__ void kmt_pix_position_pad(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, bool valid, float Wm1, float hW, float Hm1, float hH,
+                                                     uint32_t X0, uint32_t Y0, int W, int H, KmtPix& q, float& gdx, float& gdy) {
+    kml_position<CM, FAST>(m, cu, rv, q.p);
+    q.x = kml_unnormalize<ALIGN>(q.p.gx, Wm1, hW);
+    q.y = kml_unnormalize<ALIGN>(q.p.gy, Hm1, hH);
+    gdx = 1.f; gdy = 1.f;
+    if (PADX != 0) {
+        q.x = km_compute_coord(q.x, W, PADX, ALIGN, gdx);
+        q.y = km_compute_coord(q.y, H, PADX, ALIGN, gdy);
+    }
+    kml_taps(q.x, q.y, q.t);
+    q.ux = (uint32_t)KM_F2I(q.t.xf) - X0;
+    q.uy = valid ? (uint32_t)KM_F2I(q.t.yf) - Y0 : 0x40000000u;
+}
 
 template <int CM, int ALIGN, bool FAST>
 __device__ __forceinline__ void kmt_pix_position(const float (&m)[9], const KmlHalf& cu, const KmlHalf& rv, bool valid, float Wm1, float hW, float Hm1, float hH,

@@ -103,17 +103,18 @@ def _warp2d_backward(gout: torch.Tensor, x: torch.Tensor, Mc: torch.Tensor, m: t
     B_M = Mc.shape[0]
     g = gout.detach().to(x.dtype).contiguous()
     stream = N.stream_ptr(dev)
-    gsrc = None
-    if need_src:
-        zero = lib.km_warp2d_bwd_needs_zero_init(cfg.interp, cfg.pad, N.dtype_code(x.dtype))
-        gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
     gmat = None
-    # both gradients wanted: a workspace lets the library take them from one read of grad_out (include/kornia_amd.h)
+    # both gradients wanted - or the image gradient under border / reflection padding, where the tile-owner kernel replaces a scatter with
+    # global atomics: a workspace lets the library take them from one read of grad_out (include/kornia_amd.h)
     ws, ws_bytes = None, 0
-    if need_src and need_mat:
+    if need_src and (need_mat or cfg.pad in (_PAD["border"], _PAD["reflection"])):
         ws_bytes = int(lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, cfg.interp, cfg.pad, N.dtype_code(x.dtype)))
         if ws_bytes > 0:
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    gsrc = None
+    if need_src:
+        zero = ws is None and lib.km_warp2d_bwd_needs_zero_init(cfg.interp, cfg.pad, N.dtype_code(x.dtype))  # (the tile owners write every pixel)
+        gsrc = (torch.zeros if zero else torch.empty)(B, C, H, W, device=dev, dtype=cdt)
     # (on the one-read path the first launch zeroes the fp64 accumulators itself: one fill launch less per step)
     gm = (torch.empty if ws is not None else torch.zeros)(B_M, 9, device=dev, dtype=torch.float64) if need_mat else None
     with N.device_guard(dev):

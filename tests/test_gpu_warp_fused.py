@@ -84,6 +84,56 @@ def test_any_channel_count_runs_through_the_same_tiles(oracle, C):
     assert _rel(gM, gM2) <= 2e-3 and torch.allclose(gx.float(), gx2.float(), atol=2e-3, rtol=0)
 
 
+@pytest.mark.parametrize("case", ["shift_right_down", "rotate_12deg", "flagship", "far_left", "shrink"])
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("pad", ["border", "reflection"])
+def test_border_and_reflection_padding_through_the_tile_owners(oracle, pad, align, case):
+    """padding_mode = border / reflection: every sampling position is brought into the image first (ATen's clip / reflect_coordinates), so
+    the tiles along an edge also own the output pixels that map beyond it (border) and every tile the pixels that map into its mirror
+    images (reflection) - their boxes are the bounding boxes of those copies (kmt_tile_box_padded).  Both gradients against the oracle; the
+    cells many outside pixels pile onto hold large sums, so the bound on the image gradient is relative to its largest entry."""
+    import kornia_amd as K
+
+    lib = _lib()
+    B, C, H, W, h, w = 2, 3, 150, 200, 150, 200
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, h, w, 1, {"border": 1, "reflection": 2}[pad], 0) > 0
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, C, H, W, generator=g)
+    go = torch.rand(B, C, h, w, generator=g) - 0.4
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    if case == "flagship":
+        M = flagship_homographies(B, H, W, h, w, g, jitter=10.0)
+        fn = lambda a, m: K.warp_perspective(a, m, (h, w), padding_mode=pad, align_corners=align)
+        bwd = lambda: oracle.warp_perspective_backward(go, x, M, (h, w), padding_mode=pad, align_corners=align)
+    else:
+        import math
+
+        if case == "shift_right_down":
+            A = torch.tensor([[1.0, 0.0, 23.4], [0.0, 1.0, 17.8]])
+        elif case == "far_left":
+            A = torch.tensor([[1.0, 0.02, -70.0], [-0.01, 1.0, 3.0]])
+        elif case == "shrink":
+            A = torch.tensor([[0.8, 0.0, 0.2 * cx], [0.0, 0.85, 0.15 * cy]])  # the image shrinks around its centre: a frame of padding all around
+        else:
+            c_, s_ = math.cos(math.radians(12.0)), math.sin(math.radians(12.0))
+            A = torch.tensor([[c_, s_, (1 - c_) * cx - s_ * cy], [-s_, c_, s_ * cx + (1 - c_) * cy]])
+        M = A.repeat(B, 1, 1)
+        M[1, :, 2] += torch.tensor([-9.0, 6.0])
+        fn = lambda a, m: K.warp_affine(a, m, (h, w), padding_mode=pad, align_corners=align)
+        bwd = lambda: oracle.warp_affine_backward(go, x, M, (h, w), padding_mode=pad, align_corners=align)
+    gx, gM = _run(fn, x, M, go, True)
+    gx2, gM2 = _run(fn, x, M, go, False)  # (the generic kernel: global atomics)
+    gxo, gMo = bwd()
+    scale = max(1.0, gxo.abs().max().item())
+    assert torch.allclose(gx, gxo, atol=2e-5 * scale, rtol=0), ((gx - gxo).abs().max(), scale)
+    assert torch.allclose(gx2, gxo, atol=2e-5 * scale, rtol=0)
+    assert _rel(gM, gMo) <= 2e-4, _rel(gM, gMo)
+    # the image gradient alone takes the same kernel (no matrix gradient committed)
+    xg = x.cuda().requires_grad_()
+    fn(xg, M.cuda()).backward(go.cuda())
+    assert torch.allclose(xg.grad.cpu(), gxo, atol=2e-5 * scale, rtol=0)
+
+
 def test_affine_and_homography_modes(oracle):
     """The other two coordinate generators (warp_affine with and without align_corners, homography_warp) through the one-read backward."""
     import kornia_amd as K
@@ -339,7 +389,8 @@ def test_workspace_contract():
     B, C, H, W = 2, 3, 130, 140
     assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 0, 0) == 80 * B * 3 * 3  # one 80-byte record per 64 x 64 tile
     assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 2, 0, 0) == 0   # bicubic
-    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 1, 0) == 0   # border padding
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 1, 0) == 80 * B * 3 * 3  # border padding: the same tile owners (fp32 storage)
+    assert lib.km_warp2d_bwd_workspace_bytes(B, C, H, W, H, W, 1, 1, 2) == 0   # ... bf16 storage: the generic kernel
     assert lib.km_warp2d_bwd_workspace_bytes(B, 4, H, W, H, W, 1, 0, 0) == 80 * B * 3 * 3  # RGBA = one group of three + one single channel, the larger sequence
     assert lib.km_warp2d_bwd_workspace_bytes(B, 8, H, W, H, W, 1, 0, 0) == 2 * 80 * B * 3 * 3  # two groups of three (+ two singles)
     assert lib.km_warp2d_bwd_workspace_bytes(B, 4, H, W, H, W, 1, 3, 0) == 0   # fill values are RGB / grey
