@@ -38,9 +38,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (measured streaming copy on these boxes: 6.2 TB/s)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-if not os.path.exists(PMC_FILE):
-    PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(p)), "")
+
+
+def csrc_sha256():
+    """sha256 over the kernel sources (kornia_amd/csrc/*.hip, *.h, sorted by name): what a PMC measurement is valid for"""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kornia_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
 
 
 def parse_args():
@@ -685,11 +697,18 @@ def main():
             kstats, ops = kernel_roofline(sets, S, max(6, min(args.steps, 21)))
         dom_op = max(ops, key=lambda k: ops[k]["ms"])
         dom_kernel = max(kstats, key=lambda k: kstats[k]["ms"])
-        # HBM traffic of the dominant op: rocprofv3 PMC cannot run inside this process, so the figure is the committed
-        # measurement of this very command / config (profiles/r02_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes)
+        # HBM traffic of the dominant op: rocprofv3 PMC cannot run inside this process, so the figure is the committed measurement of this
+        # very command / config (profiles/r0N_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes) - quoted only while the
+        # kernel sources of the tree hash to what that measurement recorded (csrc_sha256)
         traffic = None
-        if (B, C, S) == (256, 3, 512) and os.path.exists(PMC_FILE):
-            pmc = json.load(open(PMC_FILE)).get("kernels", {})
+        traffic_note = None
+        pmc_doc = json.load(open(PMC_FILE)) if PMC_FILE else {}
+        src_now = csrc_sha256()
+        if PMC_FILE and pmc_doc.get("csrc_sha256") != src_now:
+            # the counters were collected on other kernel sources than the tree's: not this build's traffic
+            traffic_note = f"not quoted: profiles/{os.path.basename(PMC_FILE)} was measured on kernel sources {str(pmc_doc.get('csrc_sha256'))[:12]}, the tree is {src_now[:12]}"
+        elif (B, C, S) == (256, 3, 512) and PMC_FILE:
+            pmc = pmc_doc.get("kernels", {})
             fused = "one read" in ops["km_warp2d_bwd"].get("form", "")
             want = {"km_warp2d_bwd": ("km_warp_bwd_fused_kernel",) if fused else ("km_warp_bwd_tiled_kernel", "km_warp_gm_kernel"), "km_warp2d_fwd": ("km_warp_fwd_box_kernel",),
                     "km_filter2d_sep_fwd": ("km_blur_reg_kernel<float, 5, false",), "km_filter2d_sep_bwd_input": ("km_blur_reg_kernel<float, 5, true",)}[dom_op]
@@ -706,7 +725,8 @@ def main():
             "unit": "GB/s",
             "frac": ops[dom_op]["frac_of_hbm_peak"],
             "traffic": traffic,
-            "traffic_source": f"profiles/{os.path.basename(PMC_FILE)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)" if traffic else None,
+            "traffic_source": (f"profiles/{os.path.basename(PMC_FILE)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command; kernel sources {src_now[:12]})"
+                               if traffic else traffic_note),
             "op_ms": ops[dom_op]["ms"],
             "alg_bytes_per_call": ops[dom_op]["alg_bytes"],
             "accounting": "SURVEY.md 8(d): warp fwd 2e, blur fwd 2e, blur bwd 2e, warp bwd 3e bytes per element; op = every launch of the public entry point",

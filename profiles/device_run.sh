@@ -39,6 +39,7 @@ for stage in "$@"; do
       ;;
     prof)
       P=$D/${RUN}_prof; rm -rf $P; mkdir -p $P
+      python3 -c "import bench; print(bench.csrc_sha256())" > $P/csrc.sha256 2>/dev/null
       ( cd /tmp && export TMPDIR=/tmp
         timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o f -- python $R/bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 3 --groups 3 > $P/stats.log 2>&1
         rc=$?; echo "rocprofv3 stats rc $rc" >> $O
