@@ -243,6 +243,39 @@ def _gaussian_blur_apply(original: Callable) -> Callable:
     return apply_transform
 
 
+def _affine_compute(original: Callable) -> Callable:
+    """RandomAffine.compute_transformation (_2d/geometric/affine.py:125-141) with the normalise / invert chain of the warp that follows it
+    folded into the same launch (``km_affine_params_chain_fwd``): the six sampled parameter tensors -> the (B,3,3) pixel matrix the module
+    keeps as its ``transform_matrix`` AND the (B,9) matrix the warp kernel reads (the warp's prologue).  The second one
+    is parked on the module, keyed by the identity of the sampled ``angle`` tensor; ``apply_transform`` (below) takes it when it is called
+    with the same parameters for an image of the same size - two launches for the whole augmentation instead of three."""
+    from . import augmentation as _aug
+
+    keys = ("translations", "center", "scale", "angle", "shear_x", "shear_y")
+
+    @functools.wraps(original)
+    def compute_transformation(self, input, params, flags):
+        ok = (
+            isinstance(input, torch.Tensor) and _N.on_device(input) and input.dim() == 4 and input.dtype in _COLOR_DTYPES
+            and all(isinstance(params.get(k), torch.Tensor) for k in keys)
+            and not (torch.is_grad_enabled() and any(params[k].requires_grad for k in keys))
+            and not (torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling())
+        )
+        if ok:
+            B = input.shape[0]
+            ok = all(params[k].shape[0] == B for k in keys) and tuple(params["translations"].shape) == (B, 2) and tuple(params["scale"].shape) == (B, 2)
+        self._kornia_amd_chain = None
+        if not ok:
+            return original(self, input, params, flags)
+        height, width = int(input.shape[-2]), int(input.shape[-1])
+        m, M, _ = _aug.affine_chain({k: params[k] for k in keys}, input.device, height, width, with_matrix=True)
+        self._kornia_amd_chain = (weakref.ref(params["angle"]), m, height, width)
+        return M.to(input.dtype)
+
+    compute_transformation.__wrapped__ = original
+    return compute_transformation
+
+
 def _geometric_apply(original: Callable, kind: str) -> Callable:
     """RandomAffine.apply_transform (kornia/augmentation/_2d/geometric/affine.py:143-162) and RandomPerspective.apply_transform
     (_2d/geometric/perspective.py:100-115) with the per-sample probability switch of ``transform_inputs`` (augmentation/base.py:380-393)
@@ -251,7 +284,7 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
     reference finds nothing to do (``_blend_by_prob`` above recognises the result).  The matrix is the one the module hands over
     (``transform``: what ``compute_transformation`` - already one native launch - produced, or the caller's own in
     ``inverse_transform``), never re-derived from the parameters.  Anything unusual falls through to the module's own method."""
-    from .geometry.transform.imgwarp import COORD_AFFINE, COORD_PERSPECTIVE, _warp
+    from .geometry.transform.imgwarp import COORD_AFFINE, COORD_PERSPECTIVE, _warp, _warp_affine_from_chain
 
     @functools.wraps(original)
     def apply_transform(self, input, params, flags, transform=None):
@@ -280,7 +313,17 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
             fill_value = flags.get("fill_value")
             if padding_mode == "fill" and fill_value is None:
                 fill_value = torch.zeros(input.shape[1], device=input.device, dtype=input.dtype)
-            out = _warp(input, transform[:, :2, :], (height, width), COORD_AFFINE, 1, mode, padding_mode, flags["align_corners"], fill_value, apply)
+            chain = getattr(self, "_kornia_amd_chain", None)
+            self._kornia_amd_chain = None
+            angle = params.get("angle") if hasattr(params, "get") else None
+            if (chain is not None and angle is not None and chain[0]() is angle and chain[2:] == (height, width) and chain[1].shape[0] == B
+                    and input.dtype == torch.float32):
+                # the matrix the warp reads came out of compute_transformation's own launch (_affine_compute): straight to the sampler.
+                # (16-bit images: the reference rounds the pixel matrix to the image dtype before the warp sees it, so those take the chain
+                # of the rounded matrix below - the same bits as before this shortcut existed)
+                out = _warp_affine_from_chain(input, chain[1], mode, padding_mode, flags["align_corners"], fill_value, apply)
+            else:
+                out = _warp(input, transform[:, :2, :], (height, width), COORD_AFFINE, 1, mode, padding_mode, flags["align_corners"], fill_value, apply)
         else:
             out = _warp(input, transform, (height, width), COORD_PERSPECTIVE, 1, mode, "zeros", flags["align_corners"], torch.zeros(3), apply)
         if apply is not None:
@@ -336,6 +379,10 @@ def patch() -> int:
     # the geometric leg of the same layer: the probability switch rides in the warp's own launch
     # (RandomShear / RandomTranslate apply exactly like RandomAffine - _2d/geometric/shear.py:113-131, translate.py:102-120 -, RandomRotation
     # through `affine` with zeros padding)
+    aff_mod = importlib.import_module("kornia.augmentation._2d.geometric.affine")
+    original = aff_mod.RandomAffine.compute_transformation
+    aff_mod.RandomAffine.compute_transformation = _affine_compute(original)
+    _patched_methods.append((aff_mod.RandomAffine, "compute_transformation", original))
     for mod_name, cls_name, kind in (("kornia.augmentation._2d.geometric.affine", "RandomAffine", "affine"),
                                      ("kornia.augmentation._2d.geometric.perspective", "RandomPerspective", "perspective"),
                                      ("kornia.augmentation._2d.geometric.shear", "RandomShear", "affine"),
@@ -345,7 +392,7 @@ def patch() -> int:
         original = cls.apply_transform
         cls.apply_transform = _geometric_apply(original, kind)
         _patched_methods.append((cls, "apply_transform", original))
-    return count + 10
+    return count + 11
 
 
 def unpatch() -> int:

@@ -310,3 +310,46 @@ def test_rotation_shear_translate_hooks_on_the_host_build():
         finally:
             assert P.unpatch() == n
     assert selects == [], selects   # the switch rode inside every warp launch
+
+
+def test_random_affine_is_two_launches_under_patch_on_the_host_build():
+    """parameters -> matrix -> normalise -> invert in the warp's prologue.  Under patch() RandomAffine is the parameter
+    launch (km_affine_params_chain_fwd: the module's transform_matrix AND the matrix the sampler reads) + the warp with the probability switch
+    inside it: two kernel launches for a float32 batch, with p = 1 and with p < 1, output and transform_matrix as the unpatched module's."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("host build of the kernels needs ROCm's clang++")
+    K = ref_shim.import_reference()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from mode import emulated_device
+
+    import kornia_amd.kornia_patch as P
+
+    A = K.augmentation
+    x = torch.rand(6, 3, 48, 64, generator=torch.Generator().manual_seed(2))
+    cases = []
+    torch.manual_seed(21)
+    for p in (1.0, 0.5):
+        for attempt in range(20):
+            aug = A.RandomAffine(degrees=20.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=6.0, padding_mode="border", p=p)
+            ref = aug(x)
+            mask = torch.as_tensor(aug._params["batch_prob"]) > 0.5
+            if p == 1.0 or 0 < int(mask.sum()) < 6:
+                break
+        cases.append((p, aug._params, ref, aug.transform_matrix.clone()))
+    with emulated_device():
+        import emu_lib
+
+        n = P.patch()
+        try:
+            for p, params, ref, tm in cases:
+                aug = A.RandomAffine(degrees=20.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=6.0, padding_mode="border", p=p)
+                dev_params = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in params.items()}
+                before = emu_lib.stats()["launches"]
+                out = aug(x.cuda(), params=dev_params)
+                launches = emu_lib.stats()["launches"] - before
+                assert launches == 2, f"p = {p}: {launches} kernel launches"
+                assert torch.allclose(out, ref, atol=2e-5, rtol=0), (out - ref).abs().max()
+                assert torch.allclose(aug.transform_matrix, tm, atol=1e-4, rtol=1e-5)
+                assert getattr(aug, "_kornia_amd_chain", None) is None  # consumed by the apply step
+        finally:
+            assert P.unpatch() == n
