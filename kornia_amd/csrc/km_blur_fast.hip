@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     bid /= a.bx;
     const uint32_t tby = bid % a.by;
     const uint32_t bc = bid / a.by;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the strip's rows are scalar values)
     const int gx = (int)tbx * 64 + lane;                      // column group (4 px)
     const int r0 = ((int)tby * 4 + wave) * ROWS;              // first output row of this thread's strip
     if (gx >= (int)a.groups_x || r0 >= a.H) return;
@@ -133,6 +133,28 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     float ring[K][4];  // rolling window of row-pass results
     const int n_rows = (r0 + ROWS <= H ? ROWS : H - r0);
     const int total = n_rows + K - 1;
+    const bool e0 = (lane == 0), e63 = (lane == 63);
+
+    // The row loads run ONE ROW AHEAD of the arithmetic: a wave walks its strip row by row (load -> row pass -> column pass -> store), and with
+    // the wait for a row's load directly in front of its row pass every wave had exactly one 1 KB request in flight - ~8 MB across the chip against
+    // the ~16 MB that 8 TB/s times the memory latency ask for.  The request of row it + 1 is issued before row it is processed (8 more registers).
+    // (Circular borders load their two neighbour chunks in place, as before.)
+    float on4[4] = {0.f, 0.f, 0.f, 0.f}, en4[4] = {0.f, 0.f, 0.f, 0.f};
+    int srow_n = -1;
+    auto request = [&](int it) {
+        const int rin = r0 + it - (BWD ? R : L);
+        int sr;
+        if (BWD) sr = (border == KM_BORDER_CIRCULAR) ? km_border_map(rin, H, KM_BORDER_CIRCULAR) : ((rin >= 0 && rin < H) ? rin : -1);
+        else sr = km_border_map(rin, H, border);
+        srow_n = sr;
+        if (sr >= 0) {
+            const T* rowp = img + (size_t)sr * W;
+            km_ld4(rowp + c0, on4);
+            // the two chunks no lane holds - left of lane 0, right of lane 63 - come with ONE load (see below)
+            if (border != KM_BORDER_CIRCULAR && (e0 || e63)) km_ld4(rowp + (e0 ? offL : offR), en4);
+        }
+    };
+    request(0);
 
     for (int it0 = 0; it0 < total; it0 += K) {
 #pragma unroll
@@ -140,15 +162,15 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
             const int it = it0 + kk;
             if (it < total) {
                 // ---- row pass for input row (r0 - L + it) [fwd] / (r0 - R + it) [bwd] ----
-                const int rin = r0 + it - (BWD ? R : L);
-                int srow;
-                if (BWD) srow = (border == KM_BORDER_CIRCULAR) ? km_border_map(rin, H, KM_BORDER_CIRCULAR) : ((rin >= 0 && rin < H) ? rin : -1);
-                else srow = km_border_map(rin, H, border);
+                const int srow = srow_n;
                 float v[12];
+                float o4[4], e4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o4[q] = on4[q]; e4[q] = en4[q]; }
+                if (it + 1 < total) request(it + 1);
                 if (srow >= 0) {
                     const T* rowp = img + (size_t)srow * W;
-                    float l4[4], o4[4], r4[4];
-                    km_ld4(rowp + c0, o4);
+                    float l4[4], r4[4];
                     if (border == KM_BORDER_CIRCULAR) {
                         km_ld4(rowp + offL, l4);
                         km_ld4(rowp + offR, r4);
@@ -158,9 +180,6 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
                         // unit is the busiest unit of this kernel (TA_TA_BUSY 86 % with three 16-byte loads per row,
                         // profiles/r02_pmc_units.json) and it charges ~25 cycles per wave instruction however few lanes
                         // are active, so the two chunks no lane holds - left of lane 0, right of lane 63 - come with ONE load.
-                        const bool e0 = (lane == 0), e63 = (lane == 63);
-                        float e4[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (e0 || e63) km_ld4(rowp + (e0 ? offL : offR), e4);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float pl = km_prev64(o4[q]), nr = km_next64(o4[q]);
