@@ -77,11 +77,17 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #ifndef KMO_WG_PER_CU
 #define KMO_WG_PER_CU 1    // persistent workgroups per CU (what the LDS of a workgroup allows)
 #endif
+#ifndef KMO_REC_FIELDS
+#define KMO_REC_FIELDS 1   // tile coordinates and walk steps of a tile from its workspace record instead of integer divisions in the tile loop
+#endif
+#ifndef KMO_GM_LDS
+#define KMO_GM_LDS 1       // image-end sums of the matrix gradient through the (dead) source tile in LDS instead of nine wave reductions per wave
+#endif
 #ifndef KMO_SRC_AT
 #define KMO_SRC_AT 0       // slot of the scatter after which the next tile's source tile is requested
 #endif
 #define KMO_RUN 64         // records wave 0 fetches from the workspace at once (lane = tile), into alternating halves of a 2 x 64 ring
-#define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, first plane, matrix row, the 9 matrix entries, -, -, -
+#define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, first plane, matrix row, the 9 matrix entries, tile (tx, ty), (image, group), walk steps
 enum { KMO_F_FIXED = 1, KMO_F_REGULAR = 4, KMO_F_NONFINITE = 8 };
 
 template <typename T>
@@ -119,6 +125,7 @@ struct KmoTile {
     int j0, j1, i0, i1, hb;
     bool fixed_ok, regular, svec, fvec;
     int bw, nq;
+    int di, dj;        // row / column step of the linear walk over the box (KMO_NT / bw, KMO_NT % bw)
     int p, npass;      // the box is walked in npass passes of KMO_CAP pixels; this work item is pass p
 };
 #define KMO_CAP (KMO_NT * KMO_SLOTS)  // pixels of a box the registers of a workgroup hold
@@ -177,7 +184,11 @@ __global__ __launch_bounds__(256) void km_warp_bwd_boxes_kernel(const KmWarpFuse
     o[7] = g.B_M == 1 ? 0 : b;                      // row of mat / gmat
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[8 + k] = __float_as_int(m[k]);  // (the tile loop reads its matrix from LDS, not through a vector load)
-    o[17] = 0; o[18] = 0; o[19] = 0;
+    // what the persistent loop would otherwise derive with integer divisions, executed by all 16 waves of a workgroup for every tile
+    const int bwc = max(bw, 1);
+    o[17] = tx | (ty << 16);                               // tile column / row (< 2^16 each: checked by the host)
+    o[18] = bg;                                            // (image, channel group) index of the sequence
+    o[19] = (KMO_NT / bwc) | ((KMO_NT % bwc) << 16);       // row / column step of the linear walk over the box, KMO_NT pixels apart
 }
 
 // tile t from its (block-uniform) workspace record
@@ -196,7 +207,17 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
     d.t = t;
     if (t < 0) return;
     int tx, ty;
+#if KMO_REC_FIELDS
+    {
+        const int txy = kmt_uniform(rec[17]);
+        tx = txy & 0xffff; ty = (int)((uint32_t)txy >> 16);
+        d.b = kmt_uniform(rec[18]);
+        const int st = kmt_uniform(rec[19]);
+        d.di = st & 0xffff; d.dj = (int)((uint32_t)st >> 16);
+    }
+#else
     kmo_tile_coords(a, (uint32_t)t, d.b, tx, ty);
+#endif
     d.X0 = tx * KMT_TW; d.Y0 = ty * KMO_TH;
     d.TWc = min(d.X0 + KMT_TW, g.W) - d.X0; d.THc = min(d.Y0 + KMO_TH, g.H) - d.Y0;
     d.j0 = kmt_uniform(rec[0]); d.j1 = kmt_uniform(rec[1]); d.i0 = kmt_uniform(rec[2]); d.i1 = kmt_uniform(rec[3]);
@@ -206,6 +227,9 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
     d.fixed_ok = (fl & KMO_F_FIXED) != 0; d.regular = (fl & KMO_F_REGULAR) != 0;
     const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
     d.bw = bw;
+#if !KMO_REC_FIELDS
+    d.di = kmt_uniform(KMO_NT / max(bw, 1)); d.dj = kmt_uniform(KMO_NT % max(bw, 1));
+#endif
     d.nq = (bw > 0 && bh > 0) ? bw * bh : 0;
     d.p = 0;
     d.npass = d.regular ? max(1, (d.nq + KMO_CAP - 1) / KMO_CAP) : 1;  // (a tile of the general launch is ONE item of the persistent loop, whatever its box)
@@ -372,8 +396,8 @@ template <typename T>
 __device__ __forceinline__ void kmo_walk_init(const KmWarpFusedArgs<T>& a, const KmoTile& d, KmoWalk& wk) {
     wk.bw = max(d.bw, 1);
     wk.nq = d.regular ? min(d.nq - d.p * KMO_CAP, KMO_CAP) : 0;  // pixels of this pass (a tile of the general path loads its pixels itself)
-    wk.di = kmt_uniform(KMO_NT / wk.bw);
-    wk.dj = kmt_uniform(KMO_NT % wk.bw);
+    wk.di = d.di;
+    wk.dj = d.dj;
     kmo_first(d.p * KMO_CAP + (int)threadIdx.x, wk.bw, wk.qi, wk.qj);
     wk.row0 = (uint32_t)d.i0 * (uint32_t)a.g.w + (uint32_t)d.j0;
 }
@@ -397,7 +421,7 @@ __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& 
                                             float (&S)[CC * KMO_PLANE / KMO_NT]) {
     const int tid = threadIdx.x;
     const int bw = max(d.bw, 1);
-    const int di = kmt_uniform(KMO_NT / bw), dj = kmt_uniform(KMO_NT % bw);
+    const int di = d.di, dj = d.dj;
     const int nqp = min(d.nq - d.p * KMO_CAP, KMO_CAP);  // pixels of this pass
     int qi, qj;
     kmo_first(d.p * KMO_CAP + tid, bw, qi, qj);
@@ -647,12 +671,16 @@ __device__ __forceinline__ KmoConsts kmo_consts(const KmWarpGeom<float>& g) {
     return kc;
 }
 // the wave partials of a finished image in s_gm -> 9 fp64 atomics
-template <int CM>
+template <int CM, bool TOTALS = false>
 __device__ __forceinline__ void kmo_gm_commit(const double* s_gm, double* gmat_b, int tid) {
     if (tid < 9 && gmat_b) {  // (gmat_b == nullptr: the caller wants the image gradient only)
         double s = 0.0;
+        if (TOTALS) {
+            s = s_gm[tid];  // (the persistent loop's image-end reduction leaves the nine totals)
+        } else {
 #pragma unroll
-        for (int w = 0; w < KMO_NW; ++w) s += s_gm[w * 9 + tid];
+            for (int w = 0; w < KMO_NW; ++w) s += s_gm[w * 9 + tid];
+        }
         if (s != 0.0 && !(CM == KM_COORD_AFFINE && tid >= 6)) km_atomic_add(gmat_b + tid, s);
     }
 }
@@ -779,7 +807,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
             wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
         }
         // matrix-gradient partials of the image finished before this tile
-        if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
+        if (pending_b >= 0) kmo_gm_commit<CM, (KMO_GM_LDS && CC * KMO_PLANE >= 9 * KMO_NT)>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
         pending_b = -1;
 
         // ---- the fixed-point scale: from the exact maximum of the first pass; a later pass with a larger one rescales the accumulators ----
@@ -829,11 +857,30 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         if (last_pass) {
             // ---- an image that ends here publishes its matrix-gradient partials ----
             if (nxt.t < 0 || nxt.b != cur.b) {  // (per (image, group): the groups of an image meet in gmat's atomics)
+                if (KMO_GM_LDS && CC * KMO_PLANE >= 9 * KMO_NT) {
+                    // Nine 64-lane fp64 reductions per wave are 108 ds_bpermute + 54 v_add_f64 for each of the 16 waves - 2 000 cycles per tile on
+                    // average (profiles/r03_bwd_phases.txt: "loop tail").  The source tile is dead after the last pass of its tile: the 1024
+                    // threads park their nine fp32 partials there, and wave k sums row k - sixteen conflict-free reads per lane, fp64 adds, ONE
+                    // wave reduction.  The same fp32 partials summed in fp64, in another order; two more LDS barriers per image.
+                    float* s_part = l.s_src;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const double s = km_wave_sum((double)A[k]);
-                    if (lane == 0) l.s_gm[wave * 9 + k] = s;
-                    A[k] = 0.f;
+                    for (int k = 0; k < 9; ++k) { s_part[k * KMO_NT + tid] = A[k]; A[k] = 0.f; }
+                    KM_LDS_BARRIER();
+                    if (wave < 9) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < KMO_NT / 64; ++jj) s += (double)s_part[wave * KMO_NT + jj * 64 + lane];
+                        s = km_wave_sum(s);
+                        if (lane == 0) l.s_gm[wave] = s;
+                    }
+                    KM_LDS_BARRIER();  // (the next tile's stage rewrites the source tile)
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const double s = km_wave_sum((double)A[k]);
+                        if (lane == 0) l.s_gm[wave * 9 + k] = s;
+                        A[k] = 0.f;
+                    }
                 }
                 pending_b = cur.bm;
             }
@@ -862,7 +909,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 #endif
     // ---- epilogue: the last image's partials ----
     __syncthreads();
-    if (pending_b >= 0) kmo_gm_commit<CM>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
+    if (pending_b >= 0) kmo_gm_commit<CM, (KMO_GM_LDS && CC * KMO_PLANE >= 9 * KMO_NT)>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
 }
 
 // ---- launch 3, first part: non-finite gradients at output pixels NO tile visits ---------------------------------------------------
@@ -1160,7 +1207,8 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     // C = 3 a3 + r1: the groups of three through the RGB instantiation, the rest one channel at a time through the grey one
     const uint32_t a3 = (uint32_t)C / 3u, r1 = (uint32_t)C % 3u;
     const uint64_t per_image = (uint64_t)a.tiles_x * a.tiles_y;
-    KM_REQUIRE(per_image * (uint64_t)B * (a3 > r1 ? a3 : r1) < (1ull << 26) && (uint64_t)B * (uint64_t)C < (1ull << 31), "km_warp2d_bwd: grid too large");
+    KM_REQUIRE(per_image * (uint64_t)B * (a3 > r1 ? a3 : r1) < (1ull << 26) && (uint64_t)B * (uint64_t)C < (1ull << 31) && a.tiles_x < 65536u && a.tiles_y < 65536u,
+               "km_warp2d_bwd: grid too large");
     if (per_image * (uint64_t)B == 0 || C == 0) return (int)hipMemsetAsync(gmat, 0, (size_t)B_M * 9 * sizeof(double), s);  // (nothing to add: the accumulators are still this path's to zero)
     a.reverse = km_traversal_next(s);
     a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(float));

@@ -55,6 +55,34 @@ def test_config2_512_fwd_bwd_matches_oracle(oracle, smooth):
     assert _rel(Mg.grad.cpu(), gM_o) <= 5e-5, _rel(Mg.grad.cpu(), gM_o)
 
 
+def test_config2_whole_batch_256_against_the_oracle_at_full_size(oracle):
+    """BASELINE configs[1] at its REAL batch: 256 x 3 x 512 x 512, flagship homographies - the very tensors shape bench.py times: 64 tiles per
+    persistent worker, every run of the tile sequence crossing images, the alternating batch traversal.  Forward bit-identical to the oracle
+    (warp and blur), grad wrt the image <= 1e-5, grad wrt the homography <= 5e-5 of the fp32 oracle.  (The oracle's OpenMP loops take ~10 s on the
+    GPU box's host; the host build of the kernels skips this one - the name ends in _at_full_size.)"""
+    import kornia_amd as K
+
+    B, S = 256, 512
+    g = torch.Generator().manual_seed(2020)
+    x = torch.rand(B, 3, S, S, generator=g)
+    M = flagship_homographies(B, S, S, S, S, g)
+    go = torch.rand(B, 3, S, S, generator=g)
+    xg, Mg = x.cuda().requires_grad_(), M.cuda().requires_grad_()
+    w = K.warp_perspective(xg, Mg, (S, S))
+    y = K.gaussian_blur2d(w, (5, 5), (1.5, 1.5))
+    y.backward(go.cuda())
+    w_o = oracle.warp_perspective(x, M, (S, S))
+    assert torch.equal(w.detach().cpu(), w_o)
+    y_o = oracle.gaussian_blur2d(w_o, (5, 5), (1.5, 1.5))
+    assert torch.equal(y.detach().cpu(), y_o)
+    del w, y
+    gw_o = oracle.gaussian_blur2d_backward(go, w_o, (5, 5), (1.5, 1.5))
+    gx_o, gM_o = oracle.warp_perspective_backward(gw_o, x, M, (S, S))
+    assert (xg.grad.cpu() - gx_o).abs().max().item() <= 1e-5
+    per_image = ((Mg.grad.cpu().double() - gM_o.double()).abs().amax(dim=(-2, -1)) / gM_o.double().abs().amax(dim=(-2, -1))).max().item()
+    assert per_image <= 5e-5, per_image
+
+
 def test_config2_512_rotated_and_scaled_homographies(oracle):
     """Same size, matrices far from the identity (rotation, 0.6x - 1.7x scale, strong perspective): the owner-tile boxes of the
     backward and the wave-uniform fast paths of the forward take their other branches."""
