@@ -67,6 +67,18 @@ __device__ __forceinline__ float km_next64(float v) { return __uint_as_float(km_
 __device__ __forceinline__ float km_prev64(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));
 }
+// Maximum of an unsigned value over the wave, valid in LANE 63 only (other lanes hold partial maxima): an inclusive scan inside each row
+// of 16 lanes (row_shr:1/2/4/8; a lane without a source keeps its own value), then lane 15 of a row into the next row (row_bcast:15,
+// rows 1 and 3) and lane 31 into rows 2 and 3 (row_bcast:31) - ten VALU instructions, no LDS traffic (a __shfl_down ladder is six
+// dependent ds_bpermute round trips).  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t km_wave_umax_last(uint32_t v) {
+    int x = (int)v;
+#define KM_UMAX_STEP(ctrl, rows) x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(x, x, ctrl, rows, 0xf, false));
+    KM_UMAX_STEP(0x111, 0xf) KM_UMAX_STEP(0x112, 0xf) KM_UMAX_STEP(0x114, 0xf) KM_UMAX_STEP(0x118, 0xf)
+    KM_UMAX_STEP(0x142, 0xa) KM_UMAX_STEP(0x143, 0xc)
+#undef KM_UMAX_STEP
+    return (uint32_t)x;
+}
 #endif
 
 // ---- storage types ----------------------------------------------------------------------------

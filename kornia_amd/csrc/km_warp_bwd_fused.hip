@@ -48,7 +48,7 @@
 // KMO_PROFILE (variant libraries only, profiles/time_bwd_phases.py): every wave sums the shader cycles (s_memtime) it spends in each phase
 // of the tile loop; km_debug_fused_profile() copies the table out.  Costs ~10 % of the kernel; the default build has none of it.
 #ifdef KMO_PROFILE
-#define KMO_PROF_PHASES 8
+#define KMO_PROF_PHASES 16  // 0-7: the phases of the tile loop; 8-15: parts of the stage (8-10) and of the description (11-14)
 __device__ unsigned long long kmo_prof_out[512 * 16 * KMO_PROF_PHASES];
 __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end on the constant-rate counter (s_memrealtime, 100 MHz), XCC id, -
 #define KMO_T(k)                                                              \
@@ -59,8 +59,12 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
         tlast = t_;                                                           \
         KM_SCHED_FENCE();                                                     \
     }
+#define KMO_PROF_PARAMS , unsigned long long (&prof)[KMO_PROF_PHASES], unsigned long long& tlast
+#define KMO_PROF_ARGS , prof, tlast
 #else
 #define KMO_T(k)
+#define KMO_PROF_PARAMS
+#define KMO_PROF_ARGS
 #endif
 
 #ifndef KMO_NT
@@ -83,10 +87,17 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #ifndef KMO_GM_LDS
 #define KMO_GM_LDS 1       // image-end sums of the matrix gradient through the (dead) source tile in LDS instead of nine wave reductions per wave
 #endif
+#ifndef KMO_RING_DESC
+#define KMO_RING_DESC 1    // the LDS ring holds DESCRIBED tiles (wave 0 derives every block-uniform field once per 64 tiles, lane = tile) instead of workspace records
+#endif
+#ifndef KMO_RED_ATOMIC
+#define KMO_RED_ATOMIC 1   // the maximum of |grad_out| over a pass through one LDS atomic word (two, alternating) instead of 16 wave partials read back by every wave
+#endif
 #ifndef KMO_SRC_AT
 #define KMO_SRC_AT 0       // slot of the scatter after which the next tile's source tile is requested
 #endif
 #define KMO_RUN 64         // records wave 0 fetches from the workspace at once (lane = tile), into alternating halves of a 2 x 64 ring
+#define KMO_RING_INTS (KMO_RING_DESC ? 32 : 20)  // ints per tile in the LDS ring
 #define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, first plane, matrix row, the 9 matrix entries, tile (tx, ty), (image, group), walk steps
 enum { KMO_F_FIXED = 1, KMO_F_REGULAR = 4, KMO_F_NONFINITE = 8 };
 
@@ -114,7 +125,7 @@ struct KmWarpFusedArgs {
 };
 
 __host__ __device__ constexpr int kmo_lds_bytes(int cc) {
-    return (KMT_BAND_W + KMT_TAB) * 16 + 2 * cc * KMO_PLANE * 4 + 2 * KMO_RUN * KMO_BOX_INTS * 4 + KMO_NW * 8 + KMO_NW * 9 * 8;
+    return (KMT_BAND_W + KMT_TAB) * 16 + 2 * cc * KMO_PLANE * 4 + 2 * KMO_RUN * KMO_RING_INTS * 4 + KMO_NW * 8 + KMO_NW * 9 * 8;
 }
 
 // One tile (everything block-uniform)
@@ -198,21 +209,23 @@ __device__ __forceinline__ void kmo_matrix(const int* rec, float (&m)[9]) {
     for (int k = 0; k < 9; ++k) m[k] = __int_as_float(rec[8 + k]);
 }
 // record of the q-th tile of this worker in the LDS ring
-__device__ __forceinline__ const int* kmo_ring(const int* s_box, uint32_t q) { return s_box + (q % (2u * KMO_RUN)) * KMO_BOX_INTS; }
+__device__ __forceinline__ const int* kmo_ring(const int* s_box, uint32_t q) { return s_box + (q % (2u * KMO_RUN)) * KMO_RING_INTS; }
 
-template <typename T>
+// U: the record is block-uniform (read through LDS / scalar registers); !U: one record per lane (kmo_fetch_boxes)
+template <typename T, bool U = true>
 __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t, const int* rec, KmoTile& d) {
     const KmWarpGeom<float>& g = a.g;
+    auto un = [](int v) { return U ? kmt_uniform(v) : v; };
     d = KmoTile{};
     d.t = t;
     if (t < 0) return;
     int tx, ty;
 #if KMO_REC_FIELDS
     {
-        const int txy = kmt_uniform(rec[17]);
+        const int txy = un(rec[17]);
         tx = txy & 0xffff; ty = (int)((uint32_t)txy >> 16);
-        d.b = kmt_uniform(rec[18]);
-        const int st = kmt_uniform(rec[19]);
+        d.b = un(rec[18]);
+        const int st = un(rec[19]);
         d.di = st & 0xffff; d.dj = (int)((uint32_t)st >> 16);
     }
 #else
@@ -220,15 +233,15 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
 #endif
     d.X0 = tx * KMT_TW; d.Y0 = ty * KMO_TH;
     d.TWc = min(d.X0 + KMT_TW, g.W) - d.X0; d.THc = min(d.Y0 + KMO_TH, g.H) - d.Y0;
-    d.j0 = kmt_uniform(rec[0]); d.j1 = kmt_uniform(rec[1]); d.i0 = kmt_uniform(rec[2]); d.i1 = kmt_uniform(rec[3]);
-    d.hb = kmt_uniform(rec[4]);
-    d.plane0 = kmt_uniform(rec[6]); d.bm = kmt_uniform(rec[7]);
-    const int fl = kmt_uniform(rec[5]);
+    d.j0 = un(rec[0]); d.j1 = un(rec[1]); d.i0 = un(rec[2]); d.i1 = un(rec[3]);
+    d.hb = un(rec[4]);
+    d.plane0 = un(rec[6]); d.bm = un(rec[7]);
+    const int fl = un(rec[5]);
     d.fixed_ok = (fl & KMO_F_FIXED) != 0; d.regular = (fl & KMO_F_REGULAR) != 0;
     const int bw = d.j1 - d.j0 + 1, bh = d.i1 - d.i0 + 1;
     d.bw = bw;
 #if !KMO_REC_FIELDS
-    d.di = kmt_uniform(KMO_NT / max(bw, 1)); d.dj = kmt_uniform(KMO_NT % max(bw, 1));
+    d.di = un(KMO_NT / max(bw, 1)); d.dj = un(KMO_NT % max(bw, 1));
 #endif
     d.nq = (bw > 0 && bh > 0) ? bw * bh : 0;
     d.p = 0;
@@ -242,8 +255,26 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
 template <typename T>
 __device__ __forceinline__ void kmo_fetch_boxes(const KmWarpFusedArgs<T>& a, uint32_t q0, int lane, int* s_box) {
     const int t = kmo_tile_of(a, q0 + (uint32_t)lane);
-    static_assert(KMO_BOX_INTS % 4 == 0, "16-byte pieces");
-    int4* dst = reinterpret_cast<int4*>(s_box) + (KMO_BOX_INTS / 4) * (((q0 / KMO_RUN) & 1u) * KMO_RUN + (uint32_t)lane);
+    static_assert(KMO_BOX_INTS % 4 == 0 && KMO_RING_INTS % 4 == 0, "16-byte pieces");
+    int4* dst = reinterpret_cast<int4*>(s_box) + (KMO_RING_INTS / 4) * (((q0 / KMO_RUN) & 1u) * KMO_RUN + (uint32_t)lane);
+#if KMO_RING_DESC
+    // The description of a tile is ~150 scalar instructions (and three LDS round trips) that all 16 waves of the workgroup executed for
+    // every tile, between the barrier and the scatter: here wave 0 derives it once, 64 tiles at a time in its vector lanes, and the
+    // tile loop reads the finished fields (kmo_load_desc).  Entries 8 .. 16 are the matrix, where kmo_matrix expects it.
+    KmoTile d;
+    const int* rec = a.ws + (size_t)max(t, 0) * KMO_BOX_INTS;
+    kmo_describe<T, false>(a, t, rec, d);
+    int4 mq[3] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+    if (t >= 0) { mq[0] = *reinterpret_cast<const int4*>(rec + 8); mq[1] = *reinterpret_cast<const int4*>(rec + 12); mq[2].x = rec[16]; }
+    const int flags = (d.fixed_ok ? 1 : 0) | (d.regular ? 2 : 0) | (d.svec ? 4 : 0) | (d.fvec ? 8 : 0);
+    dst[0] = make_int4(d.t, d.j0, d.i0, d.i1);
+    dst[1] = make_int4(d.hb, flags, d.plane0, d.bm);
+    dst[2] = mq[0];
+    dst[3] = mq[1];
+    dst[4] = make_int4(mq[2].x, d.X0, d.Y0, d.TWc);
+    dst[5] = make_int4(d.THc, d.bw, d.nq, d.di);
+    dst[6] = make_int4(d.dj, d.npass, d.b, d.j1);
+#else
     if (t >= 0) {
         const int4* rec = reinterpret_cast<const int4*>(a.ws + (size_t)t * KMO_BOX_INTS);
 #pragma unroll 1
@@ -252,7 +283,25 @@ __device__ __forceinline__ void kmo_fetch_boxes(const KmWarpFusedArgs<T>& a, uin
         dst[0] = make_int4(0, -1, 0, -1);
         dst[1] = make_int4(0, 0, 0, 0);
     }
+#endif
 }
+
+#if KMO_RING_DESC
+// the described tile at r (kmo_fetch_boxes) -> block-uniform registers: seven 16-byte LDS reads in flight together, no arithmetic
+__device__ __forceinline__ void kmo_load_desc(const int* r, KmoTile& d) {
+    const int4* p = reinterpret_cast<const int4*>(r);
+    const int4 a0 = p[0], a1 = p[1], a4 = p[4], a5 = p[5], a6 = p[6];
+    d.t = kmt_uniform(a0.x); d.j0 = kmt_uniform(a0.y); d.i0 = kmt_uniform(a0.z); d.i1 = kmt_uniform(a0.w);
+    d.hb = kmt_uniform(a1.x);
+    const int fl = kmt_uniform(a1.y);
+    d.fixed_ok = (fl & 1) != 0; d.regular = (fl & 2) != 0; d.svec = (fl & 4) != 0; d.fvec = (fl & 8) != 0;
+    d.plane0 = kmt_uniform(a1.z); d.bm = kmt_uniform(a1.w);
+    d.X0 = kmt_uniform(a4.y); d.Y0 = kmt_uniform(a4.z); d.TWc = kmt_uniform(a4.w);
+    d.THc = kmt_uniform(a5.x); d.bw = kmt_uniform(a5.y); d.nq = kmt_uniform(a5.z); d.di = kmt_uniform(a5.w);
+    d.dj = kmt_uniform(a6.x); d.npass = kmt_uniform(a6.y); d.b = kmt_uniform(a6.z); d.j1 = kmt_uniform(a6.w);
+    d.p = 0;
+}
+#endif
 
 // first pixel of this thread in a box of width bw walked as a linear list (element e = tid; tid < 2^24: the float quotient is off by at most one)
 __device__ __forceinline__ void kmo_first(int tid, int bw, int& qi, int& qj) {  // tid: element index (< 2^24)
@@ -659,7 +708,7 @@ __device__ __forceinline__ KmoLds kmo_carve(char* smem_raw) {
     l.s_acc = (int*)(l.s_v4 + KMT_TAB);                     // [CC][TH][TW] fixed-point accumulators
     l.s_src = (float*)(l.s_acc + CC * KMO_PLANE);           // [CC][TH][TW] the source tile (minus fill)
     l.s_box = (int*)(l.s_src + CC * KMO_PLANE);             // [2 KMO_RUN][KMO_BOX_INTS] ring of records of this worker's tiles
-    l.s_red = (uint32_t*)(l.s_box + 2 * KMO_RUN * KMO_BOX_INTS);  // [KMO_NW] (8-byte slots: keeps s_gm aligned)
+    l.s_red = (uint32_t*)(l.s_box + 2 * KMO_RUN * KMO_RING_INTS);  // [KMO_NW] (8-byte slots: keeps s_gm aligned)
     l.s_gm = (double*)(l.s_red + 2 * KMO_NW);               // [KMO_NW][9] matrix-gradient partials of a finished image
     return l;
 }
@@ -688,24 +737,37 @@ __device__ __forceinline__ void kmo_gm_commit(const double* s_gm, double* gmat_b
 // A tile whose requests have arrived: source tile -> LDS, exact maximum of |grad_out| over its box, coordinate tables
 template <typename T, int CM, int CC>
 __device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const KmoTile& d, const int* rec, const float (&G)[KMO_SLOTS][CC],
-                                          const float (&S)[CC * KMO_PLANE / KMO_NT], const KmoLds& l, const float (&fillv)[CC], bool is_fill, int lane, int wave) {
+                                          const float (&S)[CC * KMO_PLANE / KMO_NT], const KmoLds& l, const float (&fillv)[CC], bool is_fill, int lane, int wave, uint32_t par KMO_PROF_PARAMS) {
     // (no early exit for a tile this launch does not own: every path through here must CONSUME the slots and the source registers,
     // or the compiler - which cannot know that nothing was requested for such a tile - waits for them later, inside the scatter, with
     // a wait that also covers the next tile's requests)
     if (d.p == 0) kmo_store_src<CC>(d, S, l.s_src, fillv, is_fill);  // (later passes of a box: the tile is in LDS already, no request was made)
+    KMO_T(8)  // stage: source tile -> LDS
     uint32_t mb = 0;
 #pragma unroll
     for (int s = 0; s < KMO_SLOTS; ++s)
 #pragma unroll
         for (int c = 0; c < CC; ++c) mb = max(mb, __float_as_uint(G[s][c]) & 0x7fffffffu);
+#if KMO_RED_ATOMIC
+    // one word per work item (two, alternating): sixteen partials that every wave reads back become one atomic per wave here and one read
+    // after the barrier; the wave's maximum through DPP instead of six LDS round trips.  (All 64 lanes ATOMICALLY on the one word: + 12 %
+    // on the whole kernel - same-address lanes serialise; profiles/r04/bwd_fused_per_pixel_variants.txt, run 28.)
+    (void)wave;
+    mb = km_wave_umax_last(mb);
+    if (lane == 63) atomicMax(l.s_red + par, mb);
+#else
+    (void)par;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_down((int)mb, off, 64));
     if (lane == 0) l.s_red[wave] = mb;
+#endif
+    KMO_T(9)  // stage: maximum of |grad_out|
     if (d.t >= 0 && d.regular && d.nq > 0 && d.p == 0) {
         float m[9];
         kmo_matrix(rec, m);
         (void)kmo_fill_tables<CM>(a.g, m, d.j0, d.bw, d.i0, d.i1 - d.i0 + 1, l.s_u4, l.s_v4);
     }
+    KMO_T(10)  // stage: coordinate tables
 }
 
 // ---- launch 2: the persistent loop over the regular tiles -------------------------------------------------------------------------
@@ -725,9 +787,14 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
     // ---- prologue: records of the first tiles, accumulators zeroed, the first tile requested and staged ----
     if (wave == 0) kmo_fetch_boxes(a, 0u, lane, l.s_box);
     for (int e = tid; e < CC * KMO_PLANE / 4; e += KMO_NT) ((int4*)l.s_acc)[e] = make_int4(0, 0, 0, 0);
+    if (KMO_RED_ATOMIC && tid < 2) l.s_red[tid] = 0u;
     __syncthreads();
     KmoTile cur;
+#if KMO_RING_DESC
+    kmo_load_desc(kmo_ring(l.s_box, 0u), cur);
+#else
     kmo_describe(a, kmo_tile_of(a, 0u), kmo_ring(l.s_box, 0u), cur);
+#endif
     float G[KMO_SLOTS][CC];             // grad_out of this thread's pixels: the current tile's, refilled slot by slot with the next tile's
     float S[CC * KMO_PLANE / KMO_NT];   // this thread's part of the source tile on its way to LDS
 #pragma unroll
@@ -760,13 +827,13 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
     bool tile_ok = true;       // no non-finite gradient met so far
 
 #ifdef KMO_PROFILE
-    unsigned long long prof[KMO_PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof[KMO_PROF_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // A work item is (tile, pass): a box larger than the registers of the workgroup (KMO_CAP pixels: rotations beyond ~10 degrees,
     // magnification) is walked in several passes, the next pass requested slot by slot during the current one like a next tile.
-    for (uint32_t q = 0; cur.t >= 0;) {
+    for (uint32_t q = 0, item = 0; cur.t >= 0; ++item) {
         // ---- this item's requests have arrived: (first pass: source tile -> LDS, coordinate tables;) exact maximum of |grad_out| over the
         //      pass - consumed BEFORE the flush of the previous tile issues its stores (a wait for loads that has stores behind it in the
         //      queue waits for those too)
@@ -775,7 +842,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         KMO_T(0)  // wait for this item's requests
-        kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, fillv, is_fill, lane, wave);
+        kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, fillv, is_fill, lane, wave, item & 1u KMO_PROF_ARGS);
         KMO_T(1)  // stage: source tile -> LDS, maxima, tables
         // ---- flush of the previous tile (zeroes the accumulators) ----
         if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale, prev_discard);
@@ -790,11 +857,16 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         //      first slot of the scatter); its grad_out slot by slot during the scatter ----
         KmoTile nxt;
         if (last_pass) {
+#if KMO_RING_DESC
+            kmo_load_desc(kmo_ring(l.s_box, q + 1u), nxt);
+#else
             kmo_describe(a, kmo_tile_of(a, q + 1u), kmo_ring(l.s_box, q + 1u), nxt);
+#endif
         } else {
             nxt = cur;
             nxt.p = cur.p + 1;
         }
+        KMO_T(11)  // description: the next tile's fields
         const T* gout_n[CC];
 #pragma unroll
         for (int c = 0; c < CC; ++c) gout_n[c] = a.gout;
@@ -806,16 +878,22 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         } else {
             wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
         }
+        KMO_T(12)  // description: walk of the next box, plane pointers
         // matrix-gradient partials of the image finished before this tile
         if (pending_b >= 0) kmo_gm_commit<CM, (KMO_GM_LDS && CC * KMO_PLANE >= 9 * KMO_NT)>(l.s_gm, a.gmat ? a.gmat + (size_t)pending_b * 9 : nullptr, tid);
         pending_b = -1;
+        KMO_T(13)  // description: matrix-gradient commit
 
         // ---- the fixed-point scale: from the exact maximum of the first pass; a later pass with a larger one rescales the accumulators ----
         if (cur.p == 0) tile_ok = cur.regular;
         if (cur.regular && tile_ok) {
+#if KMO_RED_ATOMIC
+            uint32_t Mb = l.s_red[item & 1u];
+#else
             uint32_t Mb = l.s_red[0];
 #pragma unroll
             for (int w = 1; w < KMO_NW; ++w) Mb = max(Mb, l.s_red[w]);
+#endif
             Mb = (uint32_t)kmt_uniform((int)Mb);
             if (Mb >= 0x7f800000u) {
                 // NaN / inf in the box: IEEE float accumulation is the general launch's; mark the tile and leave it alone (what earlier
@@ -853,6 +931,8 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         KMO_T(5)  // scatter
         KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
         KMO_T(6)  // barrier B2
+        // (this item's maximum has been read by every wave; the word's next writers - the item after the next - are behind the next B1)
+        if (KMO_RED_ATOMIC && tid == 0) l.s_red[item & 1u] = 0u;
 
         if (last_pass) {
             // ---- an image that ends here publishes its matrix-gradient partials ----

@@ -26,7 +26,7 @@ def f():
                                  ws.data_ptr(), nbytes, stream), "bwd")
 t = bench.event_time_ms(f, 10)
 torch.cuda.synchronize()
-NW, PH = 16, 8   # (the table always has 16 wave slots per worker)
+NW, PH = 16, int(os.environ.get("LAB_PHASES", 16))   # (the table always has 16 wave slots per worker)
 workers = int(os.environ.get("LAB_WORKERS", 256))   # persistent workgroups of the launch (256 CUs x KMO_WG_PER_CU)
 waves = int(os.environ.get("LAB_WAVES", 16))         # waves per workgroup (KMO_NT / 64)
 TH = int(os.environ.get("LAB_TH", 64))               # KMO_TH
@@ -36,7 +36,10 @@ rc = raw.km_debug_fused_profile(out, 512 * NW * PH)
 a = np.frombuffer(out, dtype=np.uint64).reshape(512, NW, PH)[:workers, :waves].astype(np.float64)
 tiles_per_worker = B * (S // 64) * ((S + TH - 1) // TH) / workers
 names = ["wait for requests", "stage (src->LDS, max, tables)", "flush of previous tile", "barrier B1 (+ box records)", "describe next, gm commit, scale",
-         "scatter (+ next requests)", "barrier B2", "loop tail (image end sums)"]
+         "scatter (+ next requests)", "barrier B2", "loop tail (image end sums)",
+         "  stage: source tile -> LDS", "  stage: maximum of |grad_out|", "  stage: coordinate tables", "  describe: next tile's fields",
+         "  describe: walk, plane pointers", "  describe: matrix-gradient commit", "-", "-"]
+# (phases 8-14 are parts of the stage and of the description: with them phase 1 holds nothing and phase 4 only the scale)
 tot = a.sum(axis=2)
 print(f"rc {rc}  kernel+boxes+general {t:.4f} ms  B={B}  tiles/worker {tiles_per_worker:.1f}  cycles per wave (mean) {tot.mean():.0f} = {tot.mean()/tiles_per_worker:.0f} per tile"
       f"  -> {tot.mean()/ (t*1e-3) / 1e9:.2f} GHz if the loop is the whole launch")

@@ -194,11 +194,16 @@ inline float km_prev64(float v) {  // wave_shr:1
     memcpy(&r, &got, sizeof(float));
     return ok ? r : v;
 }
+inline uint32_t km_wave_umax_last(uint32_t v) {  // (km_common.h: valid in lane 63; here every lane gets the maximum)
+    for (unsigned off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(v, off, 64); v = o > v ? o : v; }
+    return __shfl(v, 0, 64);
+}
 inline int emu_readfirstlane(int v) {
     bool ok = false;
     return (int)(uint32_t)emu::wave_exchange((uint64_t)(uint32_t)v, -1, &ok);
 }
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)  // (issue priority of a wave: no meaning for results)
 inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred != 0); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __all(int pred) { return emu::wave_ballot(pred == 0) == 0ull; }  // no live lane with a false predicate
