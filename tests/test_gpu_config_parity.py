@@ -83,6 +83,30 @@ def test_config2_whole_batch_256_against_the_oracle_at_full_size(oracle):
     assert per_image <= 5e-5, per_image
 
 
+def test_config2_image_gradient_is_bit_identical_from_run_to_run_at_full_size():
+    """A size-independent property of the fixed-point accumulation: integer adds commute, so the image gradient of the
+    one-read backward does not depend on the order in which the 256 persistent workgroups and their 16 waves reach a tile - five
+    backward passes over the same tensors (the batch traversal alternates between them) give the same bits; the matrix gradient (fp64
+    atomics over the tiles of an image, rounded to fp32 once) agrees to 1e-6 of its largest entry."""
+    import kornia_amd as K
+
+    B, S = 256, 512
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(B, 3, S, S, generator=g).cuda()
+    M = flagship_homographies(B, S, S, S, S, g).cuda()
+    go = torch.rand(B, 3, S, S, generator=g).cuda()
+    first = None
+    for _ in range(5):
+        xg, Mg = x.clone().requires_grad_(), M.clone().requires_grad_()
+        K.warp_perspective(xg, Mg, (S, S)).backward(go)
+        if first is None:
+            first = (xg.grad.clone(), Mg.grad.clone())
+            continue
+        assert torch.equal(xg.grad, first[0])
+        scale = first[1].abs().amax(dim=(-2, -1), keepdim=True)
+        assert ((Mg.grad - first[1]).abs() / scale).max().item() <= 1e-6  # (the fp64 sums are rounded to fp32 once: a last-bit difference at most)
+
+
 def test_config2_512_rotated_and_scaled_homographies(oracle):
     """Same size, matrices far from the identity (rotation, 0.6x - 1.7x scale, strong perspective): the owner-tile boxes of the
     backward and the wave-uniform fast paths of the forward take their other branches."""
