@@ -5,6 +5,8 @@
 // augmentation pipeline - as ONE launch that never writes the warped image: 5e bytes per element for the fused op's forward + backward against
 // 9e for the two ops ("report it if fusion is added").  A separate public op (kornia_amd.geometry.transform.warp_perspective_blur &
 // co.), reported separately by bench.py; the two-op path stays what the headline times.
+// Built with -fno-slp-vectorize (kornia_amd/build.py): the kernel is bound by its vector work, and the SLP vectorizer's packed pairs cost more
+// issue time than they save once the moves that feed them are counted (0.546 / 0.549 against 0.555 / 0.561 ms, profiles/r04/run39_*).
 //
 // A 256-thread block owns a 64 x 32 tile of the OUTPUT of the blur.  It needs the warped image on the tile grown by the blur's reach L =
 // (K - 1) / 2 on every side - border pixels of that region are the warped image at the indices F.pad would read (reflect / replicate /

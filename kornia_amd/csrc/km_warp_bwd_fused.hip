@@ -93,6 +93,9 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #ifndef KMO_RED_ATOMIC
 #define KMO_RED_ATOMIC 1   // the maximum of |grad_out| over a pass through one LDS atomic word (two, alternating) instead of 16 wave partials read back by every wave
 #endif
+#ifndef KMO_FLUSH_STRAIGHT
+#define KMO_FLUSH_STRAIGHT 1  // full tiles: the flush's three accumulator reads in flight together (one LDS round trip instead of three)
+#endif
 #ifndef KMO_SRC_AT
 #define KMO_SRC_AT 0       // slot of the scatter after which the next tile's source tile is requested
 #endif
@@ -649,6 +652,32 @@ __device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const Kmo
     const int tid = threadIdx.x;
     const size_t src_plane = (size_t)g.H * g.W;
     float* gsrc_b = a.gsrc + (size_t)d.plane0 * src_plane;
+#if KMO_FLUSH_STRAIGHT
+    if (d.fvec && d.THc == KMO_TH && finite && KMO_TH * KMT_TW / 4 == KMO_NT) {
+        // a full tile: one 16-byte piece per thread and channel, the reads of all channels in flight together (- 1 % on the kernel:
+        // profiles/r04/bwd_fused_latency_variants.txt, runs 34 and 38)
+        int4 q[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) q[c] = reinterpret_cast<const int4*>(s_acc + c * KMO_PLANE)[tid];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) reinterpret_cast<int4*>(s_acc + c * KMO_PLANE)[tid] = make_int4(0, 0, 0, 0);
+        if (discard) return;
+        float* outp = gsrc_b + (size_t)(d.Y0 + (tid >> 4)) * g.W + (d.X0 + (tid & 15) * 4);
+#pragma unroll
+        for (int c = 0; c < CC; ++c, outp += src_plane) {
+            KM_CHECK_ALIGNED(outp, 16);
+            const float4 v = make_float4((float)q[c].x * inv_scale, (float)q[c].y * inv_scale, (float)q[c].z * inv_scale, (float)q[c].w * inv_scale);
+            if (a.stream_out) {
+                typedef float km_f4v __attribute__((ext_vector_type(4)));
+                km_f4v vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
+                __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v*>(outp));
+            } else {
+                *reinterpret_cast<float4*>(outp) = v;
+            }
+        }
+        return;
+    }
+#endif
     if (d.fvec) {
         // full-width tile, 16-byte aligned rows: 16 lanes x 16 bytes cover a tile row, a wave writes 4 rows per store
         const int col4 = (tid & 15) * 4, row0 = tid >> 4;
