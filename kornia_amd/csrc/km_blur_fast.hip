@@ -25,14 +25,22 @@
 #ifdef KMB_ROWS_OVERRIDE
 #define KMB_ROWS KMB_ROWS_OVERRIDE
 #else
-#define KMB_ROWS 32  // output rows per thread (strip height); measured at 256x3x512^2: 8 -> 0.32 ms, 16 -> 0.31, 32 -> 0.295, 64 -> 0.31
+#define KMB_ROWS 32  // output rows per thread (strip height) of the large form
 #endif
-// A wave walks its strip row by row, so a launch with few waves per SIMD (BASELINE config 3's 256x3x224^2: 5376 strips of 32 rows on 1024
-// SIMDs) has little to overlap its row loads with.  For the 16-bit storage types such launches use strips of KMB_ROWS_SMALL rows - 4x the
-// waves, (8 + K - 1) / 8 instead of (32 + K - 1) / 32 input rows per output row, the extra ones L2 hits: bf16 256x3x224^2 56.2 -> 52.0 us.
-// fp32 does not gain (224^2: 53.5 -> 56.5 us, 64x3x512^2: 64 -> 78 us: twice the bytes per row, the halo re-reads cost more) and keeps 32.
+// A wave walks its strip row by row: (ROWS + K - 1) / ROWS input rows are read per output row (the extra ones mostly L2 hits), and a launch with few
+// waves per SIMD has little to overlap its row loads with.  Three strip heights are compiled - 32, 16 and 8 rows - and km_blur_rows() picks one per
+// launch from what profiles/r04/run49_blur_strip_heights.txt measured (round 2 had measured 8 -> 0.32 ms, 16 -> 0.31, 32 -> 0.295 at 256x3x512^2 on the
+// kernel of that round; with the row loads one row ahead, round 4, the forward is fastest at 16):
+//   fp32   few waves (16x3x512^2: 37.2 -> 24.6 us forward, 44.5 -> 30.8 adjoint; 4x3x512^2: 21.0 -> 13.1): 16
+//          K = 3: 16 (294-307 -> 278-281 us forward, 297-309 -> 280-283 adjoint); K = 5: forward 16 (298-302 -> 290-291), adjoint 32 (295-298 against
+//          305); K >= 7: 32 (the adjoint's position-dependent taps: K = 7 413 against 464 us, K = 9 824 against 1 031)
+//   16-bit few waves (256x3x224^2, BASELINE config 3): forward 8 (56.2 -> 52.0 us, round 3), adjoint 16 (81.1 -> 70.8); else 32 (256x3x512^2: 201 / 229
+//          against 211 / 258 us with 16)
+// The arithmetic per output pixel is the same in all three: bit-identical results (tests force each height: KM_BLUR_ROWS / km_config_set).
+#define KMB_ROWS_MID 16
 #define KMB_ROWS_SMALL 8
-#define KMB_SMALL_BELOW_WAVES 8192  // 8 waves per SIMD of the 32-row form
+#define KMB_SMALL_BELOW_WAVES 8192  // 16-bit: 8 waves per SIMD of the 32-row form
+#define KMB_FEW_WAVES_F32 4096       // fp32: 4 waves per SIMD of the 32-row form
 
 template <typename T>
 struct KmVec4;
@@ -65,7 +73,7 @@ struct KmBlurArgs {
     uint32_t bx, by;     // blocks per plane in x / y
     uint32_t nblocks;
     uint32_t reverse;    // the XCDs walk their block ranges backwards (km_traversal_next)
-    uint32_t small;      // strips of KMB_ROWS_SMALL rows (host-side choice of the instantiation)
+    uint32_t rows;       // strip height of the launch (host-side choice of the instantiation: KMB_ROWS, KMB_ROWS_MID or KMB_ROWS_SMALL)
     uint32_t stream_out; // streaming stores (km_stream_stores)
 };
 
@@ -250,20 +258,28 @@ __global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a)
     }
 }
 
+template <typename T, int K, int ROWS>
+static void km_blur_launch_rows(bool bwd, const KmBlurArgs<T>& a, hipStream_t s) {
+    if (bwd)
+        hipLaunchKernelGGL((km_blur_reg_kernel<T, K, true, ROWS>), dim3(a.nblocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((km_blur_reg_kernel<T, K, false, ROWS>), dim3(a.nblocks), dim3(256), 0, s, a);
+}
 template <typename T, int K>
 static int km_blur_launch(bool bwd, const KmBlurArgs<T>& a, hipStream_t s) {
-    if (a.small) {
-        if constexpr (sizeof(T) == 2) {  // (the caller sets `small` for the 16-bit types only)
-            if (bwd)
-                hipLaunchKernelGGL((km_blur_reg_kernel<T, K, true, KMB_ROWS_SMALL>), dim3(a.nblocks), dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL((km_blur_reg_kernel<T, K, false, KMB_ROWS_SMALL>), dim3(a.nblocks), dim3(256), 0, s, a);
-        }
-    } else if (bwd)
-        hipLaunchKernelGGL((km_blur_reg_kernel<T, K, true>), dim3(a.nblocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((km_blur_reg_kernel<T, K, false>), dim3(a.nblocks), dim3(256), 0, s, a);
+    if (a.rows == KMB_ROWS_SMALL) km_blur_launch_rows<T, K, KMB_ROWS_SMALL>(bwd, a, s);
+    else if (a.rows == KMB_ROWS_MID) km_blur_launch_rows<T, K, KMB_ROWS_MID>(bwd, a, s);
+    else km_blur_launch_rows<T, K, KMB_ROWS>(bwd, a, s);
     return km_check_launch(bwd ? "km_blur_reg_bwd" : "km_blur_reg_fwd");
+}
+
+// strip height of a launch (see the table at KMB_ROWS); `force`: KM_BLUR_ROWS / km_config_set("blur_rows") = 8 / 16 / 32
+static int km_blur_rows(bool bwd, size_t elem, int K, uint64_t waves_big, int force) {
+    if (force == KMB_ROWS_SMALL || force == KMB_ROWS_MID || force == KMB_ROWS) return force;
+    if (elem == 2) return waves_big < KMB_SMALL_BELOW_WAVES ? (bwd ? KMB_ROWS_MID : KMB_ROWS_SMALL) : KMB_ROWS;
+    if (waves_big < KMB_FEW_WAVES_F32 || K == 3) return KMB_ROWS_MID;
+    if (K == 5) return bwd ? KMB_ROWS : KMB_ROWS_MID;
+    return KMB_ROWS;
 }
 
 template <typename T>
@@ -274,10 +290,10 @@ static int km_blur_run(bool bwd, const void* x, const void* kx, const void* ky, 
     a.C = C; a.H = H; a.W = W; a.Bk = Bk; a.border = border;
     a.groups_x = (uint32_t)(W / 4);
     a.bx = (a.groups_x + 63) / 64;
-    const int force_rows = km_config().blur_rows;  // 8 / 32: forces the instantiation (tests, A/B timing: KM_BLUR_ROWS / km_config_set)
+    const int force_rows = km_config().blur_rows;  // 8 / 16 / 32: forces the instantiation (tests, A/B timing: KM_BLUR_ROWS / km_config_set)
     const uint64_t waves_big = (uint64_t)a.bx * (uint64_t)((H + KMB_ROWS - 1) / KMB_ROWS) * (uint64_t)B * C;
-    a.small = sizeof(T) != 2 ? 0u : (force_rows ? (force_rows == KMB_ROWS_SMALL ? 1u : 0u) : (waves_big < KMB_SMALL_BELOW_WAVES ? 1u : 0u));
-    const int rows = a.small ? KMB_ROWS_SMALL : KMB_ROWS;
+    const int rows = km_blur_rows(bwd, sizeof(T), K, waves_big, force_rows);
+    a.rows = (uint32_t)rows;
     a.by = (uint32_t)((H + 4 * rows - 1) / (4 * rows));
     const uint64_t nb = (uint64_t)a.bx * a.by * (uint64_t)B * C;
     KM_REQUIRE(nb < (1ull << 31), "km_blur: grid too large");

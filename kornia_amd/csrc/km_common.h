@@ -314,7 +314,7 @@ struct KmConfig {
     int sep_lds;            // KM_SEP_ALGO=lds
     int sg_generic;         // KM_SG_ALGO=generic
     int pyrdown_separable;  // KM_PYRDOWN_ALGO=separable
-    int blur_rows;          // KM_BLUR_ROWS=8 / 32 (0: by the size of the launch)
+    int blur_rows;          // KM_BLUR_ROWS=8 / 16 / 32 (0: by storage type, direction, kernel size and size of the launch: km_blur_rows)
 };
 const KmConfig& km_config();
 int km_device_cus();

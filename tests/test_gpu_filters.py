@@ -301,8 +301,8 @@ def test_half_precision_blur(oracle, dtype, tol):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("K,border,shape", [(5, "reflect", (2, 3, 70, 72)), (3, "constant", (3, 1, 37, 128)), (7, "replicate", (1, 2, 64, 264)), (9, "circular", (2, 1, 41, 16))])
 def test_half_precision_blur_strip_heights(dtype, K, border, shape, monkeypatch):
-    """16-bit storage: launches with few waves per SIMD use 8-row strips instead of 32-row ones (km_blur_fast.hip).  Same arithmetic per
-    output pixel, so forward and adjoint are bit-identical between the two forms."""
+    """The strip height of a launch is chosen from storage type, direction, kernel size and the number of waves (km_blur_fast.hip
+    km_blur_rows: 32, 16 or 8 rows).  Same arithmetic per output pixel, so forward and adjoint are bit-identical between the three forms."""
     import kornia_amd as K_
 
     g = torch.Generator().manual_seed(11)
@@ -312,7 +312,7 @@ def test_half_precision_blur_strip_heights(dtype, K, border, shape, monkeypatch)
     from kornia_amd import _native as N
 
     res = {}
-    for rows in ("8", "32"):
+    for rows in ("8", "16", "32"):
         prev = N.lib().km_config_set(b"blur_rows", int(rows))  # (the KM_BLUR_ROWS switch: read once at load, set explicitly here)
         try:
             xg = x.clone().requires_grad_()
@@ -322,6 +322,7 @@ def test_half_precision_blur_strip_heights(dtype, K, border, shape, monkeypatch)
             N.lib().km_config_set(b"blur_rows", prev)
         res[rows] = (out.detach(), xg.grad)
     assert torch.equal(res["8"][0], res["32"][0]) and torch.equal(res["8"][1], res["32"][1])
+    assert torch.equal(res["16"][0], res["32"][0]) and torch.equal(res["16"][1], res["32"][1])
     ref = K_.filter2d_separable(x.float(), kx, ky, border)
     # against the fp32 evaluation: two roundings to the storage type (row pass, result), relative to the largest value
     assert (res["8"][0].float() - ref).abs().max().item() <= (1.2e-2 if dtype == torch.bfloat16 else 2e-3) * ref.abs().max().item()
@@ -331,11 +332,11 @@ def test_half_precision_blur_strip_heights(dtype, K, border, shape, monkeypatch)
 @pytest.mark.parametrize("K", [3, 5, 7, 9])
 @pytest.mark.parametrize("Bk", [1, "B"])
 @pytest.mark.parametrize("border", BORDERS)
-@pytest.mark.parametrize("rows", ["8", "32"])
+@pytest.mark.parametrize("rows", ["8", "16", "32"])
 def test_register_tiled_blur_fast_path(oracle, border, Bk, K, shape, rows, monkeypatch):
     """W % 4 == 0, square odd K <= 9: served by csrc/km_blur_fast.hip (no LDS). Forward bit-exact;
-    the adjoint against the oracle's scatter-form adjoint.  KM_BLUR_ROWS: see test_half_precision_blur_strip_heights (fp32 always
-    takes 32-row strips; the variable must not change anything here)."""
+    the adjoint against the oracle's scatter-form adjoint.  KM_BLUR_ROWS: each of the three strip heights (see
+    test_half_precision_blur_strip_heights), against the oracle."""
     import kornia_amd as K_
     from kornia_amd import _native as N
 
