@@ -34,12 +34,12 @@
 //   fp32   few waves (16x3x512^2: 37.2 -> 24.6 us forward, 44.5 -> 30.8 adjoint; 4x3x512^2: 21.0 -> 13.1): 16
 //          K = 3: 16 (294-307 -> 278-281 us forward, 297-309 -> 280-283 adjoint); K = 5: forward 16 (298-302 -> 290-291), adjoint 32 (295-298 against
 //          305); K >= 7: 32 (the adjoint's position-dependent taps: K = 7 413 against 464 us, K = 9 824 against 1 031)
-//   16-bit few waves (256x3x224^2, BASELINE config 3): forward 8 (56.2 -> 52.0 us, round 3), adjoint 16 (81.1 -> 70.8); else 32 (256x3x512^2: 201 / 229
-//          against 211 / 258 us with 16)
+//   16-bit 32 (256x3x512^2: 201 / 229 us forward / adjoint against 211 / 258 with 16; 256x3x224^2, BASELINE config 3: 54-56 / 62 us against 56-58 / 71 with
+//          16 and 55-58 / 82 with 8 - round 3's kernel had gained from 8-row strips for such launches, 56.2 -> 52.0 us; with the row loads one row ahead
+//          it no longer does: profiles/r04/run49_blur_strip_heights.txt, second table)
 // The arithmetic per output pixel is the same in all three: bit-identical results (tests force each height: KM_BLUR_ROWS / km_config_set).
 #define KMB_ROWS_MID 16
 #define KMB_ROWS_SMALL 8
-#define KMB_SMALL_BELOW_WAVES 8192  // 16-bit: 8 waves per SIMD of the 32-row form
 #define KMB_FEW_WAVES_F32 4096       // fp32: 4 waves per SIMD of the 32-row form
 
 template <typename T>
@@ -276,7 +276,7 @@ static int km_blur_launch(bool bwd, const KmBlurArgs<T>& a, hipStream_t s) {
 // strip height of a launch (see the table at KMB_ROWS); `force`: KM_BLUR_ROWS / km_config_set("blur_rows") = 8 / 16 / 32
 static int km_blur_rows(bool bwd, size_t elem, int K, uint64_t waves_big, int force) {
     if (force == KMB_ROWS_SMALL || force == KMB_ROWS_MID || force == KMB_ROWS) return force;
-    if (elem == 2) return waves_big < KMB_SMALL_BELOW_WAVES ? (bwd ? KMB_ROWS_MID : KMB_ROWS_SMALL) : KMB_ROWS;
+    if (elem == 2) return KMB_ROWS;
     if (waves_big < KMB_FEW_WAVES_F32 || K == 3) return KMB_ROWS_MID;
     if (K == 5) return bwd ? KMB_ROWS : KMB_ROWS_MID;
     return KMB_ROWS;
