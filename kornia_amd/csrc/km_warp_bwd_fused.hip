@@ -1318,7 +1318,8 @@ static int kmo_run(const void* gout, const void* src, const void* mat, void* gsr
     const uint64_t per_image = (uint64_t)a.tiles_x * a.tiles_y;
     KM_REQUIRE(per_image * (uint64_t)B * (a3 > r1 ? a3 : r1) < (1ull << 26) && (uint64_t)B * (uint64_t)C < (1ull << 31) && a.tiles_x < 65536u && a.tiles_y < 65536u,
                "km_warp2d_bwd: grid too large");
-    if (per_image * (uint64_t)B == 0 || C == 0) return (int)hipMemsetAsync(gmat, 0, (size_t)B_M * 9 * sizeof(double), s);  // (nothing to add: the accumulators are still this path's to zero)
+    if (per_image * (uint64_t)B == 0 || C == 0)  // (nothing to add: the accumulators are still this path's to zero; gmat == nullptr: image gradient only)
+        return (gmat && B_M > 0) ? (int)hipMemsetAsync(gmat, 0, (size_t)B_M * 9 * sizeof(double), s) : 0;
     a.reverse = km_traversal_next(s);
     a.stream_out = km_stream_stores((uint64_t)B * C * H * W * sizeof(float));
     int rc = 0;

@@ -69,6 +69,9 @@ def _warp_blur(src, M, dsize, coord_mode, kernel_size, sigma, border_type, mode,
         isinstance(src, torch.Tensor) and isinstance(M, torch.Tensor) and src.dim() == 4 and N.on_device(src) and isinstance(sigma, tuple)
         and kx == ky and str(border_type).lower() in _BORDER_CODE and src.dtype in (torch.float32, torch.bfloat16, torch.float16)
         and M.dim() == 3 and (M.shape[0] == src.shape[0] or (M.shape[0] == 1 and coord_mode == COORD_AFFINE))
+        # the matrix shape of THIS op (anything else takes the two calls, whose own argument checks raise what the reference raises)
+        and tuple(M.shape[-2:]) == ((2, 3) if coord_mode == COORD_AFFINE else (3, 3))
+        and isinstance(dsize, (tuple, list)) and len(dsize) == 2
     )
     if fusable:
         interp, pad = _mode_codes(mode, padding_mode)

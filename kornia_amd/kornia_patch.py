@@ -269,7 +269,11 @@ def _affine_compute(original: Callable) -> Callable:
             return original(self, input, params, flags)
         height, width = int(input.shape[-2]), int(input.shape[-1])
         m, M, _ = _aug.affine_chain({k: params[k] for k in keys}, input.device, height, width, with_matrix=True)
-        self._kornia_amd_chain = (weakref.ref(params["angle"]), m, height, width)
+        # parked only for the warp that transform_inputs runs next on the same image: an image that requires a gradient goes through the
+        # module's own apply_transform (below), which would leave the chain behind for a later, unrelated call (inverse_transform hands
+        # over the same parameter tensors with the INVERSE matrix)
+        if not (torch.is_grad_enabled() and input.requires_grad):
+            self._kornia_amd_chain = (weakref.ref(params["angle"]), m, height, width)
         return M.to(input.dtype)
 
     compute_transformation.__wrapped__ = original
@@ -288,6 +292,11 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
 
     @functools.wraps(original)
     def apply_transform(self, input, params, flags, transform=None):
+        # the matrix parked by compute_transformation (_affine_compute) serves exactly ONE call - this one, whatever path it takes:
+        # taken off the module before any fall-through, so that no later call (inverse_transform, a direct apply_transform) finds it
+        chain = getattr(self, "_kornia_amd_chain", None)
+        if chain is not None:
+            self._kornia_amd_chain = None
         ok = (
             isinstance(input, torch.Tensor) and isinstance(transform, torch.Tensor) and _N.on_device(input) and _N.on_device(transform)
             and input.dim() == 4 and input.dtype in _COLOR_DTYPES and transform.dim() == 3 and tuple(transform.shape[-2:]) == (3, 3)
@@ -313,11 +322,11 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
             fill_value = flags.get("fill_value")
             if padding_mode == "fill" and fill_value is None:
                 fill_value = torch.zeros(input.shape[1], device=input.device, dtype=input.dtype)
-            chain = getattr(self, "_kornia_amd_chain", None)
-            self._kornia_amd_chain = None
             angle = params.get("angle") if hasattr(params, "get") else None
-            if (chain is not None and angle is not None and chain[0]() is angle and chain[2:] == (height, width) and chain[1].shape[0] == B
-                    and input.dtype == torch.float32):
+            # (only inside transform_inputs - the forward call that compute_transformation preceded; inverse_transform and direct calls
+            # bring their own `transform`, which is the one to warp with)
+            if (chain is not None and _switch_allowed() and angle is not None and chain[0]() is angle and chain[2:] == (height, width)
+                    and chain[1].shape[0] == B and input.dtype == torch.float32):
                 # the matrix the warp reads came out of compute_transformation's own launch (_affine_compute): straight to the sampler.
                 # (16-bit images: the reference rounds the pixel matrix to the image dtype before the warp sees it, so those take the chain
                 # of the rounded matrix below - the same bits as before this shortcut existed)

@@ -2,7 +2,7 @@
 
 Only usable inside the build container (``/root/reference`` does not exist on the GPU box).
 It is used by ``oracle/make_golden.py`` to generate the committed fixtures under
-``tests/golden/`` and by ``tests/test_oracle_vs_reference.py`` (auto-skipped when the
+``tests/golden/`` and by ``tests/test_patch_reference.py`` (auto-skipped when the
 reference tree is absent).  Nothing in the product path (``kornia_amd/``) imports this.
 
 The reference needs Python >= 3.11 (``enum.StrEnum`` kornia/config.py:20, ``enum.member``

@@ -5,7 +5,8 @@ sequence of torch ops (``F.grid_sample``, ``F.pad``, ``F.conv2d`` ...).  This mo
 sequence (citing the reference lines) so that the GPU box - where ``/root/reference`` does not
 exist but PyTorch does - can (a) time "the reference's CPU path" on its host cores for
 ``bench.py``'s ``cpu_baseline`` leg and (b) cross-check the C oracle at sizes with no committed
-fixture.  It is validated against the real reference in ``tests/test_oracle_vs_reference.py``.
+fixture.  It is validated against the real reference in ``tests/test_oracle_golden.py`` (against the fixtures the real
+reference wrote, ``oracle/make_golden.py``).
 
 Never imported by the product path.
 """

@@ -6,6 +6,7 @@
 #   bench:N        the driver's command verbatim (`python3 bench.py --gpus 1 --steps 20 --warmup 5`) N times, every JSON line kept
 #   benchlite:N    the same without cpu baseline / other configs (A/B of libraries: KORNIA_AMD_LIB is honoured)
 #   prof           rocprofv3 --kernel-trace --stats of the bench command, then FETCH_SIZE / WRITE_SIZE in separate --pmc passes
+#   units          unit counters (separate --pmc passes) of the four hot launches + km_points -> <run-name>_units/ (pmc_units_to_json.py)
 #   py:<script>    python <script> (a profiles/time_*.py), output appended to the run log
 #   rocprof:<script>   the same under rocprofv3 --kernel-trace --stats, per-kernel table appended to the run log
 #   ab:<script>:<lib1>,<lib2>,...   python <script> once per library under kornia_amd/lib/var (name without lib_/.so; "default" = the shipped one)
@@ -55,6 +56,9 @@ for stage in "$@"; do
       ;;
     py:*)
       run python ${stage#py:}
+      ;;
+    units)       # SQ / TA / TCP / TCC / GRBM counters of the hot kernels + km_points (profiles/pmc_units.sh, profiles/pmc_step.py)
+      run bash profiles/pmc_units.sh $D/${RUN}_units
       ;;
     rocprof:*)   # rocprofv3 --kernel-trace --stats of python <script>; the km_* rows of the stats table go to the run log
       script=${stage#rocprof:}; P=$D/${RUN}_rocprof_$(basename $script .py); rm -rf $P; mkdir -p $P

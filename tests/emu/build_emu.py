@@ -15,7 +15,10 @@ EMU = os.path.join(ROOT, "tests", "emu")
 ASAN = os.environ.get("KM_EMU_ASAN", "") not in ("", "0")
 # KM_EMU_UBSAN=1: UndefinedBehaviorSanitizer build (signed overflow in index arithmetic, misaligned typed accesses, bad shifts ...)
 UBSAN = os.environ.get("KM_EMU_UBSAN", "") not in ("", "0")
-_TAG = "_asan" if ASAN else ("_ubsan" if UBSAN else "")
+# KM_EMU_DEFS="-DKMB_UPDOWN=1 ...": extra preprocessor definitions (variant builds of the kernels, as profiles/build_variant2.sh makes for the
+# device), in a build directory of their own
+DEFS = os.environ.get("KM_EMU_DEFS", "").split()
+_TAG = ("_asan" if ASAN else ("_ubsan" if UBSAN else "")) + ("_" + "".join(c if c.isalnum() else "_" for c in "".join(DEFS)) if DEFS else "")
 OUT = os.path.join(ROOT, "tests", "_build", "emu" + _TAG)
 LIB = os.path.join(ROOT, "tests", "_build", f"libkornia_amd_emu{_TAG}.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
@@ -39,6 +42,7 @@ def _flags() -> list[str]:
         cpu = open("/proc/cpuinfo").read()
     except OSError:
         cpu = ""
+    flags += DEFS
     if ASAN:
         flags += ["-fsanitize=address", "-fno-omit-frame-pointer", "-g1"]
     if UBSAN:

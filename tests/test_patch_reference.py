@@ -353,3 +353,49 @@ def test_random_affine_is_two_launches_under_patch_on_the_host_build():
                 assert getattr(aug, "_kornia_amd_chain", None) is None  # consumed by the apply step
         finally:
             assert P.unpatch() == n
+
+
+def test_parked_affine_chain_never_outlives_its_call_on_the_host_build():
+    """The matrix that compute_transformation parks for the warp of the same forward call (km_affine_params_chain_fwd) must not be found by
+    any later call.  (a) A forward on an image that requires a gradient goes through the module's own apply_transform: nothing may stay
+    parked, and `aug.inverse(y)` afterwards - same parameter tensors, the INVERSE matrix - must warp with the matrix it is handed.  (b) A direct
+    compute_transformation() followed by inverse() the same.  Both compared with the unpatched module on the same parameters."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("host build of the kernels needs ROCm's clang++")
+    K = ref_shim.import_reference()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    from mode import emulated_device
+
+    import kornia_amd.kornia_patch as P
+
+    A = K.augmentation
+    x = torch.rand(4, 3, 40, 56, generator=torch.Generator().manual_seed(5))
+    torch.manual_seed(33)
+    ref_aug = A.RandomAffine(degrees=25.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=1.0)
+    ref_y = ref_aug(x)
+    params = ref_aug._params
+    ref_inv = ref_aug.inverse(ref_y)
+    assert (ref_inv - ref_y).abs().max() > 1e-2  # (the inverse warp is not the forward one: the comparison below can tell them apart)
+    with emulated_device():
+        n = P.patch()
+        try:
+            dev_params = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in params.items()}
+            # (a) grad-enabled forward, then inverse under no_grad
+            aug = A.RandomAffine(degrees=25.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=1.0)
+            xg = x.cuda().requires_grad_()
+            y = aug(xg, params=dev_params)
+            assert getattr(aug, "_kornia_amd_chain", None) is None
+            assert torch.allclose(y.detach(), ref_y, atol=2e-5, rtol=0)
+            with torch.no_grad():
+                inv = aug.inverse(y.detach())
+            assert torch.allclose(inv, ref_inv, atol=5e-5, rtol=0), (inv - ref_inv).abs().max()
+            # (b) a direct compute_transformation() (parks), then inverse(): the parked forward matrix must not be the one used
+            aug = A.RandomAffine(degrees=25.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=1.0)
+            with torch.no_grad():
+                y = aug(x.cuda(), params=dev_params)
+                aug.compute_transformation(x.cuda(), aug._params, aug.flags)
+                inv = aug.inverse(y)
+            assert torch.allclose(inv, ref_inv, atol=5e-5, rtol=0), (inv - ref_inv).abs().max()
+            assert getattr(aug, "_kornia_amd_chain", None) is None
+        finally:
+            assert P.unpatch() == n
