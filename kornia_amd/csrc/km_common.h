@@ -291,6 +291,29 @@ __device__ __forceinline__ uint32_t km_xcd_remap(uint32_t bid, uint32_t nblocks,
     return start + (reverse ? count - 1u - k : k);
 }
 
+// LDS-DMA (gfx950 global_load_lds_dwordx4 / _dword): every lane names a 16-byte (4-byte) piece of global memory; the wave's pieces land in
+// LDS at lds_wave_base + lane * 16 (* 4) - straight from the memory pipe, no vector register, no ds_write.  Issued as inline assembly
+// (M0 carries the LDS byte address: saved, set, restored in the one statement), so the COMPILER DOES NOT KNOW the operation exists: it
+// neither waits for it nor orders LDS reads behind it - the kernel does, with `KM_VMCNT0()` (the operation counts in vmcnt like any load,
+// and loads complete in order) and a barrier before another wave reads the piece.  lds_wave_base: a pointer into LDS, the same in every
+// lane of the wave.  (The host build of the kernels supplies functions with the same effect.)
+#ifndef KM_GLDS16
+__device__ __forceinline__ uint32_t km_lds_addr(const void* p) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p);
+}
+__device__ __forceinline__ void km_glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void km_glds4(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#define KM_GLDS16(gsrc, lds_wave_base) km_glds16((const void*)(gsrc), km_lds_addr(lds_wave_base))
+#define KM_GLDS4(gsrc, lds_wave_base) km_glds4((const void*)(gsrc), km_lds_addr(lds_wave_base))
+#define KM_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // Scheduling fence: the compiler does not move instructions across it (no code is emitted).  Used between independent unrolled
 // bodies whose interleaving would raise the register count (the host build of the kernels defines it away).
 #ifndef KM_SCHED_FENCE

@@ -99,7 +99,16 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #ifndef KMO_SRC_AT
 #define KMO_SRC_AT 0       // slot of the scatter after which the next tile's source tile is requested
 #endif
-#define KMO_RUN 64         // records wave 0 fetches from the workspace at once (lane = tile), into alternating halves of a 2 x 64 ring
+#ifndef KMO_SRC_DMA
+#define KMO_SRC_DMA 1      // fp32 storage: the next tile's source tile by LDS-DMA (global_load_lds) into a SECOND source buffer instead of through registers
+#endif
+#ifndef KMO_TAB_AHEAD
+#define KMO_TAB_AHEAD 0    // the coordinate-table entries of a slot read one slot ahead of its arithmetic
+#endif
+#ifndef KMO_FENCE_EVERY
+#define KMO_FENCE_EVERY 1  // slots of the scatter between two scheduling fences (1: one pixel at a time)
+#endif
+#define KMO_RUN (KMO_SRC_DMA ? 16 : 64)  // records wave 0 fetches from the workspace at once (lane = tile), into alternating halves of a 2 x KMO_RUN ring (the second source buffer takes 48 KB of the ring's CU)
 #define KMO_RING_INTS (KMO_RING_DESC ? 32 : 20)  // ints per tile in the LDS ring
 #define KMO_BOX_INTS 20    // workspace record of a tile: j0, j1, i0, i1, head-room bits, flags, first plane, matrix row, the 9 matrix entries, tile (tx, ty), (image, group), walk steps
 enum { KMO_F_FIXED = 1, KMO_F_REGULAR = 4, KMO_F_NONFINITE = 8 };
@@ -128,7 +137,7 @@ struct KmWarpFusedArgs {
 };
 
 __host__ __device__ constexpr int kmo_lds_bytes(int cc) {
-    return (KMT_BAND_W + KMT_TAB) * 16 + 2 * cc * KMO_PLANE * 4 + 2 * KMO_RUN * KMO_RING_INTS * 4 + KMO_NW * 8 + KMO_NW * 9 * 8;
+    return (KMT_BAND_W + KMT_TAB) * 16 + (KMO_SRC_DMA ? 3 : 2) * cc * KMO_PLANE * 4 + 2 * KMO_RUN * KMO_RING_INTS * 4 + KMO_NW * 8 + KMO_NW * 9 * 8;
 }
 
 // One tile (everything block-uniform)
@@ -257,8 +266,9 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
 // records of tiles q0 .. q0 + 63 of this worker, workspace -> LDS, one lane per tile (wave 0)
 template <typename T>
 __device__ __forceinline__ void kmo_fetch_boxes(const KmWarpFusedArgs<T>& a, uint32_t q0, int lane, int* s_box) {
+    if (lane >= KMO_RUN) return;  // (lane = tile of the run)
     const int t = kmo_tile_of(a, q0 + (uint32_t)lane);
-    static_assert(KMO_BOX_INTS % 4 == 0 && KMO_RING_INTS % 4 == 0, "16-byte pieces");
+    static_assert(KMO_BOX_INTS % 4 == 0 && KMO_RING_INTS % 4 == 0 && KMO_RUN <= 64, "16-byte pieces; one lane per tile of a run");
     int4* dst = reinterpret_cast<int4*>(s_box) + (KMO_RING_INTS / 4) * (((q0 / KMO_RUN) & 1u) * KMO_RUN + (uint32_t)lane);
 #if KMO_RING_DESC
     // The description of a tile is ~150 scalar instructions (and three LDS round trips) that all 16 waves of the workgroup executed for
@@ -377,6 +387,68 @@ __device__ __forceinline__ void kmo_store_src(const KmoTile& d, const float (&S)
     }
 }
 
+// fp32 storage (KMO_SRC_DMA): the same pieces of the source tile, every lane's straight into LDS (KM_GLDS16: the wave's 64 pieces land at
+// consecutive 16-byte cells from a wave-uniform base - exactly kmo_store_src's layout, idx4 = k * KMO_NT + tid).  No register holds the tile
+// on its way, no ds_write: what kmo_issue_src + kmo_store_src do in two phases a tile apart is ONE request here, and the 12 registers of S
+// are free during the scatter.  Ragged / unaligned tiles: one float per lane (a tile row per wave instruction), the same clamped addresses.
+// pad == fill stages the raw values; kmo_fill_in_lds subtracts the fill once they have landed.
+template <typename T, int CC>
+__device__ __forceinline__ void kmo_dma_src(const KmWarpFusedArgs<T>& a, const KmoTile& d, float* s_dst) {
+    static_assert(sizeof(T) == 4, "LDS-DMA moves bytes: fp32 storage only");
+    constexpr int SREG = CC * KMO_PLANE / KMO_NT;
+    const KmWarpGeom<float>& g = a.g;
+    const size_t src_plane = (size_t)g.H * g.W;
+    const float* src_b = reinterpret_cast<const float*>(a.src) + (size_t)d.plane0 * src_plane;
+    const int tid = threadIdx.x;
+    const int wbase = kmt_uniform(tid & ~63);  // first thread of the wave
+    if (d.svec) {
+#pragma unroll
+        for (int k = 0; k < SREG / 4; ++k) {
+            const int idx4 = k * KMO_NT + tid;
+            const int c = idx4 / (KMO_PLANE / 4), rem = idx4 % (KMO_PLANE / 4);
+            const int r = min(rem / (KMT_TW / 4), d.THc - 1), x4 = (rem % (KMT_TW / 4)) * 4;
+            const float* p = src_b + (size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (size_t)(d.X0 + x4);
+            KM_CHECK_ALIGNED(p, 16);
+            KM_GLDS16(p, s_dst + 4 * (k * KMO_NT + wbase));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SREG; ++k) {
+            const int idx = k * KMO_NT + tid;
+            const int c = idx / KMO_PLANE, rem = idx % KMO_PLANE;
+            const int r = min(rem / KMT_TW, d.THc - 1), x = min(rem % KMT_TW, d.TWc - 1);
+            KM_GLDS4(src_b + (size_t)c * src_plane + (size_t)(d.Y0 + r) * g.W + (size_t)(d.X0 + x), s_dst + (k * KMO_NT + wbase));
+        }
+    }
+}
+// pad == fill: (v - fill) in place, every thread on the cells its own requests filled (they have landed: the caller waited for them)
+template <int CC>
+__device__ __forceinline__ void kmo_fill_in_lds(const KmoTile& d, float* s_src, const float (&fill)[CC]) {
+    constexpr int SREG = CC * KMO_PLANE / KMO_NT;
+    const int tid = threadIdx.x;
+    if (d.svec) {
+#pragma unroll
+        for (int k = 0; k < SREG / 4; ++k) {
+            const int idx4 = k * KMO_NT + tid;
+            float f = 0.f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) f = (idx4 / (KMO_PLANE / 4) == c) ? fill[c] : f;
+            float4 v = reinterpret_cast<float4*>(s_src)[idx4];
+            v.x -= f; v.y -= f; v.z -= f; v.w -= f;
+            reinterpret_cast<float4*>(s_src)[idx4] = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SREG; ++k) {
+            const int idx = k * KMO_NT + tid;
+            float f = 0.f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) f = (idx / KMO_PLANE == c) ? fill[c] : f;
+            s_src[idx] = s_src[idx] - f;
+        }
+    }
+}
+
 // ---- one visited output pixel: contributions to grad_src (taps inside the tile) and this tile's share of its matrix-gradient terms ----
 // FIXED: int32 fixed-point LDS accumulators; otherwise IEEE float LDS atomics (non-finite gradients, vanishing-line tiles, extreme
 // magnification).  The image gradient at the sample is  gix = sum_c g_c ((ne - nw) wy1 + (se - sw) wy0),  giy = sum_c g_c ((sw - nw) wx1 +
@@ -470,32 +542,58 @@ template <typename T, int CM, int ALIGN, int CC, bool FAST, bool FIXED, int PADX
 __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& d, const KmoConsts& k, float (&G)[KMO_SLOTS][CC], const float4* s_u4,
                                             const float4* s_v4, int* s_acc, const float* s_src, float scale, float (&A)[9], int w, KmoWalk& wn,
                                             const T* const (&gout_n)[CC], bool mine, const KmWarpFusedArgs<T>& a, const KmoTile& nxt,
-                                            float (&S)[CC * KMO_PLANE / KMO_NT]) {
+                                            float (&S)[CC * KMO_PLANE / KMO_NT], float* s_src_next) {
     const int tid = threadIdx.x;
     const int bw = max(d.bw, 1);
     const int di = d.di, dj = d.dj;
     const int nqp = min(d.nq - d.p * KMO_CAP, KMO_CAP);  // pixels of this pass
     int qi, qj;
     kmo_first(d.p * KMO_CAP + tid, bw, qi, qj);
+#if KMO_TAB_AHEAD
+    // the table entries of a slot are read ONE SLOT AHEAD - in front of the previous pixel's twelve LDS atomics and tap reads, which an LDS
+    // read issued behind them would queue behind (LDS operations of a wave complete in order)
+    float4 cN = make_float4(0.f, 0.f, 0.f, 0.f), rN = cN;
+    bool vN = false;
+    if (mine && 0 < nqp && !(KMO_ABL & 4)) {
+        vN = tid < nqp;
+        cN = s_u4[vN ? qj : 0]; rN = s_v4[vN ? qi : 0];
+        kmt_advance(qi, qj, di, dj, bw);
+    }
+#endif
 #pragma unroll
     for (int s = 0; s < KMO_SLOTS; ++s) {
         // (mine == false: a tile this launch leaves to the general one - only the refill below happens.  One code path for both, so
         // that the compiler sees ONE set of registers for the slots: two paths meant copies, and a wait for every load in flight)
         if (mine && s * KMO_NT < nqp && !(KMO_ABL & 4)) {  // block-uniform
+#if KMO_TAB_AHEAD
+            const bool valid = vN;
+            const float4 c0 = cN, r0 = rN;
+            if ((s + 1) * KMO_NT < nqp) {
+                vN = (s + 1) * KMO_NT + tid < nqp;
+                cN = s_u4[vN ? qj : 0]; rN = s_v4[vN ? qi : 0];
+                kmt_advance(qi, qj, di, dj, bw);
+            }
+#else
             const bool valid = s * KMO_NT + tid < nqp;
             const int vqi = valid ? qi : 0, vqj = valid ? qj : 0;
             const float4 c0 = s_u4[vqj], r0 = s_v4[vqi];
+#endif
             KmtPix q;
             float gdx, gdy;
             kmt_pix_position_pad<CM, ALIGN, FAST, PADX>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, a.g.W, a.g.H, q, gdx, gdy);
             kmo_pix<CM, CC, FAST, FIXED>(q, G[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
+#if !KMO_TAB_AHEAD
             kmt_advance(qi, qj, di, dj, bw);
+#endif
         }
         kmo_request_slot<T, CC>(gout_n, w, s, wn, G[s]);
         // the next tile's source tile is requested here, not before the loop: registers that are live across the whole loop get
         // moved by the register allocator at its entry, and a move of a register with a load in flight is a wait for that load
-        if (s == KMO_SRC_AT && nxt.t >= 0 && nxt.regular && nxt.p == 0) kmo_issue_src<T, CC>(a, nxt, S);
-        KM_SCHED_FENCE();  // one pixel at a time: interleaving the slots costs more registers than it hides latency
+        if (s == KMO_SRC_AT && nxt.t >= 0 && nxt.regular && nxt.p == 0) {
+            if constexpr (KMO_SRC_DMA && sizeof(T) == 4) kmo_dma_src<T, CC>(a, nxt, s_src_next);
+            else kmo_issue_src<T, CC>(a, nxt, S);
+        }
+        if ((s + 1) % KMO_FENCE_EVERY == 0) KM_SCHED_FENCE();  // one pixel at a time: interleaving the slots costs more registers than it hides latency
     }
 }
 
@@ -725,6 +823,7 @@ struct KmoLds {
     float4 *s_u4, *s_v4;
     int* s_acc;
     float* s_src;
+    float* s_src2;   // KMO_SRC_DMA: the second source buffer (tile q uses buffer q & 1)
     int* s_box;
     uint32_t* s_red;
     double* s_gm;
@@ -736,7 +835,8 @@ __device__ __forceinline__ KmoLds kmo_carve(char* smem_raw) {
     l.s_v4 = l.s_u4 + KMT_BAND_W;                           // [KMT_TAB] per row of the box
     l.s_acc = (int*)(l.s_v4 + KMT_TAB);                     // [CC][TH][TW] fixed-point accumulators
     l.s_src = (float*)(l.s_acc + CC * KMO_PLANE);           // [CC][TH][TW] the source tile (minus fill)
-    l.s_box = (int*)(l.s_src + CC * KMO_PLANE);             // [2 KMO_RUN][KMO_BOX_INTS] ring of records of this worker's tiles
+    l.s_src2 = l.s_src + CC * KMO_PLANE;                    // [CC][TH][TW] (KMO_SRC_DMA only)
+    l.s_box = (int*)(l.s_src + (KMO_SRC_DMA ? 2 : 1) * CC * KMO_PLANE);  // [2 KMO_RUN][KMO_BOX_INTS] ring of records of this worker's tiles
     l.s_red = (uint32_t*)(l.s_box + 2 * KMO_RUN * KMO_RING_INTS);  // [KMO_NW] (8-byte slots: keeps s_gm aligned)
     l.s_gm = (double*)(l.s_red + 2 * KMO_NW);               // [KMO_NW][9] matrix-gradient partials of a finished image
     return l;
@@ -766,11 +866,18 @@ __device__ __forceinline__ void kmo_gm_commit(const double* s_gm, double* gmat_b
 // A tile whose requests have arrived: source tile -> LDS, exact maximum of |grad_out| over its box, coordinate tables
 template <typename T, int CM, int CC>
 __device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const KmoTile& d, const int* rec, const float (&G)[KMO_SLOTS][CC],
-                                          const float (&S)[CC * KMO_PLANE / KMO_NT], const KmoLds& l, const float (&fillv)[CC], bool is_fill, int lane, int wave, uint32_t par KMO_PROF_PARAMS) {
+                                          const float (&S)[CC * KMO_PLANE / KMO_NT], const KmoLds& l, float* s_src_cur, const float (&fillv)[CC], bool is_fill, int lane, int wave, uint32_t par KMO_PROF_PARAMS) {
     // (no early exit for a tile this launch does not own: every path through here must CONSUME the slots and the source registers,
     // or the compiler - which cannot know that nothing was requested for such a tile - waits for them later, inside the scatter, with
     // a wait that also covers the next tile's requests)
-    if (d.p == 0) kmo_store_src<CC>(d, S, l.s_src, fillv, is_fill);  // (later passes of a box: the tile is in LDS already, no request was made)
+    if constexpr (KMO_SRC_DMA && sizeof(T) == 4) {
+        // this wave's LDS-DMA requests (issued during the previous item's scatter, in front of most of this item's grad_out requests) have
+        // landed: the compiler does not know them - its own waits cover them only when a later load of its own is waited for
+        KM_VMCNT0();
+        if (d.p == 0 && is_fill && d.t >= 0 && d.regular) kmo_fill_in_lds<CC>(d, s_src_cur, fillv);
+    } else {
+        if (d.p == 0) kmo_store_src<CC>(d, S, s_src_cur, fillv, is_fill);  // (later passes of a box: the tile is in LDS already, no request was made)
+    }
     KMO_T(8)  // stage: source tile -> LDS
     uint32_t mb = 0;
 #pragma unroll
@@ -812,6 +919,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 #pragma unroll
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
     const size_t dst_plane = (size_t)g.h * g.w;
+    constexpr bool DMA = KMO_SRC_DMA && sizeof(T) == 4;  // the source tiles by LDS-DMA, double-buffered (kmo_dma_src)
 
     // ---- prologue: records of the first tiles, accumulators zeroed, the first tile requested and staged ----
     if (wave == 0) kmo_fetch_boxes(a, 0u, lane, l.s_box);
@@ -837,7 +945,8 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         if (cur.t >= 0 && cur.regular) {
 #pragma unroll
             for (int c = 0; c < CC; ++c) gout_c[c] = a.gout + ((size_t)cur.plane0 + (size_t)c) * dst_plane;
-            kmo_issue_src<T, CC>(a, cur, S);
+            if constexpr (DMA) kmo_dma_src<T, CC>(a, cur, l.s_src);  // (tile q uses source buffer q & 1)
+            else kmo_issue_src<T, CC>(a, cur, S);
         } else {
             w0.nq = 0;
         }
@@ -871,7 +980,9 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         KMO_T(0)  // wait for this item's requests
-        kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, fillv, is_fill, lane, wave, item & 1u KMO_PROF_ARGS);
+        float* const s_src_cur = (DMA && (q & 1u)) ? l.s_src2 : l.s_src;
+        float* const s_src_nxt = (DMA && !(q & 1u)) ? l.s_src2 : l.s_src;  // (of tile q + 1)
+        kmo_stage<T, CM, CC>(a, cur, kmo_ring(l.s_box, q), G, S, l, s_src_cur, fillv, is_fill, lane, wave, item & 1u KMO_PROF_ARGS);
         KMO_T(1)  // stage: source tile -> LDS, maxima, tables
         // ---- flush of the previous tile (zeroes the accumulators) ----
         if (prev.t >= 0) kmo_flush<T, CC>(a, prev, l.s_acc, true, prev_inv_scale, prev_discard);
@@ -955,7 +1066,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         {
             float m[9];
             kmo_matrix(kmo_ring(l.s_box, q), m);
-            kmo_process<T, CM, ALIGN, CC, true, true, PADX>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, l.s_src, scale, A, g.w, wn, gout_n, mine, a, nxt, S);
+            kmo_process<T, CM, ALIGN, CC, true, true, PADX>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, s_src_cur, scale, A, g.w, wn, gout_n, mine, a, nxt, S, s_src_nxt);
         }
         KMO_T(5)  // scatter
         KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
@@ -971,7 +1082,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
                     // average (profiles/r03_bwd_phases.txt: "loop tail").  The source tile is dead after the last pass of its tile: the 1024
                     // threads park their nine fp32 partials there, and wave k sums row k - sixteen conflict-free reads per lane, fp64 adds, ONE
                     // wave reduction.  The same fp32 partials summed in fp64, in another order; two more LDS barriers per image.
-                    float* s_part = l.s_src;
+                    float* s_part = s_src_cur;  // (KMO_SRC_DMA: the other buffer is receiving the next tile)
 #pragma unroll
                     for (int k = 0; k < 9; ++k) { s_part[k * KMO_NT + tid] = A[k]; A[k] = 0.f; }
                     KM_LDS_BARRIER();

@@ -120,6 +120,11 @@ inline int emu_cvt_i32_f32(float v) {
 #define KM_LDS_BARRIER() __syncthreads()
 #define KM_SCHED_FENCE() ((void)0)
 #define KM_OPAQUE(v) ((void)0)
+// LDS-DMA (km_common.h KM_GLDS16 / KM_GLDS4): the lane's piece lands at lds_wave_base + lane * size.  On the host the copy is immediate
+// (what the device's vmcnt wait + barrier discipline guarantees is therefore NOT checked here: the -m gpu run does that)
+#define KM_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gsrc), 16)
+#define KM_GLDS4(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 4 * emu::lane_id(), (const void*)(gsrc), 4)
+#define KM_VMCNT0() ((void)0)
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_fmed3f((a), (b), (c))
 
