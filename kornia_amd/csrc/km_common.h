@@ -314,6 +314,17 @@ __device__ __forceinline__ void km_glds4(const void* gsrc, uint32_t lds_dst) {
 #define KM_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// The thread index as a value the optimiser cannot hoist out of a loop (an empty volatile statement "writes" it): in a kernel that walks
+// several tiles, everything that depends on the thread index alone - lane / wave / column / chunk indices, address offsets - is
+// loop-invariant, gets hoisted and stays live across the whole body.  (The host build of the kernels: the plain index.)
+#ifndef KM_TID_PINNED
+__device__ __forceinline__ int km_tid_pinned() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#endif
+
 // Scheduling fence: the compiler does not move instructions across it (no code is emitted).  Used between independent unrolled
 // bodies whose interleaving would raise the register count (the host build of the kernels defines it away).
 #ifndef KM_SCHED_FENCE

@@ -730,6 +730,9 @@ struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50;
 #ifndef KMB_TRY_WIDE
 #define KMB_TRY_WIDE 1       // 0: squares only (A/B)
 #endif
+#ifndef KMB_FILL_DMA
+#define KMB_FILL_DMA 1       // fp32 storage: the box by LDS-DMA (global_load_lds_dwordx4) instead of through registers
+#endif
 #ifndef KMB_TILT_ROWS
 #define KMB_TILT_ROWS 4      // a region whose output rows span at most this many source rows takes the gather rows when its wide box does not fit
 #endif
@@ -800,7 +803,7 @@ __device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const floa
     static_assert(TW == 64 || TW == 32, "lane = output column");
     static_assert(TH <= 64 && PITCH % 4 == 0, "one wave fills the row table; whole chunks");
     const KmWarpGeom<float>& g = a.g;
-    const int tid = threadIdx.x;
+    const int tid = km_tid_pinned();
     const int j = j0 + (tid % TW);
     const int li_base = (tid / TW) * RPT;             // this thread's rows: li_base + r
     const int i_base = i0 + li_base;
@@ -816,17 +819,37 @@ __device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const floa
     const bool filler = (rq < RCPP) && (ck < bx.nch);
     const bool col_in = (xg >= 0) && (xg + 3 < W);  // W % 4 == 0 and xs % 4 == 0: a chunk is inside or outside as a whole
     const int nrc = bx.nrows * NC;
+#if KMB_FILL_DMA
+    // fp32 storage: every chunk straight into LDS (KM_GLDS16: the wave's 64 pieces land at consecutive 16-byte cells - a pass of the block is
+    // RCPP * NCHK consecutive chunks, thread t's at chunk t); no register holds the box on its way (40 of this kernel's 127), no ds_write pass.
+    // Chunks outside the image are zeros, written the ordinary way.  The requests have landed after KM_VMCNT0() + the barrier below.
+    constexpr bool DMA = sizeof(T) == 4;
+#else
+    constexpr bool DMA = false;
+#endif
     // (UNCONDITIONAL loads - a chunk outside the image or beyond the box reads the first chunk of the image and is replaced by zeros on its
     // way to LDS: with `v = 0; if (inside) load` the compiler keeps the whole array as one register tuple and copies - or spills - all of
     // it at every conditional definition)
-    float v[NPASS][4];
+    float v[DMA ? 1 : NPASS][4];
     uint32_t inmask = 0u;
+    if constexpr (DMA) {
+        const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int rc = ps * RCPP + rq, r = rc / NC, c = rc - r * NC, y = bx.ys + r;
-        const bool inb = filler && col_in && (rc < nrc) && (y >= 0) && (y < H);
-        inmask |= inb ? (1u << ps) : 0u;
-        km_ld4(km_at(src_b + (inb ? c : 0) * src_plane, inb ? (uint32_t)y * (uint32_t)W + (uint32_t)xg : 0u), v[ps]);
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int rc = ps * RCPP + rq, r = rc / NC, c = rc - r * NC, y = bx.ys + r;
+            const bool live = filler && (rc < nrc);
+            const bool inb = live && col_in && (y >= 0) && (y < H);
+            if (inb) KM_GLDS16(km_at(reinterpret_cast<const float*>(src_b) + c * src_plane, (uint32_t)y * (uint32_t)W + (uint32_t)xg), s_src + ps * (RCPP * PITCH) + 4 * wbase);
+            else if (live) *reinterpret_cast<float4*>(s_src + rc * PITCH + 4 * ck) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int rc = ps * RCPP + rq, r = rc / NC, c = rc - r * NC, y = bx.ys + r;
+            const bool inb = filler && col_in && (rc < nrc) && (y >= 0) && (y < H);
+            inmask |= inb ? (1u << ps) : 0u;
+            km_ld4(km_at(src_b + (inb ? c : 0) * src_plane, inb ? (uint32_t)y * (uint32_t)W + (uint32_t)xg : 0u), v[ps]);
+        }
     }
 
     // ---- this thread's positions, while the requests fly ----
@@ -851,14 +874,18 @@ __device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const floa
     }
 
     // ---- requests -> LDS ----
+    if constexpr (DMA) {
+        KM_VMCNT0();
+    } else {
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int rc = ps * RCPP + rq;
-        if (filler && rc < nrc) {
-            float* q = s_src + rc * PITCH + 4 * ck;
-            KM_CHECK_ALIGNED(q, 16);
-            const bool inb = (inmask >> ps) & 1u;
-            *reinterpret_cast<float4*>(q) = make_float4(inb ? v[ps][0] : 0.f, inb ? v[ps][1] : 0.f, inb ? v[ps][2] : 0.f, inb ? v[ps][3] : 0.f);
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int rc = ps * RCPP + rq;
+            if (filler && rc < nrc) {
+                float* q = s_src + rc * PITCH + 4 * ck;
+                KM_CHECK_ALIGNED(q, 16);
+                const bool inb = (inmask >> ps) & 1u;
+                *reinterpret_cast<float4*>(q) = make_float4(inb ? v[ps][0] : 0.f, inb ? v[ps][1] : 0.f, inb ? v[ps][2] : 0.f, inb ? v[ps][3] : 0.f);
+            }
         }
     }
     __syncthreads();
@@ -893,22 +920,19 @@ __device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const floa
     }
 }
 
+#ifndef KMB_PERSISTENT
+#define KMB_PERSISTENT 0     // 1: the launch is KMB_WAVES_PER_EU workgroups per CU, each walking its share of the regions (measured: slower, see below)
+#endif
+// one 64 x 32 region of the output (logical block `bid` of a.nblocks), by the whole workgroup
 template <typename T, int CM, int NC, int ALIGN, bool STREAM>
-__global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(const KmWarpArgs<T> a) {
-    static_assert(KmbWide::TH == KmbSquare::TH && KmbWide::TW == 2 * KmbSquare::TW, "a wide tile is two square ones side by side");
-    static_assert(KmbSquare::TH / (256 / KmbSquare::TW) == KM_ROWS, "the gather rows walk KM_ROWS rows of a square half per thread");
+__device__ __forceinline__ void kmb_region(const KmWarpArgs<T>& a, uint32_t bid, float4* s_rv, int* s_info, float* s_src) {
     const KmWarpGeom<float>& g = a.g;
-    uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const uint32_t ty = bid % a.tiles_y;
     const uint32_t b = bid / a.tiles_y;
-    const int tid = threadIdx.x;
+    const int tid = km_tid_pinned();
     const int J0 = (int)tx * KmbWide::TW, I0 = (int)ty * KmbWide::TH;
-    __shared__ float4 s_rv[KmbWide::TH];
-    __shared__ int s_info[8];
-    __shared__ __attribute__((aligned(16))) float s_src[KMB_LDS_FLOATS(NC)];  // [row][channel][x]
-
     if (a.apply && !a.apply[b]) {  // block-uniform: this sample is not transformed
         km_fwd_copy_rows<T>(a, b, J0 + (tid % KmbWide::TW), I0 + (tid / KmbWide::TW) * (KmbWide::TH / 4), 1, KmbWide::TH / 4);
         return;
@@ -964,6 +988,27 @@ __global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(
     }
 }
 
+
+// One workgroup per region.  (The counters say a workgroup lives 8.7 us and the CUs hold 11.1 of their 16 waves on average
+// (profiles/r05_pmc_units.json); KMB_PERSISTENT = 1 - KMB_WAVES_PER_EU workgroups per CU that WALK the regions, no dispatch between two of
+// them - was nevertheless 8 % SLOWER on the flagship maps and 25 - 45 % slower under rotation / minification, where regions differ in cost
+// and a fixed share per workgroup does not balance: profiles/r05/fwd_box_variants.txt.  The loop stays for that switch: the default launch
+// has one region per workgroup and runs it once.)
+template <typename T, int CM, int NC, int ALIGN, bool STREAM>
+__global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(const KmWarpArgs<T> a) {
+    static_assert(KmbWide::TH == KmbSquare::TH && KmbWide::TW == 2 * KmbSquare::TW, "a wide tile is two square ones side by side");
+    static_assert(KmbSquare::TH / (256 / KmbSquare::TW) == KM_ROWS, "the gather rows walk KM_ROWS rows of a square half per thread");
+    __shared__ float4 s_rv[KmbWide::TH];
+    __shared__ int s_info[8];
+    __shared__ __attribute__((aligned(16))) float s_src[KMB_LDS_FLOATS(NC)];  // [row][channel][x]
+    // (inside the loop every helper takes its thread index through km_tid_pinned(): what depends on the thread index alone would otherwise be
+    // hoisted out of the loop and stay live across the whole body - 280 bytes of spills in a kernel that sits at its register limit)
+    for (uint32_t lb = blockIdx.x; lb < a.nblocks; lb += gridDim.x) {
+        if (lb != blockIdx.x) __syncthreads();  // the previous region's readers are done with s_rv, s_info and s_src
+        kmb_region<T, CM, NC, ALIGN, STREAM>(a, km_xcd_remap(lb, a.nblocks, a.reverse), s_rv, s_info, s_src);
+    }
+}
+
 // LDS-staged bicubic forward (km_warp_cubic.hip): launches and returns 1 when it takes the case, 0 otherwise
 int km_warp_fwd_cubic_try_any(int dtype, int coord_mode, const void* args, hipStream_t s);
 
@@ -994,12 +1039,18 @@ static void km_warp_fwd_box_launch_nc(const KmWarpArgs<T>& a, hipStream_t s) {
     b.nblocks = b.tiles_x * b.tiles_y * (uint32_t)a.g.B;
     b.reverse = km_traversal_next(s);
     b.stream_out = km_stream_stores((uint64_t)a.g.B * a.g.C * a.g.h * a.g.w * sizeof(T));
+    uint32_t grid = b.nblocks;
+    if (KMB_PERSISTENT) {
+        // (a multiple of 8: a launch block and its logical blocks then share an XCD)
+        const uint32_t resident = (uint32_t)(km_device_cus() > 0 ? km_device_cus() : 1) * KMB_WAVES_PER_EU;
+        if (grid > resident) grid = resident;
+    }
     if (a.g.align) {
-        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, true>), dim3(b.nblocks), dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, false>), dim3(b.nblocks), dim3(256), 0, s, b);
+        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, true>), dim3(grid), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 1, false>), dim3(grid), dim3(256), 0, s, b);
     } else {
-        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, true>), dim3(b.nblocks), dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, false>), dim3(b.nblocks), dim3(256), 0, s, b);
+        if (b.stream_out) hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, true>), dim3(grid), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((km_warp_fwd_box_kernel<T, CM, NC, 0, false>), dim3(grid), dim3(256), 0, s, b);
     }
 }
 template <typename T>

@@ -40,7 +40,7 @@ struct KmfBox {
 // TW x TH: the output tile; PITCH x ROWS: the capacity of the staged box (the defaults are the bilinear kernels' 32 x 32 / 56 x 56)
 template <int CM, int ALIGN, int MARGIN = 0, int TW = KMF_T, int TH = KMF_T, int PITCH = KMF_PITCH, int ROWS = KMF_ROWS>
 __device__ __forceinline__ void kmf_tile_setup(const KmWarpGeom<float>& g, const float (&m)[9], int j0, int i0, float4* s_rv, int* s_info, bool keep_v) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid_ = km_tid_pinned(), lane = tid_ & 63, wave = tid_ >> 6;  // (pinned: callers walk several tiles in a loop - km_tid_pinned)
     const int W = g.W, H = g.H;
     const float Wm1 = (float)(W - 1), Hm1 = (float)(H - 1), hW = (float)W / 2, hH = (float)H / 2;
     static_assert(TH <= 64, "one wave fills the row table");
