@@ -142,6 +142,10 @@ int km_affine_params_chain_fwd(const void* translations, const void* center, con
  * `(factor != neutral).any()` guards, apply (B) uint8 = batch_prob > 0.5 (iff batch_prob is given). */
 int km_color_params_fwd(const void* brightness, const void* contrast, const void* saturation, const void* hue, const void* batch_prob, void* params,
                         void* enable, void* apply, int B, void* stream);
+/* The same, and gray_sum (B) fp64 - the workspace km_color_jitter_fwd's contrast stage accumulates into - is zeroed by the launch (the
+ * caller's fill launch folded in). */
+int km_color_params_ws_fwd(const void* brightness, const void* contrast, const void* saturation, const void* hue, const void* batch_prob,
+                           void* params, void* enable, void* apply, void* gray_sum, int B, void* stream);
 
 /* Replaces get_perspective_transform (kornia/geometry/transform/imgwarp.py:397-525, Heckbert closed form) as called by
  * RandomPerspective.compute_transformation (kornia/augmentation/_2d/geometric/perspective.py): one launch instead of ~40.
@@ -269,6 +273,14 @@ int km_transform_points_bwd(const void* gout, const void* T, const void* pts, vo
  * sample whose entry is 0 gets the identity kernel - odd sizes), km_warp2d_fwd_masked and km_color_jitter_fwd_masked (the arguments of
  * km_warp2d_fwd / km_color_jitter_fwd plus `apply`; a sample whose entry is 0 is copied; the warp needs h == H, w == W). */
 int km_gaussian_taps_fwd(const void* sigma, const void* apply, void* taps_x, void* taps_y, int B, int kx, int ky, void* stream);
+/* The same for RandomGaussianBlur.apply_transform's own call (kornia/augmentation/_2d/intensity/gaussian_blur.py:95-114: ONE sigma per sample,
+ * images of any supported dtype) with what the host layer would otherwise spend ATen launches on folded in: sigma (B,2) [per_axis != 0] or
+ * (B) [per_axis == 0: the same sigma for both axes - no expanded copy]; batch_prob (B) fp32, nullable: the layer's probability draw,
+ * thresholded here (`> 0.5` blurred, else the identity kernel; odd sizes) - no comparison launch, no uint8 copy; round_dtype (KM_F32 /
+ * KM_BF16 / KM_F16): the taps rounded to the image's dtype and kept as fp32 values - filter2d's cast of its kernel to the input dtype
+ * (kornia/filters/filter.py:126) without the two cast round trips. */
+int km_gaussian_taps_dtype_fwd(const void* sigma, int per_axis, const void* batch_prob, void* taps_x, void* taps_y, int B, int kx, int ky,
+                               int round_dtype, void* stream);
 int km_warp2d_fwd_masked(const void* src, const void* mat, void* dst, const void* apply, int B, int C, int H, int W, int h,
                          int w, int B_M, int coord_mode, int norm_coords, int interp, int pad, int align, const void* fill,
                          int dtype, void* stream);

@@ -54,10 +54,12 @@ _PROTOTYPES = {
     "km_resize_bilinear_bwd": [_P, _P] + [_I] * 8 + [_P],
     "km_warp_masked_loss": [_P, _P, _P, _P] + [_I] * 11 + [c_double, _I, _P],
     "km_gaussian_taps_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "km_gaussian_taps_dtype_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "km_warp2d_fwd_masked": [_P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],
     "km_color_jitter_fwd_masked": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "km_affine_params_chain_fwd": [_P] * 10 + [_I] * 5 + [_P],
     "km_color_params_fwd": [_P] * 8 + [_I, _P],
+    "km_color_params_ws_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "km_color_jitter_bwd": [_P] * 10 + [_I] * 5 + [_P],
     "km_select_samples_fwd": [_P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P],
     "km_canny_nms_fwd": [_P, _P, _P, _I, _I, _I, c_double, c_double, c_double, _P],
@@ -183,11 +185,13 @@ def device_guard(device: torch.device):
 
 
 def flags(t, device, n=None):
-    """A per-sample / per-stage switch as the contiguous uint8 array the kernels read: a bool tensor is reinterpreted in place
-    (no launch), anything else goes through ``!= 0``."""
+    """A per-sample / per-stage switch as the contiguous uint8 array the kernels read (zero / non-zero): a bool tensor is reinterpreted
+    in place and a uint8 tensor - what the parameter kernels write - is taken as it is (no launch), anything else goes through ``!= 0``."""
     import torch
     t = t.detach().to(device=device).reshape(-1)
     if n is not None and t.numel() != n:
         raise ValueError(f"expected {n} switch entries, got {t.numel()}")
     t = t.contiguous()
+    if t.dtype == torch.uint8:
+        return t
     return t.view(torch.uint8) if t.dtype == torch.bool else t.ne(0).view(torch.uint8)

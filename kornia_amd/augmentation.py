@@ -30,7 +30,7 @@ import torch
 
 from . import _native as N
 from .enhance.adjust import color_jitter as _color_jitter, color_jitter_from_table
-from .filters.filter import filter2d_separable
+from .filters.filter import filter2d_separable, filter2d_separable_taps
 from .filters.gaussian import gaussian_blur2d
 from .geometry.transform.builders import get_affine_matrix2d, get_perspective_transform
 from .geometry.transform.imgwarp import COORD_PERSPECTIVE, _warp, _warp_affine_from_chain, warp_affine, warp_perspective
@@ -78,16 +78,33 @@ def select_samples(transformed: torch.Tensor, original: torch.Tensor, apply: Opt
     return out
 
 
-def gaussian_taps(sigma: torch.Tensor, kernel_size, apply: Optional[torch.Tensor] = None) -> tuple:
-    """Per-sample 1-D Gaussian taps from ``sigma`` (B,2) = (sigma_y, sigma_x): ``(taps_x (B,kx), taps_y (B,ky))`` in float32, one
-    launch (``km_gaussian_taps_fwd``) for the ~16 elementwise launches of the reference's two ``get_gaussian_kernel1d`` calls.
+def gaussian_taps(sigma: torch.Tensor, kernel_size, apply: Optional[torch.Tensor] = None, batch_prob: Optional[torch.Tensor] = None,
+                  round_to: Optional[torch.dtype] = None) -> tuple:
+    """Per-sample 1-D Gaussian taps from ``sigma`` (B,2) = (sigma_y, sigma_x) - or (B,): the same sigma for both axes -:
+    ``(taps_x (B,kx), taps_y (B,ky))`` in float32, one launch (``km_gaussian_taps_fwd`` / ``km_gaussian_taps_dtype_fwd``) for the ~16
+    elementwise launches of the reference's two ``get_gaussian_kernel1d`` calls.
     ``apply`` (B,) bool: a sample whose entry is False gets the identity kernel (odd sizes), so the blur returns it unchanged - bit for
-    bit when the image is finite (0 * inf is NaN).  A sigma of 0 gives the identity kernel too (the sigma -> 0 limit), NaN gives NaN taps."""
+    bit when the image is finite (0 * inf is NaN).  ``batch_prob`` (B,) float: the same switch from the augmentation layer's draw itself
+    (``> 0.5``), thresholded inside the launch.  ``round_to``: the image dtype - the taps come out rounded to it (still float32 values), what
+    ``filter2d``'s cast of its kernel to the input dtype does (filter.py:126).  A sigma of 0 gives the identity kernel too (the sigma -> 0
+    limit), NaN gives NaN taps."""
     ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
     s = sigma.detach().to(torch.float32).contiguous()
     B = s.shape[0]
     tx = torch.empty(B, kx, device=s.device, dtype=torch.float32)
     ty = torch.empty(B, ky, device=s.device, dtype=torch.float32)
+    if s.dim() == 1 or batch_prob is not None or round_to not in (None, torch.float32):
+        if apply is not None:
+            raise ValueError("gaussian_taps: give the per-sample switch as `apply` (flags) or as `batch_prob` (the draw), not both forms")
+        if s.dim() not in (1, 2) or (s.dim() == 2 and s.shape[1] != 2):
+            raise ValueError("gaussian_taps: sigma must be (B,) or (B,2)")
+        prob = None if batch_prob is None else batch_prob.detach().to(device=s.device, dtype=torch.float32).reshape(-1).contiguous()
+        if prob is not None and prob.numel() != B:
+            raise ValueError(f"batch_prob has {prob.numel()} entries, expected the batch size {B}")
+        with N.device_guard(s.device):
+            N.check(N.lib().km_gaussian_taps_dtype_fwd(s.data_ptr(), int(s.dim() == 2), N.ptr(prob), tx.data_ptr(), ty.data_ptr(), B, kx, ky,
+                                                       N.dtype_code(round_to or torch.float32), N.stream_ptr(s.device)), "km_gaussian_taps_dtype_fwd")
+        return tx, ty
     flags = None if apply is None else N.flags(apply, s.device, B)
     with N.device_guard(s.device):
         N.check(N.lib().km_gaussian_taps_fwd(s.data_ptr(), N.ptr(flags), tx.data_ptr(), ty.data_ptr(), B, kx, ky, N.stream_ptr(s.device)), "km_gaussian_taps_fwd")
@@ -172,10 +189,11 @@ def color_jitter(input: torch.Tensor, params: Mapping[str, Any], order: Optional
         enable = torch.empty(4, device=dev, dtype=torch.uint8)
         apply = torch.empty(B, device=dev, dtype=torch.uint8) if prob is not None else None
         bf, cf, sf, hf = (f.contiguous() for f in (bf, cf, sf, hf))
+        gray_ws = torch.empty(B, device=dev, dtype=torch.float64)  # the contrast stage's accumulators: zeroed by the same launch
         with N.device_guard(dev):
-            N.check(N.lib().km_color_params_fwd(bf.data_ptr(), cf.data_ptr(), sf.data_ptr(), hf.data_ptr(), N.ptr(prob), table.data_ptr(), enable.data_ptr(),
-                                                N.ptr(apply), B, N.stream_ptr(dev)), "km_color_params_fwd")
-        return color_jitter_from_table(input, table, enable, apply, order)
+            N.check(N.lib().km_color_params_ws_fwd(bf.data_ptr(), cf.data_ptr(), sf.data_ptr(), hf.data_ptr(), N.ptr(prob), table.data_ptr(), enable.data_ptr(),
+                                                   N.ptr(apply), gray_ws.data_ptr(), B, N.stream_ptr(dev)), "km_color_params_ws_fwd")
+        return color_jitter_from_table(input, table, enable, apply, order, gray_ws)
     enable = torch.stack([(bf != 0).any(), (cf != 1).any(), (sf != 1).any(), (hf != 0).any()])
     return _color_jitter(input, bf, cf, sf, hf, order, enable=enable, apply=_apply_mask(params, dev))
 
@@ -184,20 +202,21 @@ def random_gaussian_blur(input: torch.Tensor, params: Mapping[str, Any], kernel_
                          separable: bool = True) -> torch.Tensor:
     """RandomGaussianBlur.apply_transform (gaussian_blur.py:95-114): per-sample ``sigma`` (B,), same in both directions."""
     N.require_device(input, "input")
-    sigma = _p(params, "sigma", input.device).unsqueeze(-1).expand(-1, 2)
-    if separable and input.dtype in (torch.float32, torch.bfloat16, torch.float16):
-        # taps in float32 from the float32 sigma (the reference rounds sigma to the image dtype first), cast to the image dtype by
-        # filter2d_separable exactly as it casts any kernel (kornia/filters/filter.py:126)
+    sigma1 = _p(params, "sigma", input.device)
+    if separable and input.dtype in (torch.float32, torch.bfloat16, torch.float16) and sigma1.dim() == 1:
+        # taps in float32 from the float32 sigma (the reference rounds sigma to the image dtype first), rounded to the image dtype inside the
+        # same launch - filter2d_separable's cast of any kernel (kornia/filters/filter.py:126) - and handed to the fused filter as they are
         ky, kx = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
-        mask = _apply_mask(params, input.device)
-        if mask is None or (kx % 2 == 1 and ky % 2 == 1):
+        has_prob = "batch_prob" in params and params["batch_prob"] is not None
+        if not has_prob or (kx % 2 == 1 and ky % 2 == 1):
             # the switch rides in the taps: a sample that is not blurred gets the identity kernel: 1 * x + 0 * neighbours = x bit for bit
             # for FINITE images (an inf / NaN pixel of an untouched sample spreads NaN over its neighbourhood, -0.0 comes back as +0.0:
             # patch() therefore keeps the select pass for RandomGaussianBlur; this entry function states the precondition)
-            taps_x, taps_y = gaussian_taps(sigma, kernel_size, mask)
-            return filter2d_separable(input, taps_x, taps_y, border_type)
-        taps_x, taps_y = gaussian_taps(sigma, kernel_size)
-        return select_samples(filter2d_separable(input, taps_x, taps_y, border_type), input, mask)
+            taps_x, taps_y = gaussian_taps(sigma1, kernel_size, batch_prob=torch.as_tensor(params["batch_prob"]) if has_prob else None, round_to=input.dtype)
+            return filter2d_separable_taps(input, taps_x, taps_y, border_type)
+        taps_x, taps_y = gaussian_taps(sigma1, kernel_size, round_to=input.dtype)
+        return select_samples(filter2d_separable_taps(input, taps_x, taps_y, border_type), input, _apply_mask(params, input.device))
+    sigma = sigma1.unsqueeze(-1).expand(-1, 2)
     out = gaussian_blur2d(input, kernel_size, sigma.to(input.dtype), border_type, separable)
     return select_samples(out, input, _apply_mask(params, input.device))
 

@@ -11,16 +11,25 @@
 //                          broadcast mask), reading only the side that is kept: 2e bytes per element instead of 3e.
 #include "km_regtile.h"
 
+// taps rounded to the image's storage type (what filter2d's cast of its kernel to the input dtype does, kornia/filters/filter.py:126), kept as fp32
+__device__ __forceinline__ float km_taps_round(float v, int round_dtype) {
+    if (round_dtype == KM_BF16) return __uint_as_float(((uint32_t)km_f32_to_bf16_bits(v)) << 16);
+    if (round_dtype == KM_F16) return km_round_as(v, (const km_f16*)nullptr);
+    return v;
+}
+// per_axis: sigma is (B,2) = (sigma_y, sigma_x); else (B): one sigma for both axes.  apply (B) uint8 / prob (B) fp32 (applied when > 0.5):
+// at most one of them; round_dtype: KM_F32 (none) / KM_BF16 / KM_F16.
 template <int MAXK>
 __global__ __launch_bounds__(64) void km_gaussian_taps_kernel(const float* __restrict__ sigma, const uint8_t* __restrict__ apply, float* __restrict__ taps_x,
-                                                              float* __restrict__ taps_y, int B, int kx, int ky) {
+                                                              float* __restrict__ taps_y, int B, int kx, int ky, int per_axis = 1,
+                                                              const float* __restrict__ prob = nullptr, int round_dtype = KM_F32) {
     const int t = blockIdx.x * 64 + threadIdx.x;  // one thread per (sample, axis)
     if (t >= 2 * B) return;
     const int b = t >> 1, axis = t & 1;           // axis 0: horizontal taps from sigma[:, 1]; axis 1: vertical from sigma[:, 0]
     const int k = axis ? ky : kx;
-    const float s = sigma[(size_t)b * 2 + (axis ? 0 : 1)];
+    const float s = per_axis ? sigma[(size_t)b * 2 + (axis ? 0 : 1)] : sigma[b];
     float* out = (axis ? taps_y : taps_x) + (size_t)b * k;
-    if (apply && !apply[b]) {
+    if ((apply && !apply[b]) || (prob && !(prob[b] > 0.5f))) {
         // a sample that is not blurred gets the identity kernel: 1 * x + 0 * neighbours reproduces a finite image bit for bit, so the
         // probability blend of the augmentation layer costs no pass of its own (odd kernel sizes; the caller blends otherwise)
         for (int i = 0; i < k; ++i) out[i] = (i == k / 2) ? 1.0f : 0.0f;
@@ -48,7 +57,7 @@ __global__ __launch_bounds__(64) void km_gaussian_taps_kernel(const float* __res
     }
 #pragma unroll
     for (int i = 0; i < MAXK; ++i)
-        if (i < k) out[i] = g[i] / sum;
+        if (i < k) out[i] = km_taps_round(g[i] / sum, round_dtype);
 }
 
 template <typename T>
@@ -90,9 +99,10 @@ static int km_select_run(const void* transformed, const void* original, const vo
 // `(factor != neutral).any()` guards (color_jitter.py:137-148: brightness != 0, contrast != 1, saturation != 1, hue != 0) and,
 // when the parameters carry a probability draw, the per-sample switch `batch_prob > 0.5` (augmentation/base.py:380).
 __global__ __launch_bounds__(256) void km_color_params_kernel(const float* bf, const float* cf, const float* sf, const float* hf, const float* prob,
-                                                              float* params, uint8_t* enable, uint8_t* apply, int B) {
+                                                              float* params, uint8_t* enable, uint8_t* apply, int B, double* gray_sum = nullptr) {
     int any_b = 0, any_c = 0, any_s = 0, any_h = 0;
     for (int b = threadIdx.x; b < B; b += 256) {
+        if (gray_sum) gray_sum[b] = 0.0;  // (km_color_params_ws_fwd: the contrast stage's accumulators start at zero - no fill launch of the caller's)
         const float vb = bf[b], vc = cf[b], vs = sf[b], vh = hf[b];
         params[4 * b + 0] = vb; params[4 * b + 1] = vc; params[4 * b + 2] = vs; params[4 * b + 3] = vh * 6.283185307179586f;
         any_b |= (vb != 0.0f); any_c |= (vc != 1.0f); any_s |= (vs != 1.0f); any_h |= (vh != 0.0f);
@@ -113,10 +123,34 @@ int km_gaussian_taps_fwd(const void* sigma, const void* apply, void* taps_x, voi
     KM_REQUIRE(!apply || ((kx & 1) && (ky & 1)), "km_gaussian_taps_fwd: the per-sample switch needs odd kernel sizes (%d, %d)", kx, ky);
     const dim3 grid((2 * B + 63) / 64);
     if (kx <= 8 && ky <= 8)
-        hipLaunchKernelGGL(km_gaussian_taps_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)apply, (float*)taps_x, (float*)taps_y, B, kx, ky);
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)apply, (float*)taps_x, (float*)taps_y, B, kx, ky,
+                           1, (const float*)nullptr, (int)KM_F32);
     else
-        hipLaunchKernelGGL(km_gaussian_taps_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)apply, (float*)taps_x, (float*)taps_y, B, kx, ky);
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)apply, (float*)taps_x, (float*)taps_y, B, kx, ky,
+                           1, (const float*)nullptr, (int)KM_F32);
     return km_check_launch("km_gaussian_taps_fwd");
+}
+
+// km_gaussian_taps_fwd for the augmentation layer's own call (RandomGaussianBlur.apply_transform: ONE sigma per sample, an image of a 16-bit
+// type): sigma (B,2) [per_axis != 0] or (B) [per_axis == 0] fp32; batch_prob (B) fp32 on the device, nullable - the layer's probability draw,
+// thresholded here (> 0.5: blurred; else the identity kernel, odd sizes); round_dtype: the image's dtype code - the taps are rounded to it
+// (and stay fp32 values), which is what the reference's cast of its kernels to the input dtype does (kornia/filters/filter.py:126).  Replaces
+// the expand / contiguous copy of sigma, the comparison and the two cast round trips the host layer otherwise spends ATen launches on.
+int km_gaussian_taps_dtype_fwd(const void* sigma, int per_axis, const void* batch_prob, void* taps_x, void* taps_y, int B, int kx, int ky, int round_dtype,
+                               void* stream) {
+    if (B == 0) return 0;
+    KM_REQUIRE(sigma && taps_x && taps_y, "km_gaussian_taps_dtype_fwd: null pointer");
+    KM_REQUIRE(B > 0 && kx > 0 && ky > 0 && kx <= 64 && ky <= 64, "km_gaussian_taps_dtype_fwd: bad sizes B=%d kx=%d ky=%d (1..64)", B, kx, ky);
+    KM_REQUIRE(!batch_prob || ((kx & 1) && (ky & 1)), "km_gaussian_taps_dtype_fwd: the per-sample switch needs odd kernel sizes (%d, %d)", kx, ky);
+    KM_REQUIRE(round_dtype == KM_F32 || round_dtype == KM_BF16 || round_dtype == KM_F16, "km_gaussian_taps_dtype_fwd: round_dtype must be f32 / bf16 / f16");
+    const dim3 grid((2 * B + 63) / 64);
+    if (kx <= 8 && ky <= 8)
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<8>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)nullptr, (float*)taps_x, (float*)taps_y, B, kx, ky,
+                           per_axis, (const float*)batch_prob, round_dtype);
+    else
+        hipLaunchKernelGGL(km_gaussian_taps_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, (const float*)sigma, (const uint8_t*)nullptr, (float*)taps_x, (float*)taps_y, B, kx, ky,
+                           per_axis, (const float*)batch_prob, round_dtype);
+    return km_check_launch("km_gaussian_taps_dtype_fwd");
 }
 
 // transformed, original, out: (B, n_per_sample) elements of `dtype`; apply: (B) uint8 on the device (non-zero: keep the transformed sample).
@@ -143,6 +177,17 @@ int km_color_params_fwd(const void* brightness, const void* contrast, const void
     hipLaunchKernelGGL(km_color_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)brightness, (const float*)contrast,
                        (const float*)saturation, (const float*)hue, (const float*)batch_prob, (float*)params, (uint8_t*)enable, (uint8_t*)apply, B);
     return km_check_launch("km_color_params_fwd");
+}
+
+// km_color_params_fwd that also ZEROES gray_sum (B) fp64, the workspace km_color_jitter_fwd's contrast stage accumulates the per-image gray
+// sums in (its caller would otherwise spend a fill launch on it).
+int km_color_params_ws_fwd(const void* brightness, const void* contrast, const void* saturation, const void* hue, const void* batch_prob, void* params,
+                           void* enable, void* apply, void* gray_sum, int B, void* stream) {
+    KM_REQUIRE(B >= 0 && enable && (B == 0 || (brightness && contrast && saturation && hue && params && gray_sum)), "km_color_params_ws_fwd: null pointer");
+    KM_REQUIRE((batch_prob == nullptr) == (apply == nullptr) || B == 0, "km_color_params_ws_fwd: batch_prob and apply go together");
+    hipLaunchKernelGGL(km_color_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)brightness, (const float*)contrast,
+                       (const float*)saturation, (const float*)hue, (const float*)batch_prob, (float*)params, (uint8_t*)enable, (uint8_t*)apply, B, (double*)gray_sum);
+    return km_check_launch("km_color_params_ws_fwd");
 }
 
 }  // extern "C"

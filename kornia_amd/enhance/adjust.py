@@ -55,13 +55,15 @@ class _ColorJitterFunction(torch.autograd.Function):
     """``km_color_jitter_fwd(_masked)`` / ``km_color_jitter_bwd``: gradients wrt the image and the (B,4) parameter table."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor], stages: tuple):
+    def forward(ctx, x: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor], stages: tuple,
+                gray_ws: Optional[torch.Tensor] = None):
         B, _, H, W = x.shape
         dev = x.device
         x = x.contiguous()
         params = params.contiguous()
         out = torch.empty_like(x)
-        gray_sum = torch.zeros(B, device=dev, dtype=torch.float64) if CONTRAST in stages else None
+        # (gray_ws: a (B,) float64 workspace that the launch which made `params` has ALREADY zeroed - km_color_params_ws_fwd - instead of a fill launch here)
+        gray_sum = (gray_ws if gray_ws is not None else torch.zeros(B, device=dev, dtype=torch.float64)) if CONTRAST in stages else None
         arr = (ctypes.c_int * max(len(stages), 1))(*stages)
         with N.device_guard(dev):
             if apply is None:
@@ -89,7 +91,7 @@ class _ColorJitterFunction(torch.autograd.Function):
         with N.device_guard(dev):
             N.check(N.lib().km_color_jitter_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(gsum), N.ptr(gparams),
                                                 N.ptr(enable), N.ptr(apply), arr, len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_bwd")
-        return (gx if ctx.needs_input_grad[0] else None), (gparams.to(params.dtype) if gparams is not None else None), None, None, None
+        return (gx if ctx.needs_input_grad[0] else None), (gparams.to(params.dtype) if gparams is not None else None), None, None, None, None
 
 
 def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], enable: Optional[torch.Tensor] = None,
@@ -117,9 +119,10 @@ def _run(image: torch.Tensor, factors: Sequence[Factor], stages: Sequence[int], 
 
 
 def color_jitter_from_table(image: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor],
-                            stages: Sequence[int]) -> torch.Tensor:
+                            stages: Sequence[int], gray_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The fused kernel on an already assembled parameter table (``km_color_params_fwd``): params (B,4) float32 - brightness,
-    contrast, saturation factors and the hue shift in RADIANS; enable (4) / apply (B) uint8 device tensors or None."""
+    contrast, saturation factors and the hue shift in RADIANS; enable (4) / apply (B) uint8 device tensors or None; gray_ws: a (B,)
+    float64 device workspace ALREADY ZEROED by the launch that made the table (``km_color_params_ws_fwd``), or None."""
     N.require_device(image, "image")
     if image.dim() != 4 or image.shape[1] != 3 or image.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         raise ValueError(f"expected a (B,3,H,W) float32 / bfloat16 / float16 image. Got {tuple(image.shape)} {image.dtype}")
@@ -128,7 +131,9 @@ def color_jitter_from_table(image: torch.Tensor, params: torch.Tensor, enable: O
         raise ValueError(f"`order` entries must be in 0..3 (brightness, contrast, saturation, hue), contrast at most once. Got {list(stages)}")
     if params.dtype != torch.float32 or tuple(params.shape) != (image.shape[0], 4):
         raise ValueError("params must be (B,4) float32")
-    return _ColorJitterFunction.apply(image, params, enable, apply, stages)
+    if gray_ws is not None and (gray_ws.dtype != torch.float64 or gray_ws.numel() != image.shape[0] or gray_ws.device != image.device or not gray_ws.is_contiguous()):
+        raise ValueError("gray_ws must be a contiguous (B,) float64 tensor on the image's device")
+    return _ColorJitterFunction.apply(image, params, enable, apply, stages, gray_ws)
 
 
 def adjust_brightness_accumulative(image: torch.Tensor, factor: Union[float, torch.Tensor], clip_output: bool = True) -> torch.Tensor:

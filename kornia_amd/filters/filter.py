@@ -191,6 +191,28 @@ def filter2d(
     return _Filter2dFunction.apply(input, k, _BORDER_CODE[border], same)
 
 
+def filter2d_separable_taps(input: torch.Tensor, taps_x: torch.Tensor, taps_y: torch.Tensor, border_type: str = "reflect") -> torch.Tensor:
+    """:func:`filter2d_separable` ('same' padding, correlation) for taps that are ALREADY what ``filter2d`` would make of them: (1|B, k)
+    contiguous float32 device tensors whose values are rounded to the image's dtype (``augmentation.gaussian_taps(..., round_to=...)``).
+    Skips the cast round trip of the kernels (two ATen launches each for a 16-bit image); everything else - validation, the fused
+    launch, the autograd node - is ``filter2d_separable``'s."""
+    ok = (isinstance(taps_x, torch.Tensor) and isinstance(taps_y, torch.Tensor) and taps_x.dtype == torch.float32 and taps_y.dtype == torch.float32
+          and taps_x.dim() == 2 and taps_y.dim() == 2 and taps_x.shape[0] == taps_y.shape[0] and taps_x.is_contiguous() and taps_y.is_contiguous()
+          and isinstance(input, torch.Tensor) and input.dim() == 4 and N.on_device(input) and taps_x.device == input.device and taps_y.device == input.device
+          and input.dtype in (torch.float32, torch.bfloat16, torch.float16) and not (taps_x.requires_grad or taps_y.requires_grad))
+    if ok:
+        kW, kH = taps_x.shape[1], taps_y.shape[1]
+        ok = bool(N.lib().km_filter2d_sep_supported(kH, kW, 1, N.dtype_code(input.dtype)) & 1)
+    if not ok:
+        return filter2d_separable(input, taps_x, taps_y, border_type)
+    _validate(input, taps_x[..., None, :], ["B", "H", "W"], border_type, "same")
+    B, C, H, W = input.shape
+    _check_kernel_batch(taps_x.shape[0], B, C)
+    border = str(border_type).lower()
+    _check_pad_fits(border, kH, kW, H, W)
+    return _Filter2dSepFunction.apply(input, taps_x, taps_y, _BORDER_CODE[border], 1)
+
+
 def filter2d_separable(
     input: torch.Tensor,
     kernel_x: torch.Tensor,

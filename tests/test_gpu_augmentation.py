@@ -56,3 +56,39 @@ def test_random_affine_replays_the_reference(name, kw):
     Mref = torch.from_numpy(d[name + "__matrix"])
     assert torch.allclose(M.cpu()[applied], Mref[applied], atol=1e-5, rtol=1e-5)
     assert torch.equal(ap.cpu().bool(), applied)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_gaussian_taps_dtype_entry_point_is_the_cast_round_trip(dtype):
+    """km_gaussian_taps_dtype_fwd (one sigma per sample, the probability draw thresholded in the launch, taps rounded to the image dtype in the
+    launch) against km_gaussian_taps_fwd + the torch ops it replaces: sigma.unsqueeze(-1).expand(-1, 2).contiguous(), batch_prob > 0.5, and
+    filter2d's taps.to(image dtype) (kornia/filters/filter.py:126) widened back to float32 - bit for bit, and the blur that uses them."""
+    import kornia_amd.augmentation as A
+    from kornia_amd.filters.filter import filter2d_separable, filter2d_separable_taps
+
+    g = torch.Generator().manual_seed(11)
+    B = 37
+    sigma = (0.1 + 1.9 * torch.rand(B, generator=g)).cuda()
+    sigma[3] = 0.0  # (the sigma -> 0 limit: identity kernel)
+    prob = (torch.rand(B, generator=g) < 0.6).float().cuda()
+    for ks in ((5, 5), (3, 7)):
+        ox, oy = A.gaussian_taps(sigma.unsqueeze(-1).expand(-1, 2), ks, apply=prob > 0.5)
+        nx, ny = A.gaussian_taps(sigma, ks, batch_prob=prob, round_to=dtype)
+        assert torch.equal(nx, ox.to(dtype).float()) and torch.equal(ny, oy.to(dtype).float())
+        ox, oy = A.gaussian_taps(sigma.unsqueeze(-1).expand(-1, 2), ks)
+        nx, ny = A.gaussian_taps(sigma, ks, round_to=dtype)
+        assert torch.equal(nx, ox.to(dtype).float()) and torch.equal(ny, oy.to(dtype).float())
+        s2 = torch.stack([sigma, sigma.flip(0)], dim=1)  # (sigma_y, sigma_x) per sample
+        o2x, o2y = A.gaussian_taps(s2, ks)
+        n2x, n2y = A.gaussian_taps(s2, ks, round_to=dtype)
+        assert torch.equal(n2x, o2x.to(dtype).float()) and torch.equal(n2y, o2y.to(dtype).float())
+    x = torch.rand(B, 3, 24, 32, generator=g).to(dtype).cuda()
+    ox, oy = A.gaussian_taps(sigma.unsqueeze(-1).expand(-1, 2), (5, 5))
+    nx, ny = A.gaussian_taps(sigma, (5, 5), round_to=dtype)
+    assert torch.equal(filter2d_separable_taps(x, nx, ny, "reflect"), filter2d_separable(x, ox, oy, "reflect"))
+    # the entry function: the draw rides in the taps (finite image: untouched samples come back bit for bit)
+    out = A.random_gaussian_blur(x, {"sigma": sigma, "batch_prob": prob})
+    ref = torch.where((prob > 0.5).view(-1, 1, 1, 1), filter2d_separable(x, ox, oy, "reflect"), x)
+    assert torch.equal(out, ref)
+    with pytest.raises(ValueError):
+        A.gaussian_taps(sigma, (5, 5), apply=prob > 0.5, batch_prob=prob)
