@@ -320,7 +320,9 @@ __device__ __forceinline__ void km_glds4(const void* gsrc, uint32_t lds_dst) {
 #ifndef KM_TID_PINNED
 __device__ __forceinline__ int km_tid_pinned() {
     int t = (int)threadIdx.x;
+#ifndef KM_TID_UNPINNED
     asm volatile("" : "+v"(t));
+#endif
     return t;
 }
 #endif

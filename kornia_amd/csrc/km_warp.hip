@@ -1003,10 +1003,14 @@ __global__ __launch_bounds__(256, KMB_WAVES_PER_EU) void km_warp_fwd_box_kernel(
     __shared__ __attribute__((aligned(16))) float s_src[KMB_LDS_FLOATS(NC)];  // [row][channel][x]
     // (inside the loop every helper takes its thread index through km_tid_pinned(): what depends on the thread index alone would otherwise be
     // hoisted out of the loop and stay live across the whole body - 280 bytes of spills in a kernel that sits at its register limit)
+#if KMB_PERSISTENT
     for (uint32_t lb = blockIdx.x; lb < a.nblocks; lb += gridDim.x) {
         if (lb != blockIdx.x) __syncthreads();  // the previous region's readers are done with s_rv, s_info and s_src
         kmb_region<T, CM, NC, ALIGN, STREAM>(a, km_xcd_remap(lb, a.nblocks, a.reverse), s_rv, s_info, s_src);
     }
+#else
+    kmb_region<T, CM, NC, ALIGN, STREAM>(a, km_xcd_remap(blockIdx.x, a.nblocks, a.reverse), s_rv, s_info, s_src);
+#endif
 }
 
 // LDS-staged bicubic forward (km_warp_cubic.hip): launches and returns 1 when it takes the case, 0 otherwise

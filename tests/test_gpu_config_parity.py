@@ -172,6 +172,86 @@ def test_config3_224_pipeline_replays_the_reference_fixture():
     assert torch.equal(A.random_gaussian_blur(s2, Pb), s2)
 
 
+def test_config3_whole_share_256_bf16_replays_the_reference_fixture_at_full_size():
+    """BASELINE configs[2] at its per-GPU batch: 256 x 3 x 224 x 224 bfloat16 through RandomAffine -> ColorJitter -> RandomGaussianBlur.  The
+    reference's sampled parameters and its float32 output exist for the fixture's two images (oracle/make_golden.py 'config3'); here they are
+    TILED to 256 samples - the launches then have the grids, the per-image contrast means and the per-sample taps of the real share - and every
+    sample must (a) come out bit-identical to the same sample of the 2-image run (nothing depends on the batch around it) and (b) stay within
+    BASELINE's 1e-2 of the float32 reference (bf16) / 1e-5 (float32)."""
+    import kornia_amd.augmentation as A
+
+    d = golden("config3")
+    x2 = torch.from_numpy(d["x_bf16_bits"].view("int16")).view(torch.bfloat16)
+    ref2 = torch.from_numpy(d["out"])
+    P2 = {name: {k.split("__", 1)[1]: torch.from_numpy(v) for k, v in d.items() if k.startswith(name + "__")} for name in ("affine", "jitter", "blur")}
+    B, reps = 256, 128
+    assert x2.shape[0] == 2
+
+    def tile(v):
+        return v.repeat(reps, *([1] * (v.dim() - 1))) if (isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == 2) else v
+
+    P = {n: {k: tile(v) for k, v in p.items() if k != "matrix"} for n, p in P2.items()}
+    P2 = {n: {k: v for k, v in p.items() if k != "matrix"} for n, p in P2.items()}
+    for dtype, tol in ((torch.bfloat16, 1e-2), (torch.float32, 1e-5)):
+        xs = x2.to(dtype)
+        small = A.apply_sequence(xs.cuda(), P2["affine"], P2["jitter"], P2["blur"])
+        big = A.apply_sequence(tile(xs).cuda(), P["affine"], P["jitter"], P["blur"])
+        assert big.shape == (B, 3, 224, 224) and big.dtype == dtype
+        assert torch.equal(big.view(reps, 2, 3, 224, 224), small.unsqueeze(0).expand(reps, -1, -1, -1, -1))
+        err = (big.float().cpu().view(reps, 2, 3, 224, 224) - ref2.unsqueeze(0)).abs().max().item()
+        assert err <= tol, f"{dtype}: {err:.2e}"
+
+
+def test_config4_whole_batch_64_frames_against_the_oracle_at_full_size(oracle):
+    """BASELINE configs[3] at its batch: 64 x 1 x 1080 x 1920 - SpatialGradient(sobel) and Sobel bit-identical to the oracle on every frame,
+    bicubic warp_affine (2 degrees about the centre + (3, -2) px) <= 1e-6."""
+    import kornia_amd as K
+
+    B, H, W = 64, 1080, 1920
+    g = torch.Generator().manual_seed(404)
+    x = torch.rand(B, 1, H, W, generator=g)
+    xd = x.cuda()
+    assert torch.equal(K.spatial_gradient(xd).cpu(), oracle.spatial_gradient(x))
+    assert torch.equal(K.sobel(xd).cpu(), oracle.sobel(x))
+    a = math.radians(2.0)
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    ca, sa = math.cos(a), math.sin(a)
+    A = torch.tensor([[[ca, sa, (1 - ca) * cx - sa * cy + 3.0], [-sa, ca, sa * cx + (1 - ca) * cy - 2.0]]]).repeat(B, 1, 1)
+    got = K.warp_affine(xd, A.cuda(), (H, W), mode="bicubic").cpu()
+    err = (got - oracle.warp_affine(x, A, (H, W), mode="bicubic")).abs().max().item()
+    assert err <= 1e-6, f"bicubic: {err:.2e}"
+
+
+def test_config5_whole_share_128_learned_homography_grad_at_full_size(oracle):
+    """BASELINE configs[4] at its per-GPU batch: 128 x 3 x 256 x 256, H = I + 0.01 randn (normalised dst -> src, align_corners=False), l1 loss:
+    forward <= 1e-5 of the oracle, H.grad of EVERY image within 5e-4 of the fp32 oracle (which shares the kernel's sampling positions) and
+    2e-2 of the oracle evaluated in float64 (what fp32 positions leave of this quantity)."""
+    import kornia_amd as K
+
+    B, S = 128, 256
+    g = torch.Generator().manual_seed(505)
+    v, u = torch.meshgrid(torch.linspace(0, 1, S), torch.linspace(0, 1, S), indexing="ij")
+    smooth = (0.5 + 0.3 * torch.sin(9.0 * u + 1.0) * torch.cos(7.0 * v) + 0.2 * u * v)[None, None]
+    x = (smooth + 0.02 * torch.rand(B, 3, S, S, generator=g)).contiguous()
+    target = torch.rand(B, 3, S, S, generator=g)
+    Hm = torch.eye(3)[None] + 0.01 * torch.randn(B, 3, 3, generator=g)
+    Hg = Hm.cuda().requires_grad_()
+    y = K.homography_warp(x.cuda(), Hg, (S, S))
+    torch.nn.functional.l1_loss(y, target.cuda()).backward()
+    y_o = oracle.homography_warp(x, Hm, (S, S))
+    assert (y.detach().cpu() - y_o).abs().max().item() <= 1e-5
+    go = torch.sign(y_o - target) / y_o.numel()
+    _, gH32 = oracle.homography_warp_backward(go, x, Hm, (S, S))
+    _, gH64 = oracle.homography_warp_backward(go.double(), x.double(), Hm.double(), (S, S))
+    got = Hg.grad.cpu().double()
+
+    def per_image(ref):
+        return ((got - ref.double()).abs().amax(dim=(-2, -1)) / ref.double().abs().amax(dim=(-2, -1))).max().item()
+
+    assert per_image(gH32) <= 5e-4, per_image(gH32)
+    assert per_image(gH64) <= 2e-2, per_image(gH64)
+
+
 def test_config4_1080p_sobel_and_bicubic_match_oracle(oracle):
     """SpatialGradient(sobel) bit-identical and bicubic warp_affine <= 1e-6 on 1080x1920 frames (rotation 2 deg about the
     centre + (3, -2) px)."""
