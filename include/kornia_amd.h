@@ -45,7 +45,7 @@ int km_device_info(char* name, int n);
 int km_set_traversal(int mode);
 /* Launch policy.  The library reads its A/B switches (profiles/README.md: KM_WARP_FWD_ALGO, KM_BLUR_ROWS, ...) from the environment ONCE,
  * when it is first used; no launcher calls getenv.  km_config_set changes one entry explicitly ("traversal_fixed", "warp_fwd_algo",
- * "warp_gm_algo", "warp_bwd_generic", "warp_bwd_fused", "sep_lds", "sg_generic", "pyrdown_separable", "blur_rows") and returns its
+ * "warp_gm_algo", "warp_bwd_generic", "warp_bwd_fused", "sep_lds", "sg_generic", "pyrdown_separable", "blur_rows", "warp_bwd_no_scan") and returns its
  * previous value (-1: unknown key).  For tests and A/B timing - call it between launches, not concurrently with them.  The alternating
  * traversal itself keeps its parity per (device, stream): what one stream launches never changes the order another stream's kernels
  * walk the batch.  (No reference counterpart.) */

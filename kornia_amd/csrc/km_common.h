@@ -351,6 +351,7 @@ struct KmConfig {
     int sg_generic;         // KM_SG_ALGO=generic
     int pyrdown_separable;  // KM_PYRDOWN_ALGO=separable
     int blur_rows;          // KM_BLUR_ROWS=8 / 16 / 32 (0: by storage type, direction, kernel size and size of the launch: km_blur_rows)
+    int warp_bwd_no_scan;   // KM_WARP_BWD_SCAN=0: the one-read backward does not look for non-finite gradients at output pixels that sample entirely outside the source
 };
 const KmConfig& km_config();
 int km_device_cus();

@@ -44,6 +44,7 @@ static void km_config_init() {
     c.pyrdown_separable = km_env_first("KM_PYRDOWN_ALGO", 's');
     const char* br = getenv("KM_BLUR_ROWS");
     c.blur_rows = br ? atoi(br) : 0;
+    c.warp_bwd_no_scan = km_env_first("KM_WARP_BWD_SCAN", '0');
 }
 const KmConfig& km_config() {
     std::call_once(g_km_config_once, km_config_init);
@@ -117,7 +118,7 @@ static int* km_config_field(const char* key) {
         {"warp_gm_algo", &g_km_config.warp_gm_algo},       {"warp_bwd_generic", &g_km_config.warp_bwd_generic},
         {"warp_bwd_fused", &g_km_config.warp_bwd_fused},   {"sep_lds", &g_km_config.sep_lds},
         {"sg_generic", &g_km_config.sg_generic},           {"pyrdown_separable", &g_km_config.pyrdown_separable},
-        {"blur_rows", &g_km_config.blur_rows},
+        {"blur_rows", &g_km_config.blur_rows},                 {"warp_bwd_no_scan", &g_km_config.warp_bwd_no_scan},
     };
     if (key)
         for (auto& e : table)

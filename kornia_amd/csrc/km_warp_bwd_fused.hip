@@ -134,6 +134,7 @@ struct KmWarpFusedArgs {
     // launch sequence with CC = 3 (a groups) and one with CC = 1 (r groups).  All groups of an image add to the same matrix gradient.
     uint32_t c0, ngrp, cc;
     uint32_t first;      // the first launch sequence of the call: it zeroes gmat (boxes) and scans for unvisited non-finite gradients (general)
+    uint32_t scan;       // ... unless the launch policy says not to (KM_WARP_BWD_SCAN=0 / km_config_set("warp_bwd_no_scan", 1): see kmo_scan_unvisited)
 };
 
 __host__ __device__ constexpr int kmo_lds_bytes(int cc) {
@@ -1141,6 +1142,10 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 // one sign sends the block to a convex quad), blocks that may hold an unvisited pixel are tested pixel by pixel with an APPROXIMATE
 // position and a margin (testing a visited pixel as well changes nothing: its gradient already made the result non-finite), and an image
 // with a hit gets NaN added to its accumulators.
+// WHICH REFERENCE.  This is ATen's CPU kernel (the oracle, tests/golden/nonfinite_outside.npz).  ATen's CUDA / HIP grid_sampler backward - what the
+// reference runs on an accelerator - skips out-of-bounds taps instead, and such a gradient leaves the matrix gradient finite.  The launch policy
+// `warp_bwd_no_scan` (KM_WARP_BWD_SCAN=0) selects that behaviour and saves this scan (~20 us of a 0.55 ms backward at config 2: it reads one
+// 128-byte line per row, side and channel along the image's borders); the default is the CPU reference's, which is what parity is pinned to.
 struct KmoScanMap {
     float au, bu, av, bv;  // base coordinates: u = au * j + bu, v = av * i + bv
     float sx, ox, sy, oy;  // source pixel = s * normalised + o
@@ -1287,7 +1292,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
     // (every workgroup of the launch takes its share first: most have nothing else to do; the list borrows the coordinate tables' LDS)
     static_assert((KMT_BAND_W + KMT_TAB) * 16 >= KMO_NT * 4, "the candidate list fits the tables");
-    if (a.first && PADX == 0 && a.gmat) kmo_scan_unvisited<T, CM, ALIGN, CC>(a, (uint32_t*)l.s_u4, l.s_red);  // (border / reflection: every output pixel is some tile's)
+    if (a.first && a.scan && PADX == 0 && a.gmat) kmo_scan_unvisited<T, CM, ALIGN, CC>(a, (uint32_t*)l.s_u4, l.s_red);  // (border / reflection: every output pixel is some tile's)
     // A workgroup of this launch holds a CU's LDS: the grid is one workgroup per persistent worker, each walking its share of the tile
     // groups (a grid of one workgroup per group - 1024 at config 2, four rounds of dispatch with 114 KB of LDS each - cost 45 us per
     // round on some boxes, whatever the workgroups then did: profiles/r04/bwd_general_launch_grid.txt)
@@ -1388,6 +1393,7 @@ static int kmo_launch(const KmWarpFusedArgs<T>& a, hipStream_t s) {
 template <typename T>
 static int kmo_run_groups(KmWarpFusedArgs<T>& a, int B, uint32_t c0, uint32_t ngrp, uint32_t cc, bool first, int coord_mode, hipStream_t s) {
     a.c0 = c0; a.ngrp = ngrp; a.cc = cc; a.first = first ? 1u : 0u;
+    a.scan = km_config().warp_bwd_no_scan ? 0u : 1u;
     const uint64_t ntiles = (uint64_t)a.tiles_x * a.tiles_y * (uint64_t)B * ngrp;
     a.ntiles = (uint32_t)ntiles;
     const int cus = km_device_cus();

@@ -297,6 +297,32 @@ def test_non_finite_gradient_outside_the_source_reference_fixture(fused):
     assert torch.isfinite(gx).all() and torch.allclose(gx, d["persp__gx"], atol=1e-5)
 
 
+def test_launch_policy_without_the_scan_has_the_accelerator_kernels_semantics():
+    """km_config_set("warp_bwd_no_scan", 1) (KM_WARP_BWD_SCAN=0): the one-read backward skips the scan for non-finite gradients at output pixels
+    that sample entirely outside the source - ATen's CUDA / HIP grid_sampler backward skips out-of-bounds taps, so there such a gradient leaves
+    the matrix gradient FINITE (and equal to the gradient of the same input with that entry zeroed); with the default policy the result is
+    the CPU reference's (the fixture above)."""
+    import kornia_amd as K
+    from _util import golden
+    from kornia_amd import _native as N
+
+    d = {k: torch.from_numpy(v) for k, v in golden("nonfinite_outside").items()}
+    go = d["persp__go"].clone()
+    bad = ~torch.isfinite(go)
+    assert bad.any()
+    fn = lambda a, m: K.warp_perspective(a, m, (96, 160))
+    prev = N.lib().km_config_set(b"warp_bwd_no_scan", 1)
+    try:
+        gx, gM = _run(fn, d["persp__x"], d["persp__M"], go, True)
+    finally:
+        N.lib().km_config_set(b"warp_bwd_no_scan", prev)
+    gx0, gM0 = _run(fn, d["persp__x"], d["persp__M"], torch.where(bad, torch.zeros_like(go), go), True)
+    assert torch.isfinite(gM).all() and torch.isfinite(gx).all()
+    assert _rel(gM, gM0) <= 1e-6 and torch.equal(gx, gx0)
+    gx1, gM1 = _run(fn, d["persp__x"], d["persp__M"], go, True)  # the default policy again
+    assert torch.equal(torch.isfinite(gM1), torch.isfinite(d["persp__gM"]))
+
+
 @pytest.mark.parametrize("case", ["growing", "zero_top", "nonfinite_bottom", "shrinking"])
 @pytest.mark.parametrize("angle", [0.0, 30.0])
 def test_fixed_point_scale_follows_the_gradients_of_the_box(oracle, case, angle):
