@@ -721,7 +721,11 @@ static bool km_fwd_generic_forced() {
 //                 degrees: 0.37 - 0.39 ms where the gather kernel takes 0.47 / 0.71 / 0.92);
 //   3. the gather rows of km_warp_fwd_lean_kernel: for a half whose box still does not fit, and - before the squares are tried - for a region
 //      whose output rows stay nearly horizontal in the source (its wide box was too large because the map minifies: gathers are fine there).
-struct KmbWide   { static constexpr int TW = 64, TH = 32, PITCH = 80, ROWS = 40; };
+#ifndef KMB_WIDE_PITCH
+#define KMB_WIDE_PITCH 80
+#define KMB_WIDE_ROWS 40
+#endif
+struct KmbWide   { static constexpr int TW = 64, TH = 32, PITCH = KMB_WIDE_PITCH, ROWS = KMB_WIDE_ROWS; };
 struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50; };
 #define KMB_LDS_FLOATS(NC) ((KmbWide::ROWS * KmbWide::PITCH > KmbSquare::ROWS * KmbSquare::PITCH ? KmbWide::ROWS * KmbWide::PITCH : KmbSquare::ROWS * KmbSquare::PITCH) * (NC))
 #ifndef KMB_WAVES_PER_EU
