@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (measured streaming copy on these boxes: 6.2 TB/s)
-PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(p)), "")
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(p)), "")
 
 
 def csrc_sha256():
