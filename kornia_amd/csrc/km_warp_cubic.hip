@@ -19,6 +19,9 @@
 //     bit-identical to km_warp_fwd_kernel<INTERP = bicubic> (tests compare the two);
 //   * a wave whose footprints are not all inside the staged box (box larger than the LDS tile under minification, NaN
 //     positions, vanishing line) gathers its taps from global memory with the generic kernel's per-tap bounds test.
+#ifndef KMQ_FILL_DMA
+#define KMQ_FILL_DMA 1   // fp32 storage: the source box by LDS-DMA (kmf_stage_box_dma)
+#endif
 #ifndef KMQ_TW
 #define KMQ_TW 64
 #define KMQ_TH 32
@@ -110,7 +113,14 @@ __global__ __launch_bounds__(256) void km_warp_fwd_cubic_kernel(const KmWarpArgs
         float oob[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) oob[c] = 0.f;
-        kmf_stage_box_dyn<T, NC, PITCH>(src_b, src_plane, W, H, bx, s_src, oob);
+#if KMQ_FILL_DMA
+        if constexpr (sizeof(T) == 4) {
+            // fp32 storage: the whole box by LDS-DMA, every pass in flight together (the register copy is three round trips for an 80-row box)
+            kmf_stage_box_dma<NC, PITCH, ROWS>(reinterpret_cast<const float*>(src_b), src_plane, W, H, bx, s_src);
+            KM_VMCNT0();
+        } else
+#endif
+            kmf_stage_box_dyn<T, NC, PITCH>(src_b, src_plane, W, H, bx, s_src, oob);
         __syncthreads();
     }
     if (j >= g.w) return;

@@ -182,6 +182,31 @@ __device__ __forceinline__ void kmf_stage_box_dyn(const T* __restrict__ src_b, s
     }
 }
 
+// The same copy by LDS-DMA (fp32 storage, zeros outside the image): thread t's 16-byte chunk of a pass lands at chunk t of the staged box -
+// a pass is RCPP consecutive (row, channel) pairs of NCHK = PITCH / 4 chunks, the layout s_src[row][channel][PITCH] unchanged - straight
+// from the memory pipe (KM_GLDS16, km_common.h): ALL passes are in flight together (the register copy above waits for four rows at a time)
+// and no register holds the box.  Chunks outside the image are zeros written the ordinary way.  The caller makes the requests land:
+// KM_VMCNT0() and a barrier.
+template <int NC, int PITCH, int ROWS>
+__device__ __forceinline__ void kmf_stage_box_dma(const float* __restrict__ src_b, size_t src_plane, int W, int H, const KmfBox& bx, float* s_src) {
+    static_assert((PITCH % 4) == 0 && PITCH / 4 <= 64, "whole chunks; a staged row fits a wave instruction");
+    constexpr int NCHK = PITCH / 4, RCPP = 256 / NCHK, NPASS = (ROWS * NC + RCPP - 1) / RCPP;
+    const int tid = km_tid_pinned(), ck = tid % NCHK, rq = tid / NCHK;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int xg = bx.xs + 4 * ck;
+    const bool filler = (rq < RCPP) && (ck < bx.nch);
+    const bool col_in = (xg >= 0) && (xg + 3 < W);  // W % 4 == 0 and xs % 4 == 0: a chunk is inside or outside as a whole
+    const int nrc = bx.nrows * NC;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int rc = ps * RCPP + rq, r = rc / NC, c = rc - r * NC, y = bx.ys + r;
+        const bool live = filler && (rc < nrc);
+        const bool inb = live && col_in && (y >= 0) && (y < H);
+        if (inb) KM_GLDS16(km_at(src_b + c * src_plane, (uint32_t)y * (uint32_t)W + (uint32_t)xg), s_src + ps * (RCPP * PITCH) + 4 * wbase);
+        else if (live) *reinterpret_cast<float4*>(s_src + rc * PITCH + 4 * ck) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // the 2 x 2 footprint of a pixel lies in the staged box (NaN / inf positions do not)
 __device__ __forceinline__ bool kmf_in_box(const KmlTaps& t, const KmfBox& bx) {
     return (t.xf >= bx.bxlo) & (t.xf <= bx.bxhi) & (t.yf >= bx.bylo) & (t.yf <= bx.byhi);
