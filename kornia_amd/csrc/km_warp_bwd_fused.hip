@@ -1176,6 +1176,12 @@ __device__ __forceinline__ bool kmo_scan_maybe_unvisited(float x, float y, float
     return !((x > -1.f + e) && (x < W - e) && (y > -1.f + e) && (y < H - e));
 }
 #define KMO_SCAN_BLK 16
+#ifndef KMO_SCAN_NB
+#define KMO_SCAN_NB 2   // candidate blocks a wave scans at a time
+#endif
+#ifndef KMO_SCAN_CH
+#define KMO_SCAN_CH 3   // channels whose loads fly together
+#endif
 // One workgroup classifies KMO_NT blocks at a time (thread = block: its four corners), compacts the candidates into an LDS list and deals
 // them to its 16 waves - the candidates are the blocks along the image's borders, i.e. whole rows of blocks: left with the wave that
 // classified them, a few waves walked 30 - 60 blocks each while the rest had none (180 us for the launch; profiles/r04/bwd_general_launch_grid.txt).
@@ -1225,9 +1231,9 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
         __syncthreads();
         const uint32_t n = *s_count;
         // ---- wave w takes candidates w, w + 16, ... TWO at a time (their matrix loads, then their grad_out loads, fly together):
-        //      64 lanes = 16 columns x 4 rows of a block, four steps ----
-        for (uint32_t it = (uint32_t)wave; it < n; it += 2 * KMO_NW) {
-            constexpr int NB = 2, NS = KMO_SCAN_BLK / 4;
+        //      64 lanes = 16 columns x 4 rows of a block, four steps ----  (KMO_SCAN_NB at a time)
+        for (uint32_t it = (uint32_t)wave; it < n; it += KMO_SCAN_NB * KMO_NW) {
+            constexpr int NB = KMO_SCAN_NB, NS = KMO_SCAN_BLK / 4;
             uint32_t bb[NB], tty[NB], ttx[NB];
             float m[NB][9];
 #pragma unroll
@@ -1253,18 +1259,35 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
                     need[u][rr] = (j < g.w) && (i < g.h) && kmo_scan_maybe_unvisited(x, y, Wf, Hf);
                 }
             }
-            uint32_t worst[NB] = {0u, 0u};  // largest exponent field seen
-            for (int c = 0; c < g.C; ++c) {
+            uint32_t worst[NB];  // largest exponent field seen
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const T* gp = a.gout + ((size_t)bb[u] * g.C + (size_t)c) * dst_plane + (size_t)((int)(ttx[u] * KMO_SCAN_BLK) + (lane & 15));
+            for (int u = 0; u < NB; ++u) worst[u] = 0u;
+            // (the loads of up to KMO_SCAN_CH channels of all NB blocks fly TOGETHER: channel by channel the launch was a chain of memory
+            // round trips - matrices, then each channel of each pair - 26 us for 57 MB)
+            for (int c0 = 0; c0 < g.C; c0 += KMO_SCAN_CH) {
+                T raw[KMO_SCAN_CH][NB][NS];
 #pragma unroll
-                    for (int rr = 0; rr < NS; ++rr) {
-                        const int i = (int)(tty[u] * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
-                        const uint32_t bits = __float_as_uint((float)km_ld(need[u][rr] ? gp + (size_t)i * g.w : a.gout)) & 0x7f800000u;
-                        worst[u] = max(worst[u], need[u][rr] ? bits : 0u);
+                for (int cc = 0; cc < KMO_SCAN_CH; ++cc) {
+                    const int c = min(c0 + cc, g.C - 1);  // (a channel beyond the last repeats it: a max is idempotent)
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const T* gp = a.gout + ((size_t)bb[u] * g.C + (size_t)c) * dst_plane + (size_t)((int)(ttx[u] * KMO_SCAN_BLK) + (lane & 15));
+#pragma unroll
+                        for (int rr = 0; rr < NS; ++rr) {
+                            const int i = (int)(tty[u] * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
+                            raw[cc][u][rr] = *(need[u][rr] ? gp + (size_t)i * g.w : a.gout);
+                        }
                     }
                 }
+#pragma unroll
+                for (int cc = 0; cc < KMO_SCAN_CH; ++cc)
+#pragma unroll
+                    for (int u = 0; u < NB; ++u)
+#pragma unroll
+                        for (int rr = 0; rr < NS; ++rr) {
+                            const uint32_t bits = __float_as_uint((float)km_ld(&raw[cc][u][rr])) & 0x7f800000u;
+                            worst[u] = max(worst[u], need[u][rr] ? bits : 0u);
+                        }
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u)
