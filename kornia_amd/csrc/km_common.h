@@ -327,13 +327,6 @@ __device__ __forceinline__ int km_tid_pinned() {
 }
 #endif
 
-// Pointer for a load at a WAVE-UNIFORM address of memory the kernel does not write: through the constant address space the compiler selects
-// a scalar load (s_load_dword .. x8 into scalar registers, served by the scalar cache, counted by lgkmcnt).  The address must be the same in
-// every lane.  (The host build of the kernels defines it as a plain pointer.)
-#ifndef KM_UNIFORM_PTR
-#define KM_UNIFORM_PTR(TYPE, p) ((const __attribute__((address_space(4))) TYPE*)(p))
-#endif
-
 // Scheduling fence: the compiler does not move instructions across it (no code is emitted).  Used between independent unrolled
 // bodies whose interleaving would raise the register count (the host build of the kernels defines it away).
 #ifndef KM_SCHED_FENCE

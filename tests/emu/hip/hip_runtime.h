@@ -125,7 +125,6 @@ inline int emu_cvt_i32_f32(float v) {
 #define KM_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gsrc), 16)
 #define KM_GLDS4(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 4 * emu::lane_id(), (const void*)(gsrc), 4)
 #define KM_VMCNT0() ((void)0)
-#define KM_UNIFORM_PTR(TYPE, p) ((const TYPE*)(p))  // (no scalar cache on the host: a plain load)
 #define KM_TID_PINNED 1
 inline int km_tid_pinned() { return (int)threadIdx.x; }
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
