@@ -153,3 +153,105 @@ def test_random_box_forward_against_the_gather_kernel(seed):
                 lib.km_config_set(b"warp_fwd_algo", prev)
             outs.append(torch.nan_to_num(o.float(), nan=12345.0, posinf=23456.0, neginf=-23456.0))
         assert torch.equal(outs[0], outs[1]), (kind, fn, (B, C, H, W), (h, w), dtype, align, (outs[0] - outs[1]).abs().max().item())
+
+
+def _sweep_case(seed, big):
+    """One case of the extended sweep, from its seed alone (a failure message names the seed: `_sweep_case(seed, True)` rebuilds it)."""
+    import random
+
+    from _util import flagship_homographies
+
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+
+    def size():
+        if rnd.random() < 0.6:
+            return max(8, 64 * rnd.randint(1, 8 if big else 3) + rnd.choice([-5, -4, -1, 0, 0, 1, 3, 4, 32]))
+        return rnd.randint(30, 560 if big else 200)
+
+    B, C = rnd.choice([1, 2, 3] if big else [1, 2]), rnd.choice([1, 2, 3, 3, 4, 5])
+    H, W = size(), size()
+    h, w = (H, W) if rnd.random() < 0.6 else (size(), size())
+    pad = rnd.choice(["zeros", "zeros", "fill", "border", "reflection"])
+    fn = rnd.choice(["persp", "persp", "affine", "homog"])
+    if pad == "fill" and (C != 3 or fn == "homog"):  # (the reference's fill value is an RGB triple; homography_warp has no fill mode)
+        pad = "zeros"
+    align = rnd.choice([True, False])
+    kind = rnd.choice(["near", "near", "rot"])
+    if fn == "homog":
+        # homography_warp takes the normalised dst -> src map: a perturbation of the identity
+        M = torch.eye(3).repeat(B, 1, 1) + 0.03 * torch.randn(B, 3, 3, generator=g)
+        M[:, 2, 2] = 1.0
+    elif kind == "near":
+        M = flagship_homographies(B, H, W, h, w, g, jitter=rnd.choice([1.0, 4.0, 8.0]))
+    else:
+        M = _random_homography(g, B, H, W, h, w)
+    if fn == "affine":
+        M = M[:, :2, :].contiguous()
+    x = torch.rand(B, C, H, W, generator=g)
+    go = torch.rand(B, C, h, w, generator=g)
+    fill = torch.rand(3, generator=g) if pad == "fill" else None
+    return dict(fn=fn, kind=kind, x=x, M=M, go=go, dsize=(h, w), pad=pad, align=align, fill=fill)
+
+
+def _sweep_run(oracle, c):
+    """The device result and the oracle's for one case: (y, ref, gx, gx_ref, gM, gM_ref)."""
+    import kornia_amd as K
+
+    x, M, go, (h, w), pad, align, fill = c["x"], c["M"], c["go"], c["dsize"], c["pad"], c["align"], c["fill"]
+    xg, Mg = x.cuda().requires_grad_(), M.cuda().requires_grad_()
+    fill_d = None if fill is None else fill.cuda()
+    if c["fn"] == "persp":
+        y = K.warp_perspective(xg, Mg, (h, w), "bilinear", pad, align, fill_d)
+        ref = oracle.warp_perspective(x, M, (h, w), "bilinear", pad, align, fill)
+        gxo, gMo = oracle.warp_perspective_backward(go, x, M, (h, w), "bilinear", pad, align, fill)
+    elif c["fn"] == "affine":
+        y = K.warp_affine(xg, Mg, (h, w), "bilinear", pad, align, fill_d)
+        ref = oracle.warp_affine(x, M, (h, w), "bilinear", pad, align, fill)
+        gxo, gMo = oracle.warp_affine_backward(go, x, M, (h, w), "bilinear", pad, align, fill)
+    else:
+        y = K.homography_warp(xg, Mg, (h, w), "bilinear", pad, align)
+        ref = oracle.homography_warp(x, M, (h, w), "bilinear", pad, align)
+        gxo, gMo = oracle.homography_warp_backward(go, x, M, (h, w), "bilinear", pad, align)
+    y.backward(go.cuda())
+    return y.detach().cpu(), ref, xg.grad.cpu(), gxo, Mg.grad.cpu(), gMo
+
+
+def test_extended_sweep_of_the_warps_at_tile_scale(oracle):
+    """A time-bounded sweep at sizes where images span several 64 x 64 owner tiles / 64 x 32 forward regions (the seeded tests above stay
+    below 150 pixels): sizes drawn around multiples of the tile sizes, near-identity maps (regular tiles: the persistent loop, LDS-DMA
+    staging of ragged / unaligned tiles, runs of tiles) and rotated / scaled ones (general launch, multi-pass boxes), the three entry
+    points, zeros / fill / border / reflection padding.  KM_FUZZ_SECONDS bounds it (default 4, and then at most three tiles a side - also
+    what the host build of the kernels executes); KM_FUZZ_SEED picks the stream.  Every failure names the seed that rebuilds its case."""
+    import os
+    import time
+
+    big = "KM_FUZZ_SECONDS" in os.environ
+    budget = float(os.environ.get("KM_FUZZ_SECONDS", "4"))
+    seed0 = int(os.environ.get("KM_FUZZ_SEED", "0"))
+    t_end = time.time() + budget
+    failures, n = [], 0
+    while time.time() < t_end or n < 3:
+        seed = seed0 * 100000 + n
+        n += 1
+        c = _sweep_case(seed, big)
+        (h, w), (H, W) = c["dsize"], c["x"].shape[-2:]
+        case = f"seed={seed} fn={c['fn']} kind={c['kind']} x={tuple(c['x'].shape)} -> {(h, w)} pad={c['pad']} align={c['align']}"
+        y, ref, gx, gxo, gM, gMo = _sweep_run(oracle, c)
+        if c["fn"] == "homog":
+            # (transform_points' sum order is the BLAS kernel's in the reference, DESIGN.md 2: positions may differ by an ulp of the pixel coordinate)
+            ok = torch.allclose(y, ref, atol=2e-7 * max(H, W, h, w) * 2, rtol=0)
+        else:
+            ok = torch.equal(y, ref)
+        if not ok:
+            failures.append(f"forward {case}: max |d| {(y - ref).abs().max().item():.3e}")
+            continue
+        scale = max(1.0, 4.0 * h * w / (H * W))
+        if not torch.allclose(gx, gxo, atol=2e-5 * scale, rtol=1e-5):
+            failures.append(f"grad_src {case}: max |d| {(gx - gxo).abs().max().item():.3e}")
+        rel = ((gM - gMo).abs().max() / gMo.abs().max().clamp_min(1e-20)).item()
+        # (the oracle's fp32 matrix gradient is itself ~1e-4 accurate at these sizes: SURVEY.md App. C)
+        if not rel < 2e-3:
+            failures.append(f"grad_M {case}: rel {rel:.2e}")
+    print(f"extended sweep: {n} cases in {budget:.0f} s budget, {len(failures)} failures")
+    assert not failures, "\n".join(failures[:20])
