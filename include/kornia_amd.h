@@ -253,6 +253,16 @@ int km_warp_masked_loss(const void* src, const void* dst, const void* mat, doubl
                         int h, int w, int B_M, int coord_mode, int norm_coords, int align, int loss_kind,
                         double threshold, int dtype, void* stream);
 
+/* The rest of get_single_level_loss and of its backward (image_registrator.py:240-245: `.masked_select(...).mean()`, and autograd's
+ * product with the upstream gradient), as two small launches instead of ~nine torch ones:
+ * km_warp_masked_loss_finish: acc (B,11) as written above -> loss[0] = sum_b acc[b][0] / sum_b acc[b][1] (fp64; also as fp32 in loss_f32
+ *   when non-null; 0 / 0 = NaN like the mean of an empty selection) and gm_unit (B_M,9) fp64 = d loss / d mat (summed over the batch
+ *   for B_M == 1).  Deterministic (fixed summation order).
+ * km_scale_f64: out[k] = (out dtype)(in[k] * scale[0]), the product in fp64, rounded once; scale: ONE value on the device
+ *   (the upstream gradient of the scalar loss); scale_dtype / out_dtype 0 (f32) | 1 (f64). */
+int km_warp_masked_loss_finish(const double* acc, int B, int B_M, double* loss, float* loss_f32, double* gm_unit, void* stream);
+int km_scale_f64(const double* in, const void* scale, int scale_dtype, void* out, int out_dtype, long long n, void* stream);
+
 /* ---- transform_points ----------------------------------------------------------------------
  * Replaces kornia/geometry/linalg.py:183-239 (+ conversions.py:247-339).  T (B_T,D+1,D+1),
  * pts/out (B,N,D), D in {2,3}, B_T in {1,B}; dtype 0 | 1. */

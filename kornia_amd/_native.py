@@ -53,6 +53,8 @@ _PROTOTYPES = {
     "km_resize_bilinear_fwd": [_P, _P] + [_I] * 8 + [_P],
     "km_resize_bilinear_bwd": [_P, _P] + [_I] * 8 + [_P],
     "km_warp_masked_loss": [_P, _P, _P, _P] + [_I] * 11 + [c_double, _I, _P],
+    "km_warp_masked_loss_finish": [_P, _I, _I, _P, _P, _P, _P],
+    "km_scale_f64": [_P, _P, _I, _P, _I, ctypes.c_longlong, _P],
     "km_gaussian_taps_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "km_gaussian_taps_dtype_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "km_warp2d_fwd_masked": [_P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],

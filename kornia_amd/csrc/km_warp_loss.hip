@@ -249,7 +249,70 @@ static int kml_run(const void* src, const void* dst, const void* mat, double* ac
     return km_check_launch("km_warp_masked_loss");
 }
 
+// ---- what follows the accumulators: the two sums over the batch and the divisions, ONE launch ------------------------------------------
+// (as torch ops: sum, two index / divide pairs and casts - nine launches of 4 - 10 us around an 86 us kernel at config 5's shape)
+// One workgroup; thread t sums entries t, t + 256, ... of a column in index order, the 256 partials meet in a fixed tree: deterministic.
+__global__ __launch_bounds__(256) void km_warp_loss_finish_kernel(const double* __restrict__ acc, int B, int B_M, double* __restrict__ loss,
+                                                                   float* __restrict__ loss_f32, double* __restrict__ gm_unit) {
+    __shared__ double red[256];
+    __shared__ double tot[11];
+    const int tid = threadIdx.x;
+    const int ncol = (B_M == 1) ? 11 : 2;  // a shared matrix: its nine gradient entries are sums over the batch as well
+    for (int k = 0; k < ncol; ++k) {
+        double s = 0.0;
+        for (int b = tid; b < B; b += 256) s += acc[(size_t)b * 11 + k];
+        red[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) tot[k] = red[0];
+        __syncthreads();
+    }
+    const double n = tot[1];
+    if (tid == 0) {
+        const double l = tot[0] / n;  // 0 / 0 = NaN when nothing is selected, like the mean of an empty selection
+        loss[0] = l;
+        if (loss_f32) loss_f32[0] = (float)l;
+    }
+    if (B_M == 1) {
+        if (tid < 9) gm_unit[tid] = tot[2 + tid] / n;
+    } else {
+        for (int e = tid; e < B * 9; e += 256) gm_unit[e] = acc[(size_t)(e / 9) * 11 + 2 + (e % 9)] / n;
+    }
+}
+
+// out[k] = (out type)(in[k] * (double)scale[0]): the product with the upstream gradient of the scalar loss, formed in fp64 and rounded once
+template <typename TS, typename TO>
+__global__ __launch_bounds__(256) void km_scale_f64_kernel(const double* __restrict__ in, const TS* __restrict__ scale, TO* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (TO)(in[i] * (double)scale[0]);
+}
+
 extern "C" {
+
+int km_warp_masked_loss_finish(const double* acc, int B, int B_M, double* loss, float* loss_f32, double* gm_unit, void* stream) {
+    KM_REQUIRE(B >= 1 && (B_M == 1 || B_M == B), "km_warp_masked_loss_finish: B >= 1 and B_M in {1, B} (got B=%d, B_M=%d)", B, B_M);
+    KM_REQUIRE(acc && loss && gm_unit, "km_warp_masked_loss_finish: null pointer");
+    hipLaunchKernelGGL(km_warp_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc, B, B_M, loss, loss_f32, gm_unit);
+    return km_check_launch("km_warp_masked_loss_finish");
+}
+
+int km_scale_f64(const double* in, const void* scale, int scale_dtype, void* out, int out_dtype, long long n, void* stream) {
+    KM_REQUIRE(n >= 0, "km_scale_f64: n must be >= 0");
+    KM_REQUIRE((scale_dtype == KM_F32 || scale_dtype == KM_F64) && (out_dtype == KM_F32 || out_dtype == KM_F64), "km_scale_f64: dtypes must be f32 (0) or f64 (1)");
+    if (n == 0) return 0;
+    KM_REQUIRE(in && scale && out, "km_scale_f64: null pointer");
+    KM_REQUIRE((n + 255) / 256 < (1ll << 31), "km_scale_f64: grid too large");
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (scale_dtype == KM_F32 && out_dtype == KM_F32) hipLaunchKernelGGL((km_scale_f64_kernel<float, float>), grid, block, 0, s, in, (const float*)scale, (float*)out, n);
+    else if (scale_dtype == KM_F32) hipLaunchKernelGGL((km_scale_f64_kernel<float, double>), grid, block, 0, s, in, (const float*)scale, (double*)out, n);
+    else if (out_dtype == KM_F32) hipLaunchKernelGGL((km_scale_f64_kernel<double, float>), grid, block, 0, s, in, (const double*)scale, (float*)out, n);
+    else hipLaunchKernelGGL((km_scale_f64_kernel<double, double>), grid, block, 0, s, in, (const double*)scale, (double*)out, n);
+    return km_check_launch("km_scale_f64");
+}
 
 int km_warp_masked_loss(const void* src, const void* dst, const void* mat, double* acc, int B, int C, int H, int W, int h, int w, int B_M,
                         int coord_mode, int norm_coords, int align, int loss_kind, double threshold, int dtype, void* stream) {

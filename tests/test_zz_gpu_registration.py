@@ -156,3 +156,29 @@ def test_fused_loss_linearity_at_full_size():
     whole = t.masked_warp_loss(x, y, H)
     parts = torch.stack([t.masked_warp_loss(x[i : i + 1], y[i : i + 1], H[i : i + 1]) for i in range(0, 64, 16)])
     assert abs(whole.item() - 0.33) < 0.05 and (parts - whole).abs().max().item() < 0.02
+
+
+def test_tail_of_the_fused_loss_scales_sums_and_casts_like_autograd(oracle):
+    """km_warp_masked_loss_finish / km_scale_f64 (the two launches that replace the torch ops behind the accumulators): an upstream gradient other than one,
+    a float64 model, more images than the finishing workgroup has threads (its strided sums), a shared matrix at that batch."""
+    t = T()
+    g = torch.Generator().manual_seed(11)
+    B = 300
+    src, dst = torch.rand(B, 1, 12, 16, generator=g), torch.rand(B, 1, 12, 16, generator=g)
+    H = torch.eye(3)[None].repeat(B, 1, 1) + 0.05 * (torch.rand(B, 3, 3, generator=g) - 0.5)
+    for Hm in (H, H[:1]):
+        ref, gref = oracle.masked_warp_loss(src, dst, Hm, "l1", False)
+        for dt in (torch.float32, torch.float64):
+            Hg = Hm.to(dt).cuda().requires_grad_(True)
+            loss = t.masked_warp_loss(src.cuda(), dst.cuda(), Hg, "l1", False)
+            (2.5 * loss).backward()
+            assert Hg.grad.dtype == dt and Hg.grad.shape == Hm.shape
+            assert abs(loss.item() - ref.item()) < 1e-6
+            assert _rel(Hg.grad.cpu().float(), 2.5 * gref) < 5e-5
+    # an upstream gradient in another dtype than float32 / float64 takes the torch ops: same numbers
+    Hg = H[:4].cuda().requires_grad_(True)
+    lo = t.masked_warp_loss(src[:4].cuda().half(), dst[:4].cuda().half(), Hg, "l1")
+    lo.backward()
+    Hf = H[:4].cuda().requires_grad_(True)
+    t.masked_warp_loss(src[:4].cuda().half().float(), dst[:4].cuda().half().float(), Hf, "l1").backward()
+    assert lo.dtype == torch.float16 and _rel(Hg.grad, Hf.grad) < 2e-2
