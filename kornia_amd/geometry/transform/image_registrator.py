@@ -46,8 +46,8 @@ class _MaskedWarpLoss(torch.autograd.Function):
                                             COORD_HOMOGRAPHY, norm, align, kind, float(threshold), N.dtype_code(x.dtype),
                                             N.stream_ptr(dev)), "km_warp_masked_loss")
         # the sums over the batch, the mean and the unit gradient: one small launch (was ~nine torch ops around an 86 us kernel)
-        loss64 = torch.empty(1, device=dev, dtype=torch.float64)
-        loss32 = torch.empty(1, device=dev, dtype=torch.float32) if src.dtype == torch.float32 else None
+        loss64 = torch.empty((), device=dev, dtype=torch.float64)
+        loss32 = torch.empty((), device=dev, dtype=torch.float32) if src.dtype == torch.float32 else None  # (0-dim, returned as is: a view would forbid the caller's in-place ops)
         gm_unit = torch.empty(B_M, 9, device=dev, dtype=torch.float64)
         with N.device_guard(dev):
             N.check(lib.km_warp_masked_loss_finish(acc.data_ptr(), B, B_M, loss64.data_ptr(), N.ptr(loss32), gm_unit.data_ptr(), N.stream_ptr(dev)),
@@ -55,7 +55,7 @@ class _MaskedWarpLoss(torch.autograd.Function):
         ctx.save_for_backward(gm_unit)
         ctx.mat_shape, ctx.mat_dtype = mat.shape, mat.dtype
         # 0 / 0 = nan when nothing is selected, like the mean of an empty selection
-        return loss32.view(()) if loss32 is not None else loss64.view(()).to(src.dtype)
+        return loss32 if loss32 is not None else loss64.to(src.dtype)
 
     @staticmethod
     def backward(ctx, gout):

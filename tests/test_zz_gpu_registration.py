@@ -182,3 +182,10 @@ def test_tail_of_the_fused_loss_scales_sums_and_casts_like_autograd(oracle):
     Hf = H[:4].cuda().requires_grad_(True)
     t.masked_warp_loss(src[:4].cuda().half().float(), dst[:4].cuda().half().float(), Hf, "l1").backward()
     assert lo.dtype == torch.float16 and _rel(Hg.grad, Hf.grad) < 2e-2
+    # the loss is a tensor of its own, not a view of a buffer of the launch: callers add to it in place (the reference's registrator tests do)
+    Hg = H[:4].cuda().requires_grad_(True)
+    loss = t.masked_warp_loss(src[:4].cuda(), dst[:4].cuda(), Hg, "l1")
+    assert not loss._is_view() and loss.dim() == 0
+    loss += 1.0
+    loss.backward()
+    assert torch.isfinite(Hg.grad).all()
