@@ -48,6 +48,14 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert lib.km_filter2d_sep_supported(5, 5, 1, 0) == 3 and lib.km_filter2d_sep_supported(23, 23, 1, 0) == 1
     assert lib.km_filter2d_sep_supported(99, 5, 1, 0) == 0
     assert lib.km_warp2d_bwd_needs_zero_init(1, 0, 0) == 0 and lib.km_warp2d_bwd_needs_zero_init(2, 0, 0) == 1
+    # the tail of the fused loss step
+    rc = lib.km_warp_masked_loss_finish(buf, 4, 2, buf, None, buf, None)  # B_M must be 1 or B
+    assert rc < 0 and b"B_M in {1, B}" in lib.km_last_error()
+    rc = lib.km_warp_masked_loss_finish(None, 4, 4, buf, None, buf, None)
+    assert rc < 0 and b"null pointer" in lib.km_last_error()
+    rc = lib.km_scale_f64(buf, buf, 2, buf, 0, 9, None)  # a bf16 scale
+    assert rc < 0 and b"dtypes must be f32 (0) or f64 (1)" in lib.km_last_error()
+    assert lib.km_scale_f64(None, None, 0, None, 0, 0, None) == 0  # nothing to do
 
 
 def test_no_cpu_fallback():
