@@ -255,3 +255,64 @@ def test_extended_sweep_of_the_warps_at_tile_scale(oracle):
             failures.append(f"grad_M {case}: rel {rel:.2e}")
     print(f"extended sweep: {n} cases in {budget:.0f} s budget, {len(failures)} failures")
     assert not failures, "\n".join(failures[:20])
+
+
+def _filter_sweep_case(seed, big):
+    import random
+
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(seed)
+    hi = 640 if big else 150
+    B, C = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 3, 4])
+    # heights around multiples of the strip heights (8 / 16 / 32 rows x 4 waves), widths around multiples of the 256-column blocks; widths that are
+    # not multiples of 4 take the LDS kernels
+    H = max(3, rnd.choice([rnd.randint(3, hi), 32 * rnd.randint(1, hi // 32) + rnd.choice([-3, -1, 0, 1, 2, 5])]))
+    W = max(8, rnd.choice([4 * rnd.randint(2, hi // 4), 256 * rnd.randint(1, max(1, hi // 256)) + rnd.choice([-4, 0, 4, 8]), rnd.randint(8, hi)]))
+    ks = rnd.choice([3, 5, 5, 7, 9])
+    if rnd.random() < 0.15:
+        ks = rnd.choice([11, 15, 23])  # the large separable kernel
+    border = rnd.choice(["constant", "reflect", "reflect", "replicate", "circular"])
+    if border == "reflect":
+        H, W = max(H, ks // 2 + 1), max(W, ks // 2 + 1)  # F.pad's own limit: the reflection stays inside the image
+    H, W = max(H, ks), max(W, ks)
+    sigma = (0.4 + 2.5 * rnd.random(), 0.4 + 2.5 * rnd.random())
+    x = torch.rand(B, C, H, W, generator=g)
+    go = torch.rand(B, C, H, W, generator=g)
+    return dict(x=x, go=go, ks=ks, border=border, sigma=sigma, mode=rnd.choice(["sobel", "diff"]), order=rnd.choice([1, 2]))
+
+
+def test_extended_sweep_of_the_filters(oracle):
+    """The same time-bounded sweep for the filter side: gaussian_blur2d forward and adjoint (register-tiled kernel at its three strip heights' edge cases, the
+    LDS kernels for widths that are not multiples of 4, the large separable kernel), spatial_gradient, at sizes of several blocks a side with
+    KM_FUZZ_SECONDS set (default: 4 seconds, up to 150 pixels - what the host build executes).  Bit-identical forward, adjoint within 2e-6."""
+    import os
+    import time
+
+    import kornia_amd as K
+
+    big = "KM_FUZZ_SECONDS" in os.environ
+    budget = float(os.environ.get("KM_FUZZ_SECONDS", "4"))
+    seed0 = int(os.environ.get("KM_FUZZ_SEED", "0"))
+    t_end = time.time() + budget
+    failures, n = [], 0
+    while time.time() < t_end or n < 3:
+        seed = 50000000 + seed0 * 100000 + n
+        n += 1
+        c = _filter_sweep_case(seed, big)
+        x, go, ks, border, sigma = c["x"], c["go"], c["ks"], c["border"], c["sigma"]
+        case = f"seed={seed} x={tuple(x.shape)} k={ks} border={border}"
+        xg = x.cuda().requires_grad_()
+        y = K.gaussian_blur2d(xg, (ks, ks), sigma, border)
+        ref = oracle.gaussian_blur2d(x, (ks, ks), sigma, border)
+        if not torch.equal(y.detach().cpu(), ref):
+            failures.append(f"blur forward {case}: max |d| {(y.detach().cpu() - ref).abs().max().item():.3e}")
+            continue
+        y.backward(go.cuda())
+        gref = oracle.gaussian_blur2d_backward(go, x, (ks, ks), sigma, border)
+        if not torch.allclose(xg.grad.cpu(), gref, atol=2e-6, rtol=1e-5):
+            failures.append(f"blur adjoint {case}: max |d| {(xg.grad.cpu() - gref).abs().max().item():.3e}")
+        sg = K.spatial_gradient(x.cuda(), c["mode"], c["order"]).cpu()
+        if not torch.equal(sg, oracle.spatial_gradient(x, c["mode"], c["order"], True)):
+            failures.append(f"spatial_gradient {case} mode={c['mode']} order={c['order']}")
+    print(f"extended filter sweep: {n} cases in {budget:.0f} s budget, {len(failures)} failures")
+    assert not failures, "\n".join(failures[:20])
