@@ -217,6 +217,17 @@ def _sweep_run(oracle, c):
     return y.detach().cpu(), ref, xg.grad.cpu(), gxo, Mg.grad.cpu(), gMo
 
 
+def _sweep_forward_16(oracle, c, dt):
+    import kornia_amd as K
+
+    x, M, (h, w), pad, align = c["x"].to(dt), c["M"], c["dsize"], c["pad"], c["align"]
+    if c["fn"] == "persp":
+        return (K.warp_perspective(x.cuda(), M.cuda(), (h, w), "bilinear", pad, align).cpu(),
+                oracle.warp_perspective(x.float(), M, (h, w), "bilinear", pad, align).to(dt))
+    return (K.warp_affine(x.cuda(), M.cuda(), (h, w), "bilinear", pad, align).cpu(),
+            oracle.warp_affine(x.float(), M, (h, w), "bilinear", pad, align).to(dt))
+
+
 def test_extended_sweep_of_the_warps_at_tile_scale(oracle):
     """A time-bounded sweep at sizes where images span several 64 x 64 owner tiles / 64 x 32 forward regions (the seeded tests above stay
     below 150 pixels): sizes drawn around multiples of the tile sizes, near-identity maps (regular tiles: the persistent loop, LDS-DMA
@@ -249,6 +260,12 @@ def test_extended_sweep_of_the_warps_at_tile_scale(oracle):
         scale = max(1.0, 4.0 * h * w / (H * W))
         if not torch.allclose(gx, gxo, atol=2e-5 * scale, rtol=1e-5):
             failures.append(f"grad_src {case}: max |d| {(gx - gxo).abs().max().item():.3e}")
+        if seed % 3 == 0 and c["fn"] != "homog" and c["pad"] != "fill":
+            # 16-bit storage: exactly the fp32 result of the rounded image, rounded to the storage type
+            dt = torch.bfloat16 if seed % 2 else torch.float16
+            y16, ref16 = _sweep_forward_16(oracle, c, dt)
+            if not torch.equal(y16, ref16):
+                failures.append(f"forward {dt} {case}: max |d| {(y16.float() - ref16.float()).abs().max().item():.3e}")
         rel = ((gM - gMo).abs().max() / gMo.abs().max().clamp_min(1e-20)).item()
         # (the oracle's fp32 matrix gradient is itself ~1e-4 accurate at these sizes: SURVEY.md App. C)
         if not rel < 2e-3:
