@@ -363,11 +363,23 @@ def _geometric_apply(original: Callable, kind: str) -> Callable:
 
 
 def patch() -> int:
-    """Activate the native path inside Kornia. Returns the number of rebound module attributes."""
+    """Activate the native path inside Kornia. Returns the number of rebound module attributes.
+
+    All or nothing: if the installed Kornia lacks one of the modules / attributes the hooks bind to (another release's layout), everything
+    rebound so far is restored before the error propagates - no half-patched library, and a later ``patch()`` starts from scratch."""
     if _patched:
         return 0
     import kornia  # noqa: F401 - must be importable
 
+    try:
+        return _patch_all()
+    except BaseException:
+        _patched.setdefault(0, (None, None))  # (unpatch() returns early on an empty table: the method hooks are undone below either way)
+        unpatch()
+        raise
+
+
+def _patch_all() -> int:
     for mod_name, table in _NATIVE.items():
         mod = importlib.import_module(mod_name)
         for name, native in table.items():
@@ -427,7 +439,7 @@ def unpatch() -> int:
     """Restore Kornia's own functions."""
     if not _patched:
         return 0
-    by_wrapper = {id(w): o for o, w in _patched.values()}
+    by_wrapper = {id(w): o for o, w in _patched.values() if w is not None}
     count = 0
     for mod_name, mod in list(sys.modules.items()):
         if mod is None or not (mod_name == "kornia" or mod_name.startswith("kornia.")):

@@ -61,6 +61,43 @@ def test_patch_and_unpatch():
     assert aff_mod.warp_affine is orig and not P.is_patched()
 
 
+def test_patch_is_all_or_nothing(monkeypatch):
+    """A Kornia whose layout lacks one of the hooked modules (another release): patch() raises, and NOTHING stays rebound - neither the
+    by-value imports of the functions nor the methods hooked before the failure; a later patch() on a complete library works."""
+    K = ref_shim.import_reference()
+    import importlib
+
+    import kornia.augmentation._2d.geometric.affine as aff_mod
+    import kornia.augmentation._2d.intensity.color_jitter as cj_mod
+    import kornia.augmentation.base as base_mod
+
+    import kornia_amd.kornia_patch as P
+
+    assert not P.is_patched()
+    before = (aff_mod.warp_affine, K.filters.gaussian_blur2d, cj_mod.ColorJitter.apply_transform, aff_mod.RandomAffine.compute_transformation,
+              base_mod._AugmentationBase.__dict__["_blend_by_prob"], base_mod._AugmentationBase.transform_inputs)
+    real_import = importlib.import_module
+
+    def import_module(name, *a, **k):
+        if name == "kornia.augmentation._2d.geometric.shear":  # (one of the last modules patch() touches)
+            raise ModuleNotFoundError(f"No module named {name!r}")
+        return real_import(name, *a, **k)
+
+    monkeypatch.setattr(P.importlib, "import_module", import_module)
+    with pytest.raises(ModuleNotFoundError):
+        P.patch()
+    monkeypatch.undo()
+    after = (aff_mod.warp_affine, K.filters.gaussian_blur2d, cj_mod.ColorJitter.apply_transform, aff_mod.RandomAffine.compute_transformation,
+             base_mod._AugmentationBase.__dict__["_blend_by_prob"], base_mod._AugmentationBase.transform_inputs)
+    assert not P.is_patched() and all(a is b for a, b in zip(before, after))
+    n = P.patch()
+    try:
+        assert n > 20 and aff_mod.warp_affine is not before[0]
+    finally:
+        assert P.unpatch() == n
+    assert aff_mod.warp_affine is before[0]
+
+
 def test_oracle_vs_live_reference_config2_like(oracle):
     K = ref_shim.import_reference()
     from _util import flagship_homographies
