@@ -63,7 +63,7 @@ def test_emulator_schedules_expose_a_missing_barrier():
     if build_emu.UBSAN:
         pytest.skip("the toy kernels are not linked against the sanitizer runtime")
     build_emu.build()
-    so = os.path.join(build_emu.OUT, "libselftest.so")
+    so = os.path.join(build_emu.OUT, f"libselftest{os.environ.get('PYTEST_XDIST_WORKER', '')}.so")  # (one per worker process of a parallel run)
     subprocess.run([build_emu.CXX, *build_emu._flags(), "-shared", "-Wl,-Bsymbolic", os.path.join(build_emu.EMU, "selftest_kernels.hip"),
                     os.path.join(build_emu.EMU, "emu_runtime.cpp"), "-o", so], check=True)
     h = ctypes.CDLL(so)

@@ -58,6 +58,7 @@ def _span(path, tag):
 
 def _build(name, mutate=None):
     os.makedirs(BUILD, exist_ok=True)
+    name = name + os.environ.get("PYTEST_XDIST_WORKER", "")  # (a worker process of a parallel run builds a library of its own)
     src = os.path.join(BUILD, name + ".cpp")
     so = os.path.join(BUILD, "lib" + name + ".so")
     box = _span(os.path.join(CSRC, "km_warp_tile.h"), "tile_box")
