@@ -32,7 +32,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on these hosts needs dmabuf IPC (RCCL's peer buffers fail with `hipIpcGetMemHandle: invalid argument` otherwise); the
+# driver's environment exports it already - kept here for a launch from a bare shell, before the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
