@@ -350,6 +350,10 @@ void KO(ko_warp2d_fwd)(const REAL* src, const REAL* mat, REAL* out, int B, int C
                     long x0 = (long)xf, y0 = (long)yf, x1 = x0 + 1, y1 = y0 + 1;
                     REAL nw = ((REAL)x1 - x) * ((REAL)y1 - y), ne = (x - (REAL)x0) * ((REAL)y1 - y);
                     REAL sw = ((REAL)x1 - x) * (y - (REAL)y0), se = (x - (REAL)x0) * (y - (REAL)y0);
+                    /* NOT pinned, and known to differ from the reference: a NaN / inf coordinate (singular matrix) converts to
+                     * LONG_MIN here, so all four taps are skipped and the pixel is 0 / the fill colour - the rule the kernels
+                     * implement - where ATen's CPU sampler multiplies its masked-out zeros by the NaN weights and returns NaN
+                     * (tests/test_reference_edge_inputs.py states both sides against the live reference). */
                     int bnw = (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H), bne = (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H);
                     int bsw = (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H), bse = (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H);
                     REAL mask = 0;
