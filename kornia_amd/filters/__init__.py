@@ -23,8 +23,11 @@ from .kernels import (
 from .sobel import Sobel, SpatialGradient, sobel, spatial_gradient
 
 # reference aliases (kornia/filters/filter.py:460-548)
-correlate2d = filter2d
+def correlate2d(input, kernel, border_type="reflect", normalized=False, padding="same"):
+    """filter2d with behaviour='corr' (kornia/filters/filter.py:460-502: no `behaviour` argument of its own)"""
+    return filter2d(input, kernel, border_type, normalized, padding, behaviour="corr")
 
 
 def convolve2d(input, kernel, border_type="reflect", normalized=False, padding="same"):
+    """filter2d with behaviour='conv', the kernel flipped (kornia/filters/filter.py:505-548)"""
     return filter2d(input, kernel, border_type, normalized, padding, behaviour="conv")

@@ -177,3 +177,50 @@ def test_nonfinite_coordinates_gradients_stay_finite_on_the_native_path(env):
     assert torch.equal(xa.grad[0], torch.zeros_like(xa.grad[0]))
     assert torch.allclose(xa.grad[1], xr.grad[1], atol=1e-5, rtol=0)
     assert not torch.isfinite(xr.grad[0]).all() or torch.equal(xr.grad[0], torch.zeros_like(xr.grad[0]))
+
+
+def _mirrored_pairs(K):
+    """(reference callable, native callable) for every public name the package mirrors: the drop-in claim of SURVEY 8(b) is 'same
+    names, argument meaning and error behaviour', so each pair must have the same parameter names, order, kinds and defaults."""
+    import kornia_amd as A
+    import kornia_amd.enhance as AE
+    import kornia_amd.filters as AF
+    import kornia_amd.geometry as AG
+    import kornia_amd.geometry.transform as AT
+
+    pairs = []
+    for ref_mod, nat_mod, names in (
+        (K.geometry.transform, AT, [n for n in AT.__all__ if n not in ("warp_affine_blur", "warp_perspective_blur", "masked_warp_loss", "resize_bilinear", "grid_sample")]),
+        (K.filters, AF, [n for n in dir(AF) if not n.startswith("_") and n not in ("blur", "filter", "gaussian", "kernels", "canny", "sobel") or n in ("canny", "sobel")]),
+        (K.geometry, AG, ["transform_points", "normalize_homography", "normal_transform_pixel", "convert_affinematrix_to_homography", "create_meshgrid",
+                          "normalize_pixel_coordinates", "convert_points_from_homogeneous", "convert_points_to_homogeneous"]),
+        (K.enhance, AE, ["adjust_hue"]),
+        (K.enhance.adjust, AE, ["adjust_brightness_accumulative", "adjust_contrast_with_mean_subtraction", "adjust_saturation_with_gray_subtraction"]),
+    ):
+        for n in names:
+            r, a = getattr(ref_mod, n, None), getattr(nat_mod, n, None)
+            if r is None or a is None or isinstance(a, type(os)):
+                continue
+            if isinstance(a, type):
+                pairs.append((f"{n}.__init__", r.__init__, a.__init__))
+                if "forward" in a.__dict__ and hasattr(r, "forward"):
+                    pairs.append((f"{n}.forward", r.forward, a.forward))
+            elif callable(a):
+                pairs.append((n, r, a))
+    return pairs
+
+
+def test_every_mirrored_name_has_the_references_signature():
+    import inspect
+
+    K = ref_shim.import_reference()
+    pairs = _mirrored_pairs(K)
+    assert len(pairs) >= 70, len(pairs)
+    wrong = []
+    for name, r, a in pairs:
+        a = getattr(a, "__wrapped__", a) if not hasattr(a, "__signature__") else a
+        pr, pa = inspect.signature(r).parameters, inspect.signature(a).parameters
+        same = list(pr) == list(pa) and all(pr[k].kind == pa[k].kind and repr(pr[k].default) == repr(pa[k].default) for k in pr)
+        if not same:
+            wrong.append((name, str(inspect.signature(r)), str(inspect.signature(a))))
+    assert not wrong, wrong
