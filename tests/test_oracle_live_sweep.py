@@ -150,3 +150,106 @@ def test_oracle_matches_the_live_reference_on_random_filters(oracle):
         else:
             assert err <= 1e-5, (n, op, x.shape, bt, err)
     assert n >= 60
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host build of the kernels needs ROCm's clang++")
+def test_native_path_matches_the_live_reference_on_random_warps_with_gradients():
+    """The third side of the triangle, drawn the same way: the package (its kernels' host build, tests/emu) against the live reference,
+    forward AND both gradients through the public autograd API with a random upstream gradient.  Forward bit-identical (bicubic <= 2e-6);
+    image gradient <= 2e-5 and matrix gradient <= 5e-4 of their largest entry (recorded: 2 500 cases, 4.7e-6 and 6.3e-5 - border padding
+    sums thousands of output pixels into one source pixel, in another order than ATen's)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    K = ref_shim.import_reference()
+    from mode import emulated_device
+
+    import kornia_amd.geometry.transform as AT
+
+    d = _Draw(31337)
+    t0, n = time.time(), 0
+    with emulated_device():
+        while time.time() - t0 < SECONDS or n < 40:
+            x, M, dsize, kw = _case(d)
+            entry = ("warp_perspective", "warp_affine")[d.int(0, 1)]
+            if entry == "warp_affine":
+                M = M[:, :2]
+            xr, Mr = x.clone().requires_grad_(True), M.clone().requires_grad_(True)
+            xa, Ma = x.cuda().requires_grad_(True), M.cuda().requires_grad_(True)
+            ref = getattr(K.geometry.transform, entry)(xr, Mr, dsize, **kw)
+            out = getattr(AT, entry)(xa, Ma, dsize, **kw)
+            go = d.rand(*ref.shape)
+            ref.backward(go)
+            out.backward(go.cuda())
+            what = (n, entry, tuple(x.shape), dsize, kw)
+            if kw["mode"] == "bicubic":
+                assert (out - ref).abs().max().item() <= 2e-6, what
+            else:
+                assert torch.equal(out, ref), what
+            assert (xa.grad - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item()), what
+            if kw["mode"] != "nearest":
+                # second term: the matrix gradient is a sum over all output elements of terms up to ~(coordinate x pixel), which can cancel
+                # to nothing (every bicubic tap clamped to one border pixel: the true gradient is 0, both sides return rounding noise)
+                noise = 2e-7 * go.numel() * max(x.shape[-2:] + dsize)
+                assert (Ma.grad - Mr.grad).abs().max().item() <= 5e-4 * max(1.0, Mr.grad.abs().max().item()) + noise, what
+            else:
+                assert not Ma.grad.any() and not Mr.grad.any(), what
+            n += 1
+    assert n >= 40
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host build of the kernels needs ROCm's clang++")
+def test_native_path_matches_the_live_reference_on_random_filters_with_gradients():
+    """Same for the filters (more than one plane per batch, see the oracle sweep above): forward bit-identical (sobel: one ulp), gradient
+    wrt the input <= 1e-5 and wrt a filter2d kernel <= 1e-4 of the largest entry (recorded: 2 100 cases, 4.8e-7 and 0).  A NORMALISED
+    kernel's gradient is the difference of sums of ~numel products that cancel to first order (the taps sum to a constant), so its error is
+    bounded against those sums: 2e-7 per output element, over the L1 norm the taps were divided by."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    K = ref_shim.import_reference()
+    from mode import emulated_device
+
+    import kornia_amd.filters as AF
+
+    def rel(a, b):
+        return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+
+    d = _Draw(271828)
+    t0, n = time.time(), 0
+    with emulated_device():
+        while time.time() - t0 < SECONDS or n < 40:
+            B, C, H, W = d.int(1, 3), d.int(2, 4), d.int(9, 60), d.int(9, 60)
+            x, op, bt = d.rand(B, C, H, W), d.int(0, 4), BORDERS[d.int(0, 3)]
+            xr, xa, kr, ka, normalized = x.clone().requires_grad_(True), x.cuda().requires_grad_(True), None, None, False
+            if op == 0:
+                k = d.rand(1 if d.int(0, 1) else B, d.int(1, 9), d.int(1, 9)) - 0.3
+                kr, ka = k.clone().requires_grad_(True), k.cuda().requires_grad_(True)
+                normalized = bool(d.int(0, 1))
+                rest = (bt, normalized, ("same", "valid")[d.int(0, 1)], ("corr", "conv")[d.int(0, 1)])
+                ref, out = K.filters.filter2d(xr, kr, *rest), AF.filter2d(xa, ka, *rest)
+            elif op == 1:
+                kx, ky = d.rand(1, d.int(1, 9)), d.rand(1, d.int(1, 9))
+                rest = (bt, bool(d.int(0, 1)), ("same", "valid")[d.int(0, 1)])
+                ref, out = K.filters.filter2d_separable(xr, kx, ky, *rest), AF.filter2d_separable(xa, kx.cuda(), ky.cuda(), *rest)
+            elif op == 2:
+                rest = ((2 * d.int(0, 4) + 1, 2 * d.int(0, 4) + 1), (0.2 + 3 * d.rand(1).item(), 0.2 + 3 * d.rand(1).item()), bt, bool(d.int(0, 1)))
+                ref, out = K.filters.gaussian_blur2d(xr, *rest), AF.gaussian_blur2d(xa, *rest)
+            elif op == 3:
+                rest = (("sobel", "diff")[d.int(0, 1)], d.int(1, 2), bool(d.int(0, 1)))
+                ref, out = K.filters.spatial_gradient(xr, *rest), AF.spatial_gradient(xa, *rest)
+            else:
+                rest = (bool(d.int(0, 1)), 1e-6)
+                ref, out = K.filters.sobel(xr, *rest), AF.sobel(xa, *rest)
+            go = d.rand(*ref.shape)
+            ref.backward(go)
+            out.backward(go.cuda())
+            what = (n, op, tuple(x.shape), rest)
+            if op == 4:
+                assert (out - ref).abs().max().item() <= 1.2e-7 * max(1.0, 2 * ref.abs().max().item()), what
+            else:
+                assert torch.equal(out, ref), what
+            assert rel(xa.grad, xr.grad) <= 1e-5, what
+            if kr is not None:
+                if normalized:
+                    assert rel(ka.grad, kr.grad) <= 1e-4 or (ka.grad - kr.grad).abs().max().item() <= 2e-7 * go.numel() / k.abs().sum((-2, -1)).min().item(), what
+                else:
+                    assert rel(ka.grad, kr.grad) <= 1e-4, what
+            n += 1
+    assert n >= 40
