@@ -253,3 +253,89 @@ def test_native_path_matches_the_live_reference_on_random_filters_with_gradients
                     assert rel(ka.grad, kr.grad) <= 1e-4, what
             n += 1
     assert n >= 40
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host build of the kernels needs ROCm's clang++")
+def test_native_callers_match_the_live_reference_on_random_inputs():
+    """The rows either side of the path, forward, same draw: explicit-grid sampling and remap, transform_points, the
+    pyramid steps, the four ColorJitter adjustments, the matrix builders, normalize_homography, canny / laplacian / box_blur /
+    unsharp_mask, rotate.  Bounds = the recorded worst case of a 100 s run (~2 000 cases per row) with head-room, 0 where it was 0."""
+    import torch.nn.functional as F
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    K = ref_shim.import_reference()
+    from mode import emulated_device
+
+    import kornia_amd.enhance as AE
+    import kornia_amd.filters as AF
+    import kornia_amd.geometry as AG
+    import kornia_amd.geometry.transform as AT
+
+    bound = {
+        "grid_sample bilinear": 0, "grid_sample nearest": 0, "grid_sample bicubic": 2e-6, "remap": 0, "transform_points": 1e-4, "pyrdown": 1e-6, "pyrup": 1e-6,
+        "contrast": 5e-7, "saturation": 5e-7, "brightness": 0, "hue": 5e-6, "get_rotation_matrix2d": 0, "get_affine_matrix2d": 3e-5,
+        "get_perspective_transform": 2e-6, "normalize_homography": 0, "canny": 0, "laplacian": 5e-7, "box_blur": 5e-7, "unsharp_mask": 0, "rotate": 0,
+    }  # fmt: skip
+    seen = {}
+
+    def check(name, ref, out):
+        refs, outs = (ref, out) if isinstance(ref, (list, tuple)) else ([ref], [out])
+        for r, a in zip(refs, outs):
+            assert r.shape == a.shape and r.dtype == a.dtype, name
+            err = (r - a).abs().max().item() if r.numel() else 0.0
+            assert err <= bound[name], (name, err, tuple(r.shape))
+        seen[name] = seen.get(name, 0) + 1
+
+    d = _Draw(161803)
+    t0 = time.time()
+    with emulated_device():
+        while time.time() - t0 < SECONDS or len(seen) < len(bound):
+            B, C, H, W = d.int(1, 3), d.int(1, 4), d.int(8, 50), d.int(8, 50)
+            x, op = d.rand(B, C, H, W), d.int(0, 8)
+            if op == 0:
+                g = (d.rand(B, d.int(1, 40), d.int(1, 40), 2) - 0.5) * 2.6
+                kw = dict(mode=MODES[d.int(0, 2)], padding_mode=PADS[d.int(0, 2)], align_corners=bool(d.int(0, 1)))
+                check("grid_sample " + kw["mode"], F.grid_sample(x, g, **kw), AT.grid_sample(x.cuda(), g.cuda(), **kw))
+            elif op == 1:
+                h, w = d.int(1, 40), d.int(1, 40)
+                mx, my = d.rand(B, h, w) * W * 1.2 - 3, d.rand(B, h, w) * H * 1.2 - 3
+                rest = (("bilinear", "nearest")[d.int(0, 1)], "zeros", (None, True, False)[d.int(0, 2)], bool(d.int(0, 1)))
+                if rest[3]:
+                    mx, my = mx / W * 2 - 1, my / H * 2 - 1
+                check("remap", K.geometry.transform.remap(x, mx, my, *rest), AT.remap(x.cuda(), mx.cuda(), my.cuda(), *rest))
+            elif op == 2:
+                D = d.int(2, 3)
+                pts, T = d.rand(B, d.int(1, 30), D) * 20, torch.eye(D + 1).repeat(B, 1, 1) + (d.rand(B, D + 1, D + 1) - 0.5) * 0.02
+                check("transform_points", K.geometry.linalg.transform_points(T, pts), AG.transform_points(T.cuda(), pts.cuda()))
+            elif op == 3:
+                check("pyrdown", K.geometry.transform.pyrdown(x), AT.pyrdown(x.cuda()))
+                check("pyrup", K.geometry.transform.pyrup(x[..., :24, :24]), AT.pyrup(x[..., :24, :24].cuda()))
+            elif op == 4:
+                x3, f, hue = d.rand(B, 3, H, W), d.rand(B) * 1.5 + 0.2, (d.rand(B) - 0.5) * 2 * math.pi
+                check("contrast", K.enhance.adjust.adjust_contrast_with_mean_subtraction(x3, f), AE.adjust_contrast_with_mean_subtraction(x3.cuda(), f.cuda()))
+                check("saturation", K.enhance.adjust.adjust_saturation_with_gray_subtraction(x3, f), AE.adjust_saturation_with_gray_subtraction(x3.cuda(), f.cuda()))
+                check("brightness", K.enhance.adjust.adjust_brightness_accumulative(x3, f), AE.adjust_brightness_accumulative(x3.cuda(), f.cuda()))
+                check("hue", K.enhance.adjust_hue(x3, hue), AE.adjust_hue(x3.cuda(), hue.cuda()))
+            elif op == 5:
+                ang, c, sc = (d.rand(B) - 0.5) * 90, d.rand(B, 2) * 40, d.rand(B, 2) + 0.5
+                tr, sx, sy = (d.rand(B, 2) - 0.5) * 10, (d.rand(B) - 0.5) * 0.4, (d.rand(B) - 0.5) * 0.4
+                check("get_rotation_matrix2d", K.geometry.transform.get_rotation_matrix2d(c, ang, sc), AT.get_rotation_matrix2d(c.cuda(), ang.cuda(), sc.cuda()))
+                check("get_affine_matrix2d", K.geometry.transform.get_affine_matrix2d(tr, c, sc, ang, sx, sy),
+                      AT.get_affine_matrix2d(tr.cuda(), c.cuda(), sc.cuda(), ang.cuda(), sx.cuda(), sy.cuda()))
+            elif op == 6:
+                src = torch.tensor([[[0.0, 0], [W - 1, 0], [W - 1, H - 1], [0, H - 1]]]).repeat(B, 1, 1)
+                dst = src + (d.rand(B, 4, 2) - 0.5) * min(H, W) * 0.3
+                check("get_perspective_transform", K.geometry.transform.get_perspective_transform(src, dst), AT.get_perspective_transform(src.cuda(), dst.cuda()))
+                M, dsize = _matrix(d, B, H, W), (d.int(2, 40), d.int(2, 40))
+                check("normalize_homography", K.geometry.conversions.normalize_homography(M, (H, W), dsize), AG.normalize_homography(M.cuda(), (H, W), dsize))
+            elif op == 7:
+                x13 = x[:, :1] if C != 3 else x
+                check("canny", K.filters.canny(x13), AF.canny(x13.cuda()))
+                kk = 2 * d.int(1, 3) + 1
+                check("laplacian", K.filters.laplacian(x, kk), AF.laplacian(x.cuda(), kk))
+            else:
+                ks, ang = (2 * d.int(1, 3) + 1, 2 * d.int(1, 3) + 1), (d.rand(B) - 0.5) * 90
+                check("box_blur", K.filters.box_blur(x, ks), AF.box_blur(x.cuda(), ks))
+                check("unsharp_mask", K.filters.unsharp_mask(x, ks, (1.0, 1.5)), AF.unsharp_mask(x.cuda(), ks, (1.0, 1.5)))
+                check("rotate", K.geometry.transform.rotate(x, ang), AT.rotate(x.cuda(), ang.cuda()))
+    assert set(seen) == set(bound)
