@@ -128,7 +128,8 @@ def test_error_conventions_are_the_references(env, case):
         # the reference fails inside ATen ("grid_sampler_2d_cpu_kernel_impl" not implemented for 'Byte'); the native path refuses the dtype up front
         assert isinstance(re, (NotImplementedError, RuntimeError)) and isinstance(ae, TypeError)
     else:
-        assert type(ae) is type(re), (case, re, ae)
+        # by name: the package re-uses Kornia's exception classes only when Kornia was imported first (kornia_amd/core/exceptions.py)
+        assert type(ae).__name__ == type(re).__name__ and isinstance(ae, Exception), (case, re, ae)
 
 
 NONFINITE_MATRICES = {
