@@ -17,6 +17,17 @@
  *     allocates, frees, or retains pointers after returning;
  *   - return value: 0 = ok, < 0 = invalid argument, > 0 = hipError_t; `km_last_error()` returns a
  *     thread-local message.  No C++ exception crosses the boundary.
+ *
+ * Versioning (`km_abi_version()`, currently 3)
+ *   The version counts SYMBOL SETS: a library of version N exports every entry point of the sets 1 .. N with unchanged
+ *   signatures, so a binding checks `km_abi_version() >= V` with V the set of the newest entry point it calls (no per-symbol
+ *   probing).  Adding an entry point, or changing what an existing one computes for some input, opens a new set.
+ *     set 1  the round-1 .. round-3 entry points;
+ *     set 2  km_warp2d_bwd_ws on any channel count / border / reflection, zeroing `gmat` itself (round 4);
+ *     set 3  + km_color_params_ws_fwd, km_gaussian_taps_dtype_fwd, km_warp_masked_loss_finish, km_scale_f64 (added in round 5 while the
+ *            version still read 2: a version-2 library may lack them), km_stream_copy; and the sampler follows ATen's CPU rule for
+ *            NaN / inf sampling coordinates (taps outside the image are zeros that are still multiplied: NaN out, NaN matrix gradient)
+ *            where sets 1-2 returned the padding value.
  */
 #ifndef KORNIA_AMD_H
 #define KORNIA_AMD_H
@@ -51,6 +62,10 @@ int km_set_traversal(int mode);
  * walk the batch.  (No reference counterpart.) */
 int km_config_set(const char* key, int value);
 int km_config_get(const char* key);
+/* Diagnostic: a plain streaming copy of `bytes` bytes (a multiple of 16, both pointers 16-byte aligned), 16 bytes per lane, nontemporal != 0:
+ * non-temporal loads and stores.  bench.py times it beside the hot path, so that every line carries the copy bandwidth of THE BOX IT RAN ON
+ * (leases differ by several per cent) next to the 8 TB/s of the data sheet.  (No reference counterpart.) */
+int km_stream_copy(const void* src, void* dst, long long bytes, int nontemporal, void* stream);
 
 /* ---- batched 3x3 homography chain -----------------------------------------------------------
  * Replaces normalize_homography (kornia/geometry/conversions.py:1691-1726),

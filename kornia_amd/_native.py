@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KORNIA_AMD_LIB") or os.path.join(_PKG, "lib", "libkornia_amd.so")  # env override: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KM_F32, KM_F64, KM_BF16, KM_F16 = 0, 1, 2, 3
 _DTYPE_CODES = {torch.float32: KM_F32, torch.float64: KM_F64, torch.bfloat16: KM_BF16, torch.float16: KM_F16}
@@ -55,6 +55,7 @@ _PROTOTYPES = {
     "km_warp_masked_loss": [_P, _P, _P, _P] + [_I] * 11 + [c_double, _I, _P],
     "km_warp_masked_loss_finish": [_P, _I, _I, _P, _P, _P, _P],
     "km_scale_f64": [_P, _P, _I, _P, _I, ctypes.c_longlong, _P],
+    "km_stream_copy": [_P, _P, ctypes.c_longlong, _I, _P],
     "km_gaussian_taps_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "km_gaussian_taps_dtype_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "km_warp2d_fwd_masked": [_P, _P, _P, _P] + [_I] * 12 + [_P, _I, _P],

@@ -95,7 +95,8 @@ def gaussian_taps(sigma: torch.Tensor, kernel_size, apply: Optional[torch.Tensor
     ty = torch.empty(B, ky, device=s.device, dtype=torch.float32)
     if s.dim() == 1 or batch_prob is not None or round_to not in (None, torch.float32):
         if apply is not None:
-            raise ValueError("gaussian_taps: give the per-sample switch as `apply` (flags) or as `batch_prob` (the draw), not both forms")
+            raise ValueError("gaussian_taps: with a (B,) sigma, a `batch_prob` or a 16-bit `round_to` the per-sample switch is `batch_prob` (the layer's draw, "
+                             "thresholded inside the launch); `apply` (flags) goes with a (B,2) float32 sigma alone")
         if s.dim() not in (1, 2) or (s.dim() == 2 and s.shape[1] != 2):
             raise ValueError("gaussian_taps: sigma must be (B,) or (B,2)")
         prob = None if batch_prob is None else batch_prob.detach().to(device=s.device, dtype=torch.float32).reshape(-1).contiguous()

@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define KM_ABI_VERSION 2
+#define KM_ABI_VERSION 3  // include/kornia_amd.h, "Versioning": a library of version N exports the symbol sets of every version <= N
 
 // dtype codes of the C ABI (include/kornia_amd.h)
 enum { KM_F32 = 0, KM_F64 = 1, KM_BF16 = 2, KM_F16 = 3 };
@@ -67,6 +67,13 @@ __device__ __forceinline__ float km_next64(float v) { return __uint_as_float(km_
 __device__ __forceinline__ float km_prev64(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));
 }
+// Value held by lane ^ 1 / lane ^ 2 of the same QUAD of lanes (DPP quad_perm [1,0,3,2] / [2,3,0,1]: one VALU move each)
+__device__ __forceinline__ float km_quad_xor1(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float km_quad_xor2(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x4E, 0xf, 0xf, false));
+}
 // Maximum of an unsigned value over the wave, valid in LANE 63 only (other lanes hold partial maxima): an inclusive scan inside each row
 // of 16 lanes (row_shr:1/2/4/8; a lane without a source keeps its own value), then lane 15 of a row into the next row (row_bcast:15,
 // rows 1 and 3) and lane 31 into rows 2 and 3 (row_bcast:31) - ten VALU instructions, no LDS traffic (a __shfl_down ladder is six
@@ -80,6 +87,34 @@ __device__ __forceinline__ uint32_t km_wave_umax_last(uint32_t v) {
     return (uint32_t)x;
 }
 #endif
+
+// 4 x 4 transpose inside a quad of lanes: lane q (= lane & 3) enters with a[r] = element (row r, column q) of a 4 x 4 block and leaves with
+// a[k] = element (row q, column k) - its own ROW of the block, i.e. four horizontally adjacent pixels for ONE 16-byte store where the
+// lane = column layout of the sampling kernels would issue four 4-byte ones.  Two butterfly stages (lane bit 0 <-> register bit 0, lane bit 1
+// <-> register bit 1): 4 quad-permute moves + 12 selects, no LDS.  All four lanes of the quad must be active.
+__device__ __forceinline__ void km_quad_transpose4(float (&a)[4], int q) {
+    const bool b0 = (q & 1) != 0, b1 = (q & 2) != 0;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {  // register pairs (0,1), (2,3) with lane ^ 1
+        const float r = km_quad_xor1(b0 ? a[p] : a[p + 1]);
+        a[p] = b0 ? r : a[p];
+        a[p + 1] = b0 ? a[p + 1] : r;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {     // register pairs (0,2), (1,3) with lane ^ 2
+        const float r = km_quad_xor2(b1 ? a[p] : a[p + 2]);
+        a[p] = b1 ? r : a[p];
+        a[p + 2] = b1 ? a[p + 2] : r;
+    }
+}
+// four horizontally adjacent fp32 pixels with one 16-byte store (p 16-byte aligned), streaming or plain (km_st_c's policy)
+template <bool STREAM>
+__device__ __forceinline__ void km_st4_c(float* p, const float (&v)[4]) {
+    typedef float km_f4v_ __attribute__((ext_vector_type(4)));
+    km_f4v_ vv; vv.x = v[0]; vv.y = v[1]; vv.z = v[2]; vv.w = v[3];
+    if constexpr (STREAM) __builtin_nontemporal_store(vv, reinterpret_cast<km_f4v_*>(p));
+    else *reinterpret_cast<km_f4v_*>(p) = vv;
+}
 
 // ---- storage types ----------------------------------------------------------------------------
 struct km_bf16 {

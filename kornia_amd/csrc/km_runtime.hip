@@ -99,9 +99,40 @@ int km_check_launch(const char* what) {
     return 0;
 }
 
+// ---- km_stream_copy: the copy the hot kernels are compared with (bench.py: roofline.measured_streaming_copy_GBps) --------------------
+template <bool NT>
+__global__ __launch_bounds__(256) void km_stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+    typedef float km_f4v __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += stride) {
+        if (NT) {
+            const km_f4v v = __builtin_nontemporal_load(reinterpret_cast<const km_f4v*>(src) + i);
+            __builtin_nontemporal_store(v, reinterpret_cast<km_f4v*>(dst) + i);
+        } else {
+            dst[i] = src[i];
+        }
+    }
+}
+
 extern "C" {
 
 int km_abi_version(void) { return KM_ABI_VERSION; }
+
+int km_stream_copy(const void* src, void* dst, long long bytes, int nontemporal, void* stream) {
+    KM_REQUIRE(bytes >= 0 && bytes % 16 == 0, "km_stream_copy: bytes must be a non-negative multiple of 16");
+    if (bytes == 0) return 0;
+    KM_REQUIRE(src && dst && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "km_stream_copy: null or unaligned pointer");
+    const size_t n16 = (size_t)bytes / 16;
+    const int cus = km_device_cus();
+    // ~8 resident blocks per CU, each lane walking the buffer with a grid stride: the shape a linear 16-byte copy streams fastest in (profiles/r02_hbm_shapes.txt)
+    size_t blocks = (n16 + 255) / 256;
+    const size_t cap = (size_t)(cus > 0 ? cus : 4) * 8u * 4u;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (nontemporal) hipLaunchKernelGGL((km_stream_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)src, (float4*)dst, n16);
+    else hipLaunchKernelGGL((km_stream_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)src, (float4*)dst, n16);
+    return km_check_launch("km_stream_copy");
+}
 
 int km_set_traversal(int mode) {
     (void)km_config();

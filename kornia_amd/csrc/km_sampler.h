@@ -269,6 +269,39 @@ __device__ __forceinline__ void km_bilinear_setup(R x, R y, int W, int H, KmBili
     t.i11 = y1 * W + x1;
 }
 
+// ---- out-of-bounds taps: ZEROS THAT ARE STILL MULTIPLIED ---------------------------------------------------------------------------------
+// ATen's CPU sampler - the reference - gathers a tap outside the image as 0 (mask_gather) and still multiplies it by its weight
+// (GridSamplerKernel.cpp, ApplyGridSample<..., Bilinear, ...>::forward / backward).  For the finite weights of a finite position that leaves
+// the sum unchanged - fma(0, w, acc) == acc - so nothing moves for ordinary inputs; for a NaN / inf position (a singular or NaN-carrying
+// matrix, a projective denominator of exactly zero: every weight of the pixel is NaN) it is NaN, which is what the reference returns there:
+// NaN forward, NaN into the grid - hence the matrix - gradient, and nothing scattered into the image gradient (the scatter IS masked).
+// Every bilinear path that can meet such a position (the per-tap predicated paths: the fast paths' inside tests fail on NaN) goes through
+// these; tests/golden/nonfinite_coords.npz is the reference's result.
+template <typename R>
+__device__ __forceinline__ R km_bilinear_masked(const KmBilin<R>& t, R v00, R v01, R v10, R v11) {
+    R acc = km_fma(t.b00 ? v00 : (R)0, t.w00, (R)0);  // fma chain in nw, ne, sw, se order from 0
+    acc = km_fma(t.b01 ? v01 : (R)0, t.w01, acc);
+    acc = km_fma(t.b10 ? v10 : (R)0, t.w10, acc);
+    return km_fma(t.b11 ? v11 : (R)0, t.w11, acc);
+}
+// grid_sample(ones) of _fill_and_warp (imgwarp.py:316): the same chain on an image of ones
+template <typename R>
+__device__ __forceinline__ R km_bilinear_ones(const KmBilin<R>& t) {
+    return km_bilinear_masked<R>(t, (R)1, (R)1, (R)1, (R)1);
+}
+// d out / d (x, y) of one channel, times its upstream gradient, added to (gix, giy): taps outside the image are zeros that are still
+// multiplied (ApplyGridSample<..., Bilinear, ...>::backward forms ((ne - nw) * s + (se - sw) * n) * gOut from masked gathers)
+template <typename R>
+__device__ __forceinline__ void km_bilinear_grid_terms(const KmBilin<R>& t, R s00, R s01, R s10, R s11, R go, R& gix, R& giy) {
+    s00 = t.b00 ? s00 : (R)0; s01 = t.b01 ? s01 : (R)0; s10 = t.b10 ? s10 : (R)0; s11 = t.b11 ? s11 : (R)0;
+    gix -= s00 * t.wy1 * go; giy -= s00 * t.wx1 * go;
+    gix += s01 * t.wy1 * go; giy -= s01 * t.wx0 * go;
+    gix -= s10 * t.wy0 * go; giy += s10 * t.wx1 * go;
+    gix += s11 * t.wy0 * go; giy += s11 * t.wx0 * go;
+}
+template <typename R>
+__device__ __forceinline__ bool km_finite(R v) { return (v - v) == (R)0; }  // (inf - inf and NaN - NaN are NaN; no fast-math in this build)
+
 // matrix-gradient contribution of one output pixel: with r = (u, v, 1) the pixel adds
 //   d/dm0k += ax r_k ,  d/dm1k += ay r_k ,  d/dm2k += az r_k
 // for the (ax, ay, az) returned here (gix, giy = d loss / d (x, y) already scaled to normalised coordinates)

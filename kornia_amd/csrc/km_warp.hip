@@ -87,12 +87,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
             R inv_mask = 0;
             if (g.pad == KM_PAD_FILL) {
                 // 1 - grid_sample(ones): imgwarp.py:316
-                R mask = 0;
-                if (t.b00) mask = mask + t.w00;
-                if (t.b01) mask = mask + t.w01;
-                if (t.b10) mask = mask + t.w10;
-                if (t.b11) mask = mask + t.w11;
-                inv_mask = (R)1 - mask;
+                inv_mask = (R)1 - km_bilinear_ones(t);
             }
             if (__all(t.b00 && t.b01 && t.b10 && t.b11)) {
                 // whole wave samples strictly inside the image (the common case): no masking, same fma chain
@@ -112,12 +107,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_kernel(const KmWarpArgs<T> a)
                     const T* img = src_b + (size_t)c * src_plane;
                     const R v00 = km_ld(img + t.i00), v01 = km_ld(img + t.i01);
                     const R v10 = km_ld(img + t.i10), v11 = km_ld(img + t.i11);
-                    // fma chain in nw, ne, sw, se order; out-of-bounds taps are skipped
-                    R acc = 0;
-                    acc = t.b00 ? km_fma(v00, t.w00, acc) : acc;
-                    acc = t.b01 ? km_fma(v01, t.w01, acc) : acc;
-                    acc = t.b10 ? km_fma(v10, t.w10, acc) : acc;
-                    acc = t.b11 ? km_fma(v11, t.w11, acc) : acc;
+                    R acc = km_bilinear_masked(t, (R)v00, (R)v01, (R)v10, (R)v11);  // (out-of-bounds taps: zeros that are still multiplied - ATen's CPU rule)
                     if (g.pad == KM_PAD_FILL) acc = acc + inv_mask * a.fill[c];
                     km_st(out_px + (size_t)c * dst_plane, acc);
                 }
@@ -303,11 +293,7 @@ __global__ __launch_bounds__(256) void km_warp_fwd_bz_kernel(const KmWarpArgs<T>
                 const T* img = src_b + (size_t)c * src_plane;
                 const R v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01);
                 const R v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
-                R acc = 0;
-                acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
-                acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
-                acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
-                acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+                R acc = km_bilinear_masked(tr, (R)v00, (R)v01, (R)v10, (R)v11);  // (out-of-bounds taps: zeros that are still multiplied - ATen's CPU rule)
                 if (row_ok[r]) km_st(out_px + (size_t)c * dst_plane, acc);
             }
         }
@@ -443,11 +429,7 @@ __device__ __forceinline__ void km_warp_fwd_lean_rows(const KmWarpArgs<T>& a, co
                 const T* img = src_b + (size_t)c * src_plane;
                 const float v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01);
                 const float v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
-                float acc = 0;
-                acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
-                acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
-                acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
-                acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+                float acc = km_bilinear_masked(tr, (float)v00, (float)v01, (float)v10, (float)v11);  // (out-of-bounds taps: zeros that are still multiplied - ATen's CPU rule)
                 if (row_ok) km_st(out_px + (size_t)c * dst_plane, acc);
             }
         }
@@ -547,6 +529,9 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
     const int i_base = (int)ty * KM_TILE_H + (wave / WA) * (PH * KM_ROWS) + lane / PW;
     const bool want_gg = (CM == KM_COORD_GRID) && (a.ggrid != nullptr);  // gradient wrt the explicit grid
     const bool want_gm = ((a.gmat != nullptr) || want_gg) && (INTERP != KM_INTERP_NEAREST);  // needs d out / d (x, y)
+    // the chain from (gix, giy) to the matrix runs for nearest too, with gix = giy = 0 (ATen's zero grid gradient): autograd multiplies those
+    // zeros by the coordinates' partial derivatives, so a NaN / inf coordinate makes the matrix gradient NaN (tests/golden/nonfinite_coords.npz)
+    const bool acc_gm = (CM != KM_COORD_GRID) && (a.gmat != nullptr);
     const bool want_gs = (a.gsrc != nullptr);
 
     R m[9];
@@ -598,10 +583,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
                     if (want_gm) {
                         const T* img = src_b + (size_t)c * src_plane;
                         const R f = (g.pad == KM_PAD_FILL) ? a.fill[c] : (R)0;
-                        if (t.b00) { const R s = km_ld(img + t.i00) - f; gix -= s * t.wy1 * go; giy -= s * t.wx1 * go; }
-                        if (t.b01) { const R s = km_ld(img + t.i01) - f; gix += s * t.wy1 * go; giy -= s * t.wx0 * go; }
-                        if (t.b10) { const R s = km_ld(img + t.i10) - f; gix -= s * t.wy0 * go; giy += s * t.wx1 * go; }
-                        if (t.b11) { const R s = km_ld(img + t.i11) - f; gix += s * t.wy0 * go; giy += s * t.wx0 * go; }
+                        km_bilinear_grid_terms<R>(t, (R)km_ld(img + t.i00) - f, (R)km_ld(img + t.i01) - f, (R)km_ld(img + t.i10) - f, (R)km_ld(img + t.i11) - f, go, gix, giy);
                     }
                 }
                 gix = gix * (mx * gdx);
@@ -633,14 +615,13 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int idx = km_tap_index(xf - 1 + q, yf - 1 + rr, g.W, g.H, spad, g.align);
-                            if (idx >= 0) {
-                                if (want_gs) km_atomic_add(gi + idx, go * cx[q] * cy[rr]);
-                                if (want_gm) {
-                                    R s = km_ld(img + idx);
-                                    if (g.pad == KM_PAD_FILL) s -= f;  // fill: taps are unpadded, idx >= 0 <=> in bounds
-                                    gix -= s * dx[q] * cy[rr] * go;
-                                    giy -= s * dy[rr] * cx[q] * go;
-                                }
+                            if (idx >= 0 && want_gs) km_atomic_add(gi + idx, go * cx[q] * cy[rr]);
+                            if (want_gm) {
+                                // (get_value_bounded: a tap outside the image is a zero that is still multiplied - NaN coefficients of a
+                                // non-finite position reach the grid gradient; fill: taps are unpadded, idx >= 0 <=> in bounds)
+                                const R s = idx >= 0 ? (R)km_ld(img + idx) - ((g.pad == KM_PAD_FILL) ? f : (R)0) : (R)0;
+                                gix -= s * dx[q] * cy[rr] * go;
+                                giy -= s * dy[rr] * cx[q] * go;
                             }
                         }
                 }
@@ -654,7 +635,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
                 gp[0] = (INTERP == KM_INTERP_NEAREST) ? (R)0 : gix;
                 gp[1] = (INTERP == KM_INTERP_NEAREST) ? (R)0 : giy;
             }
-            if (CM != KM_COORD_GRID && want_gm) {
+            if (acc_gm) {
                 if (CM == KM_COORD_PERSPECTIVE) {
                     const R inv = (R)1 / cd.den;
                     const R ax = gix * inv, ay = giy * inv;
@@ -677,7 +658,7 @@ __global__ __launch_bounds__(256) void km_warp_bwd_kernel(const KmWarpArgs<T> a)
         }
     }
 
-    if (CM != KM_COORD_GRID && want_gm) {  // block-uniform
+    if (acc_gm) {  // block-uniform
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const double s = km_wave_sum((double)gm[k]);
@@ -737,6 +718,9 @@ struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50;
 #ifndef KMB_FILL_DMA
 #define KMB_FILL_DMA 1       // fp32 storage: the box by LDS-DMA (global_load_lds_dwordx4) instead of through registers
 #endif
+#ifndef KMB_ST16
+#define KMB_ST16 1           // fp32 storage: a quad of lanes transposes its 4 x 4 results and stores 16 bytes per lane (0: one dword per lane and row)
+#endif
 #ifndef KMB_TILT_ROWS
 #define KMB_TILT_ROWS 4      // a region whose output rows span at most this many source rows takes the gather rows when its wide box does not fit
 #endif
@@ -768,11 +752,7 @@ __device__ __forceinline__ void kmb_gather_rows(const KmWarpArgs<T>& a, const fl
             const T* img = src_b + (size_t)c * src_plane;
             const float v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01);
             const float v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
-            float acc = 0;
-            acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
-            acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
-            acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
-            acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+            float acc = km_bilinear_masked(tr, (float)v00, (float)v01, (float)v10, (float)v11);  // (out-of-bounds taps: zeros that are still multiplied - ATen's CPU rule)
             km_st(out_px + (size_t)c * dst_plane, acc);
         }
     }
@@ -894,6 +874,67 @@ __device__ __forceinline__ void kmb_tile_body(const KmWarpArgs<T>& a, const floa
     }
     __syncthreads();
     const bool all_in = __all(inbox);  // (by every lane of the wave: columns right of the image count as inside)
+#if KMB_ST16
+    if constexpr (sizeof(T) == 4) {
+        // 16-BYTE STORES (round 6).  The taps keep lane = output column (neighbouring lanes read neighbouring LDS banks); what changes is the
+        // way out: the thread's rows are taken four at a time, each quad of lanes transposes its 4 rows x 4 columns per channel in registers
+        // (km_quad_transpose4: quad-permute moves and selects - VALU this kernel has spare, profiles/r05_final_pmc_units.json: VALU 19 % busy,
+        // the texture-address unit 71 %, two thirds of its instructions these stores) and lane q of the quad writes row q's four pixels with
+        // ONE global_store_dwordx4: a quarter of the store instructions for the same bytes, the same values.
+        // Output rows must be 16-byte aligned runs of whole quads (block-uniform test); every lane of the wave walks the groups - lanes right
+        // of the image or below it compute nothing and store nothing, but take part in the transposes of their quad.
+        const bool vec16 = ((g.w & 3) == 0) && ((j0 & 3) == 0) && (((uintptr_t)a.dst & 15) == 0);
+        if (vec16 && all_in) {  // wave-uniform
+            static_assert(RPT % 4 == 0, "rows of a thread in groups of four");
+            const int q4 = tid & 3;
+            const bool col_ok = j < g.w;
+            const uint32_t outq = (uint32_t)i_base * (uint32_t)g.w + (uint32_t)(j & ~3);
+            float* __restrict__ dp[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dp[c] = reinterpret_cast<float*>(dst_b) + c * dst_plane;
+#pragma unroll
+            for (int r0 = 0; r0 < RPT; r0 += 4) {
+                const bool grp_ok = col_ok && (i_base + r0 < g.h);  // (the tile hangs over the bottom / right edge of the image)
+                if (!__any(grp_ok)) break;                          // wave-uniform (the groups that follow lie lower still)
+                float acc[NC][4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) acc[c][rr] = 0.f;
+                if (grp_ok) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        // (a row below the image samples the group's first row again: its own position need not lie in the box; never stored)
+                        const bool rv = i_base + r0 + rr < g.h;
+                        KmlTaps t;
+                        kml_taps(rv ? xs[r0 + rr] : xs[r0], rv ? ys[r0 + rr] : ys[r0], t);
+                        const int xi = KM_F2I(t.xf) - bx.xs, yi = KM_F2I(t.yf) - bx.ys;
+                        const float* q0 = s_src + __mul24(yi, NC * PITCH) + xi;
+                        const float* q1 = q0 + NC * PITCH;
+                        const float w00 = t.wx1 * t.wy1, w01 = t.wx0 * t.wy1, w10 = t.wx1 * t.wy0, w11 = t.wx0 * t.wy0;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const float v00 = q0[c * PITCH], v01 = q0[c * PITCH + 1], v10 = q1[c * PITCH], v11 = q1[c * PITCH + 1];
+                            acc[c][rr] = km_fma(v11, w11, km_fma(v10, w10, km_fma(v01, w01, km_fma(v00, w00, 0.0f))));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) km_quad_transpose4(acc[c], q4);
+                if (grp_ok && (i_base + r0 + q4 < g.h)) {
+                    const uint32_t oo = outq + (uint32_t)(r0 + q4) * (uint32_t)g.w;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        float* p = km_at_mut(dp[c], oo);
+                        KM_CHECK_ALIGNED(p, 16);
+                        km_st4_c<STREAM && !KM_FWD_PLAIN_ST>(p, acc[c]);
+                    }
+                }
+            }
+            return;
+        }
+    }
+#endif
     if (j < g.w) {
         if (!all_in) {  // (never seen for boxes that fit; keeps the result independent of the box estimate)
             kmb_gather_rows<T, CM, NC, ALIGN, RPT>(a, m, s_rv, b, j, li_base, i_base);

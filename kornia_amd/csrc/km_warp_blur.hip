@@ -64,11 +64,7 @@ __device__ __forceinline__ void kmwb_gather(const T* __restrict__ src_b, size_t 
     for (int c = 0; c < NC; ++c) {
         const T* img = src_b + (size_t)c * src_plane;
         const float v00 = km_ld(img + tr.i00), v01 = km_ld(img + tr.i01), v10 = km_ld(img + tr.i10), v11 = km_ld(img + tr.i11);
-        float acc = 0;
-        acc = tr.b00 ? km_fma(v00, tr.w00, acc) : acc;
-        acc = tr.b01 ? km_fma(v01, tr.w01, acc) : acc;
-        acc = tr.b10 ? km_fma(v10, tr.w10, acc) : acc;
-        acc = tr.b11 ? km_fma(v11, tr.w11, acc) : acc;
+        float acc = km_bilinear_masked(tr, (float)v00, (float)v01, (float)v10, (float)v11);  // (out-of-bounds taps: zeros that are still multiplied - ATen's CPU rule)
         val[c] = acc;
     }
 }

@@ -1139,9 +1139,14 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 // the out-of-bounds taps as zeros and multiplies) - so an image whose grad_out holds an inf or NaN ANYWHERE has a non-finite matrix
 // gradient (every pixel's term is a finite factor times its grad_out).  Visited pixels produce theirs through the IEEE path of this
 // launch; this scan finds the rest: 16 x 16 blocks of the output are classified by their corners (a projective map with a denominator of
-// one sign sends the block to a convex quad), blocks that may hold an unvisited pixel are tested pixel by pixel with an APPROXIMATE
+// one sign sends the block to a convex quad), blocks that may hold an unvisited pixel are tested pixel by pixel with the forward's own
 // position and a margin (testing a visited pixel as well changes nothing: its gradient already made the result non-finite), and an image
 // with a hit gets NaN added to its accumulators.
+// NON-FINITE POSITIONS (round 6).  A pixel whose sampling position is NaN / +-inf (a singular or NaN-carrying matrix, a projective
+// denominator of exactly zero) is in no tile's box either, and in the reference its weights are NaN: the zeros gathered for its taps times
+// those weights put NaN into the grid gradient whatever grad_out holds there (tests/golden/nonfinite_coords.npz).  The scan evaluates the
+// reference's own terms for such a pixel - gix is NaN iff the y weights are, giy iff the x weights are - through km_gm_terms, and adds NaN to
+// exactly the rows of the matrix gradient those terms reach (homography mode with a NaN in H[0, :]: rows 1 and 2, not row 0).
 // WHICH REFERENCE.  This is ATen's CPU kernel (the oracle, tests/golden/nonfinite_outside.npz).  ATen's CUDA / HIP grid_sampler backward - what the
 // reference runs on an accelerator - skips out-of-bounds taps instead, and such a gradient leaves the matrix gradient finite.  The launch policy
 // `warp_bwd_no_scan` (KM_WARP_BWD_SCAN=0) selects that behaviour and saves this scan (~20 us of a 0.55 ms backward at config 2: it reads one
@@ -1169,6 +1174,14 @@ __device__ __forceinline__ void kmo_scan_pos(const KmoScanMap& k, const float (&
     const float r = (CM == KM_COORD_AFFINE) ? 1.f : __builtin_amdgcn_rcpf(den);
     x = km_fma(nx * r, k.sx, k.ox);
     y = km_fma(ny * r, k.sy, k.oy);
+}
+// the forward's own position of output pixel (j, i): km_gen_coord + km_unnormalize, operation for operation (zeros / fill padding)
+template <int CM, int ALIGN>
+__device__ __forceinline__ void kmo_scan_exact(const KmWarpGeom<float>& g, const float (&m)[9], int j, int i, KmCoord<float>& cd, float& x, float& y) {
+    km_gen_coord<float, CM>(m, km_base_x<float, CM>(g, j), km_base_y<float, CM>(g, i), cd);
+    float mx, my;
+    x = km_unnormalize(cd.gx, g.W, ALIGN, mx);
+    y = km_unnormalize(cd.gy, g.H, ALIGN, my);
 }
 // true unless the pixel is certain to have a tap inside the image (NaN positions: true)
 __device__ __forceinline__ bool kmo_scan_maybe_unvisited(float x, float y, float W, float H) {
@@ -1247,21 +1260,28 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
 #pragma unroll
                 for (int q = 0; q < 9; ++q) m[u][q] = mp[q];
             }
-            bool need[NB][NS];
+            // (per pixel the EXACT forward position - km_gen_coord's arithmetic, not the classification's approximation: whether a position
+            // is finite is a property of the forward's own roundings)
+            bool need[NB][NS], posbad[NB][NS];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int j = (int)(ttx[u] * KMO_SCAN_BLK) + (lane & 15);
 #pragma unroll
                 for (int rr = 0; rr < NS; ++rr) {
                     const int i = (int)(tty[u] * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
-                    float x, y, d;
-                    kmo_scan_pos<CM>(k, m[u], (float)j, (float)i, x, y, d);
-                    need[u][rr] = (j < g.w) && (i < g.h) && kmo_scan_maybe_unvisited(x, y, Wf, Hf);
+                    const bool in_out = (j < g.w) && (i < g.h);
+                    KmCoord<float> cd;
+                    float x, y;
+                    kmo_scan_exact<CM, ALIGN>(g, m[u], in_out ? j : 0, in_out ? i : 0, cd, x, y);
+                    posbad[u][rr] = in_out && !(km_finite(x) && km_finite(y));
+                    need[u][rr] = in_out && kmo_scan_maybe_unvisited(x, y, Wf, Hf);  // (true for a NaN / inf position)
                 }
             }
-            uint32_t worst[NB];  // largest exponent field seen
+            uint32_t worst[NB][NS];  // largest exponent field seen at the pixel
 #pragma unroll
-            for (int u = 0; u < NB; ++u) worst[u] = 0u;
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int rr = 0; rr < NS; ++rr) worst[u][rr] = 0u;
             // (the loads of up to KMO_SCAN_CH channels of all NB blocks fly TOGETHER: channel by channel the launch was a chain of memory
             // round trips - matrices, then each channel of each pair - 26 us for 57 MB)
             for (int c0 = 0; c0 < g.C; c0 += KMO_SCAN_CH) {
@@ -1286,13 +1306,42 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
 #pragma unroll
                         for (int rr = 0; rr < NS; ++rr) {
                             const uint32_t bits = __float_as_uint((float)km_ld(&raw[cc][u][rr])) & 0x7f800000u;
-                            worst[u] = max(worst[u], need[u][rr] ? bits : 0u);
+                            worst[u][rr] = max(worst[u][rr], need[u][rr] ? bits : 0u);
                         }
             }
 #pragma unroll
-            for (int u = 0; u < NB; ++u)
-                if (__ballot(worst[u] == 0x7f800000u) != 0ull && lane < (CM == KM_COORD_AFFINE ? 6 : 9))
+            for (int u = 0; u < NB; ++u) {
+                // rows of the matrix gradient that become NaN: bit 0 -> entries 0-2 (the terms in ax), bit 1 -> 3-5 (ay), bit 2 -> 6-8 (az)
+                bool all_rows = false, any_bad = false;
+#pragma unroll
+                for (int rr = 0; rr < NS; ++rr) {
+                    all_rows = all_rows || (worst[u][rr] == 0x7f800000u && !posbad[u][rr]);  // a finite position, a non-finite gradient: 0 * inf in every term
+                    any_bad = any_bad || posbad[u][rr];
+                }
+                uint32_t rows = __ballot(all_rows) != 0ull ? 7u : 0u;
+                if (__ballot(any_bad) != 0ull) {  // (wave-uniform, rare) non-finite POSITIONS: the reference's own terms, taps gathered as zeros
+                    bool f0 = false, f1 = false, f2 = false;
+                    const int j = (int)(ttx[u] * KMO_SCAN_BLK) + (lane & 15);
+#pragma unroll 1
+                    for (int rr = 0; rr < NS; ++rr) {
+                        if (!posbad[u][rr]) continue;
+                        const int i = (int)(tty[u] * KMO_SCAN_BLK) + rr * 4 + (lane >> 4);
+                        KmCoord<float> cd;
+                        float x, y;
+                        kmo_scan_exact<CM, ALIGN>(g, m[u], j, i, cd, x, y);
+                        // gix = sum_c go_c ((ne - nw) wy1 + (se - sw) wy0) with every tap a zero: 0 unless the y weights (or go) are not finite
+                        const bool gobad = worst[u][rr] == 0x7f800000u;
+                        const float qnan = __int_as_float(0x7fc00000);
+                        const float gix = (km_finite(y) && !gobad) ? 0.f : qnan, giy = (km_finite(x) && !gobad) ? 0.f : qnan;
+                        float ax, ay, az;
+                        km_gm_terms<CM>(cd, gix, giy, ax, ay, az);
+                        f0 = f0 || !km_finite(ax); f1 = f1 || !km_finite(ay); f2 = f2 || !km_finite(az);
+                    }
+                    rows |= (__ballot(f0) != 0ull ? 1u : 0u) | (__ballot(f1) != 0ull ? 2u : 0u) | (__ballot(f2) != 0ull ? 4u : 0u);
+                }
+                if (lane < (CM == KM_COORD_AFFINE ? 6 : 9) && ((rows >> (lane / 3)) & 1u))
                     km_atomic_add(a.gmat + (size_t)(g.B_M == 1 ? 0u : bb[u]) * 9 + lane, (double)__int_as_float(0x7fc00000));
+            }
         }
         __syncthreads();  // (the list is rewritten by the next chunk)
     }

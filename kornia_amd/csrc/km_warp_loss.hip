@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
         KmBilin<R> t[KML_GROUP];
         R mx[KML_GROUP], my[KML_GROUP], gix[KML_GROUP], giy[KML_GROUP];
         uint32_t d_off[KML_GROUP];
-        bool sel[KML_GROUP];
+        bool sel[KML_GROUP], xbad[KML_GROUP], ybad[KML_GROUP];
         bool inside = true, any_sel = false;
 #pragma unroll
         for (int q = 0; q < KML_GROUP; ++q) {
@@ -105,13 +105,14 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
             const R y = km_unnormalize(cd[q].gy, H, align, my[q]);
             km_bilinear_setup(x, y, W, H, t[q]);
             // the warped ones image: the in-bounds weights through the forward's fma chain (nw, ne, sw, se from 0)
-            R ones = 0;
-            if (t[q].b00) ones = km_fma((R)1, t[q].w00, ones);
-            if (t[q].b01) ones = km_fma((R)1, t[q].w01, ones);
-            if (t[q].b10) ones = km_fma((R)1, t[q].w10, ones);
-            if (t[q].b11) ones = km_fma((R)1, t[q].w11, ones);
+            R ones = km_bilinear_ones(t[q]);  // (taps outside the image: zeros that are still multiplied - NaN for a NaN / inf position)
             ones = km_round_as(ones, (const T*)nullptr);
-            sel[q] = ok && (ones > a.threshold);
+            // threshold < 0 is "no mask" (the warped ones image is >= 0 wherever it is a number): every pixel counts, a NaN one included
+            sel[q] = ok && ((a.threshold < 0.f) || (ones > a.threshold));
+            // a pixel the mask drops still sends its (zero) gradient through the warp's backward in the reference: 0 times the NaN weights of
+            // a non-finite position is NaN in the grid - hence the matrix - gradient (gix through the y weights, giy through the x weights)
+            xbad[q] = ok && !km_finite(x);
+            ybad[q] = ok && !km_finite(y);
             d_off[q] = ok ? (uint32_t)i * (uint32_t)g.w + (uint32_t)j : 0u;
             inside = inside && t[q].b00 && t[q].b01 && t[q].b10 && t[q].b11;
             any_sel = any_sel || sel[q];
@@ -165,11 +166,10 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
                             const R v00 = (R)km_ld(img + tq.i00), v01 = (R)km_ld(img + tq.i01), v10 = (R)km_ld(img + tq.i10), v11 = (R)km_ld(img + tq.i11);
                             s00 = tq.b00 ? v00 : (R)0; s01 = tq.b01 ? v01 : (R)0; s10 = tq.b10 ? v10 : (R)0; s11 = tq.b11 ? v11 : (R)0;
                         }
-                        R wv = 0;
-                        if (tq.b00) wv = km_fma(s00, tq.w00, wv);
-                        if (tq.b01) wv = km_fma(s01, tq.w01, wv);
-                        if (tq.b10) wv = km_fma(s10, tq.w10, wv);
-                        if (tq.b11) wv = km_fma(s11, tq.w11, wv);
+                        R wv = km_fma(s00, tq.w00, (R)0);  // (s = 0 for a tap outside the image: still multiplied)
+                        wv = km_fma(s01, tq.w01, wv);
+                        wv = km_fma(s10, tq.w10, wv);
+                        wv = km_fma(s11, tq.w11, wv);
                         wv = km_round_as(wv, (const T*)nullptr);
                         const R d = (R)km_ld(km_at(dst_b + (size_t)c * dst_plane, d_off[q]));
                         R e, ge;
@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
         }
 #pragma unroll
         for (int q = 0; q < KML_GROUP; ++q) {
-            const R gx_ = sel[q] ? gix[q] * mx[q] : (R)0, gy_ = sel[q] ? giy[q] * my[q] : (R)0;
+            const R qnan = (R)__int_as_float(0x7fc00000);
+            const R gx_ = sel[q] ? gix[q] * mx[q] : (ybad[q] ? qnan : (R)0), gy_ = sel[q] ? giy[q] * my[q] : (xbad[q] ? qnan : (R)0);
             R ax, ay, az;
             km_gm_terms<CM>(cd[q], gx_, gy_, ax, ay, az);
-            if (sel[q]) {  // unselected pixels may have undefined coordinates (NaN * 0): keep them out of the sums
+            if (sel[q] || xbad[q] || ybad[q]) {  // (padding lanes / rows beyond the output may have undefined coordinates: kept out of the sums)
                 S[0] += ax; S[1] += ay; S[2] += az;
                 Sv[0] = km_fma(ax, cd[q].v, Sv[0]); Sv[1] = km_fma(ay, cd[q].v, Sv[1]); Sv[2] = km_fma(az, cd[q].v, Sv[2]);
             }

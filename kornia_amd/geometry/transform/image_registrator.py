@@ -40,6 +40,10 @@ class _MaskedWarpLoss(torch.autograd.Function):
         B, C, H, W = x.shape
         h, w = d.shape[-2:]
         B_M = m.shape[0]
+        if B == 0:  # the mean of an empty selection: NaN, and no gradient (what the reference's masked_select(...).mean() gives for an empty batch)
+            ctx.save_for_backward(torch.zeros(B_M, 9, device=dev, dtype=torch.float64))
+            ctx.mat_shape, ctx.mat_dtype = mat.shape, mat.dtype
+            return torch.full((), float("nan"), device=dev, dtype=src.dtype)
         acc = torch.zeros(B, 11, device=dev, dtype=torch.float64)  # per image: loss sum, selected count, d sum / d mat
         with N.device_guard(dev):
             N.check(lib.km_warp_masked_loss(x.data_ptr(), d.data_ptr(), m.data_ptr(), acc.data_ptr(), B, C, H, W, h, w, B_M,

@@ -350,27 +350,27 @@ void KO(ko_warp2d_fwd)(const REAL* src, const REAL* mat, REAL* out, int B, int C
                     long x0 = (long)xf, y0 = (long)yf, x1 = x0 + 1, y1 = y0 + 1;
                     REAL nw = ((REAL)x1 - x) * ((REAL)y1 - y), ne = (x - (REAL)x0) * ((REAL)y1 - y);
                     REAL sw = ((REAL)x1 - x) * (y - (REAL)y0), se = (x - (REAL)x0) * (y - (REAL)y0);
-                    /* NOT pinned, and known to differ from the reference: a NaN / inf coordinate (singular matrix) converts to
-                     * LONG_MIN here, so all four taps are skipped and the pixel is 0 / the fill colour - the rule the kernels
-                     * implement - where ATen's CPU sampler multiplies its masked-out zeros by the NaN weights and returns NaN
-                     * (tests/test_reference_edge_inputs.py states both sides against the live reference). */
+                    /* A tap outside the image is a ZERO THAT IS STILL MULTIPLIED by its weight: ATen's CPU sampler (GridSamplerKernel.cpp,
+                     * ApplyGridSample<..., Bilinear, ...>::forward) gathers masked-out taps as 0 (mask_gather) and runs the same fma chain.  For
+                     * finite weights that leaves the sum unchanged; a NaN / inf coordinate (singular matrix, zero projective denominator)
+                     * converts to LONG_MIN here - all four taps masked - and its NaN weights make the pixel NaN, as in the reference
+                     * (pinned by tests/golden/nonfinite_coords.npz; rounds 1-5 skipped the taps instead and returned 0 / the fill colour). */
                     int bnw = (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H), bne = (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H);
                     int bsw = (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H), bse = (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H);
                     REAL mask = 0;
-                    if (pad == 3) {
-                        if (bnw) mask = mask + nw;
-                        if (bne) mask = mask + ne;
-                        if (bsw) mask = mask + sw;
-                        if (bse) mask = mask + se;
+                    if (pad == 3) {  /* grid_sample(ones): the same chain on an image of ones (imgwarp.py:316) */
+                        mask = KO(ko_fma)(bnw ? (REAL)1 : (REAL)0, nw, (REAL)0);
+                        mask = KO(ko_fma)(bne ? (REAL)1 : (REAL)0, ne, mask);
+                        mask = KO(ko_fma)(bsw ? (REAL)1 : (REAL)0, sw, mask);
+                        mask = KO(ko_fma)(bse ? (REAL)1 : (REAL)0, se, mask);
                     }
                     for (int c = 0; c < C; ++c) {
                         const REAL* img = src + ((size_t)b * C + c) * H * W;
-                        REAL acc = 0;
-                        /* fma chain nw, ne, sw, se: bit-exact with ATen's CPU kernel (tests/golden) */
-                        if (bnw) acc = KO(ko_fma)(img[y0 * (long)W + x0], nw, acc);
-                        if (bne) acc = KO(ko_fma)(img[y0 * (long)W + x1], ne, acc);
-                        if (bsw) acc = KO(ko_fma)(img[y1 * (long)W + x0], sw, acc);
-                        if (bse) acc = KO(ko_fma)(img[y1 * (long)W + x1], se, acc);
+                        /* fma chain nw, ne, sw, se from 0: bit-exact with ATen's CPU kernel (tests/golden) */
+                        REAL acc = KO(ko_fma)(bnw ? img[y0 * (long)W + x0] : (REAL)0, nw, (REAL)0);
+                        acc = KO(ko_fma)(bne ? img[y0 * (long)W + x1] : (REAL)0, ne, acc);
+                        acc = KO(ko_fma)(bsw ? img[y1 * (long)W + x0] : (REAL)0, sw, acc);
+                        acc = KO(ko_fma)(bse ? img[y1 * (long)W + x1] : (REAL)0, se, acc);
                         if (pad == 3) acc = acc + ((REAL)1 - mask) * fill[c];
                         out[(((size_t)b * C + c) * h + i) * w + j] = acc;
                     }

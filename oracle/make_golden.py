@@ -486,6 +486,50 @@ def main():
     dn.update(persp__x=xp, persp__M=Mpn, persp__go=gop, persp__gx=xr.grad, persp__gM=Mr.grad)
     save("nonfinite_outside", **dn)
 
+    # ---- NON-FINITE SAMPLING COORDINATES (own generator: appended in round 6) ---------------------------------------------------------------
+    # A singular matrix (zero determinant into the closed-form inverse), a NaN / inf entry, or a projective denominator of exactly zero make the
+    # sampling coordinates NaN / +-inf.  ATen's CPU sampler (bilinear, zeros padding) masks such taps out and still multiplies the zeros it
+    # gathers by the NaN weights: NaN forward, nothing scattered into grad wrt the image, NaN into the grid - hence the matrix - gradient.
+    # Bicubic: NaN through the coefficients.  Nearest: the converted index is out of bounds -> 0.  (border / reflection with such coordinates
+    # convert a non-finite float to an integer - the platform's conversion, and ATen's CPU backward reads out of bounds there: not a fixture.)
+    g3 = torch.Generator().manual_seed(606)
+    Bq, Cq, Hq, Wq = 5, 3, 21, 33
+    xq = torch.rand(Bq, Cq, Hq, Wq, generator=g3)
+    goq = torch.rand(Bq, Cq, Hq, Wq, generator=g3) - 0.5
+    ok3 = flagship_homographies(Bq, Hq, Wq, Hq, Wq, g3, jitter=2.0)
+    nan, inf = float("nan"), float("inf")
+    Mq = ok3.clone()
+    Mq[0] = 0.0                                   # singular: every coordinate NaN
+    Mq[1, 0, 2] = nan                             # a NaN entry
+    Mq[2, 1, 1] = inf                             # an inf entry
+    a_ = 0.0625                                   # denominator a (x - (W - 1) / 2): exactly zero on the centre column of the output, finite elsewhere
+    Mq[3] = torch.linalg.inv(torch.tensor([[1.0, 0, 0], [0, 1, 0], [a_, 0, -a_ * (Wq - 1) / 2]], dtype=torch.float64)).float()
+    Aq = rotation_affines(Bq, Hq, Wq, g3)
+    Aq[0] = 0.0
+    Aq[1, 0, 2] = nan
+    Aq[2, 1, 1] = inf
+    Aq[3, 0, 0] = 3e38                            # overflows to inf in the coordinate
+    Hn = torch.eye(3).repeat(Bq, 1, 1) + 0.02 * torch.randn(Bq, 3, 3, generator=g3)
+    Hn[0] = 0.0                                   # Z = 0: transform_points' guard -> s = 1, coordinates 0 (finite)
+    Hn[1, 0, 2] = nan
+    Hn[2, 2, 2] = inf
+    Hn[3, 0, 0] = 3e38
+    dq = {"x": xq, "go": goq, "persp__M": Mq, "affine__M": Aq, "homography__M": Hn, "fill": torch.tensor([0.1, 0.2, 0.3])}
+    for api, fn, Min in (("persp", T.warp_perspective, Mq), ("affine", T.warp_affine, Aq), ("homography", T.homography_warp, Hn)):
+        for mode, pad in (("bilinear", "zeros"), ("bilinear", "fill"), ("bicubic", "zeros"), ("nearest", "zeros")):
+            if api == "homography" and pad == "fill":
+                continue
+            xr, Mr = xq.clone().requires_grad_(), Min.clone().requires_grad_()
+            kw = dict(mode=mode, padding_mode=pad)
+            if pad == "fill":
+                kw["fill_value"] = dq["fill"]
+            out = fn(xr, Mr, (Hq, Wq), **kw)
+            out.backward(goq)
+            key = f"{api}__{mode}_{pad}"
+            dq[key + "__out"], dq[key + "__gx"] = out.detach(), xr.grad
+            dq[key + "__gM"] = Mr.grad if Mr.grad is not None else torch.zeros_like(Min)
+    save("nonfinite_coords", **dq)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

@@ -38,6 +38,7 @@ static ucontext_t g_sched;
 static int g_cur = -1;
 static const std::function<void()>* g_body = nullptr;
 static std::vector<uint64_t> g_slots;     // [wave][parity][lane]
+static std::vector<unsigned> g_slot_gen;  // [wave][parity][lane]: the wave operation (its count + 1) the slot was published for
 static std::vector<unsigned char> g_pred; // [wave][parity][lane]
 static std::vector<char> g_dyn;
 static int g_or_acc = 0, g_or_result = 0;  // __syncthreads_or: accumulated by arrivals, published at release
@@ -68,22 +69,27 @@ int syncthreads_or(int pred) {
 
 static uint64_t* slot(int wave, unsigned parity, int lane) { return &g_slots[((size_t)wave * 2 + parity) * 64 + lane]; }
 static unsigned char* pred_slot(int wave, unsigned parity, int lane) { return &g_pred[((size_t)wave * 2 + parity) * 64 + lane]; }
+static unsigned* slot_gen(int wave, unsigned parity, int lane) { return &g_slot_gen[((size_t)wave * 2 + parity) * 64 + lane]; }
 
 uint64_t wave_exchange(uint64_t mine, int src, bool* ok) {
     Fiber& f = g_fibers[g_cur];
     const int wave = g_cur >> 6, lane = g_cur & 63;
     const unsigned parity = f.gen & 1u;
     *slot(wave, parity, lane) = mine;
+    *slot_gen(wave, parity, lane) = f.gen + 1u;
     *pred_slot(wave, parity, lane) = 1;
     f.state = AT_WAVE;
     yield_to_scheduler();  // resumed once every live lane of this wave has published
+    const unsigned mygen = f.gen + 1u;
     f.gen++;
     const int base = wave * 64, n = (int)g_fibers.size();
     if (src < 0) {
         for (int l = 0; l < 64 && base + l < n; ++l)
-            if (g_fibers[base + l].state != DONE) { src = l; break; }
+            if (g_fibers[base + l].state != DONE || *slot_gen(wave, parity, l) == mygen) { src = l; break; }
     }
-    if (src < 0 || base + src >= n || g_fibers[base + src].state == DONE) {
+    // (a lane that took part in THIS operation and has since run to its end - the fibers of a wave are resumed one after the other, the
+    // lanes of a real wave leave together - still counts: its slot holds what it published for this operation)
+    if (src < 0 || base + src >= n || (g_fibers[base + src].state == DONE && *slot_gen(wave, parity, src) != mygen)) {
         if (src != lane) g_stat_dead_reads++;
         *ok = false;
         return mine;
@@ -97,13 +103,15 @@ uint64_t wave_ballot(bool pred) {
     const int wave = g_cur >> 6, lane = g_cur & 63;
     const unsigned parity = f.gen & 1u;
     *pred_slot(wave, parity, lane) = pred ? 2 : 1;
+    *slot_gen(wave, parity, lane) = f.gen + 1u;
     f.state = AT_WAVE;
     yield_to_scheduler();
+    const unsigned mygen = f.gen + 1u;
     f.gen++;
     const int base = wave * 64, n = (int)g_fibers.size();
     uint64_t m = 0;
-    for (int l = 0; l < 64 && base + l < n; ++l)
-        if (g_fibers[base + l].state != DONE && *pred_slot(wave, parity, l) == 2) m |= (1ull << l);
+    for (int l = 0; l < 64 && base + l < n; ++l)  // (a lane that voted in this operation and has run to its end since still counts)
+        if ((g_fibers[base + l].state != DONE || *slot_gen(wave, parity, l) == mygen) && *pred_slot(wave, parity, l) == 2) m |= (1ull << l);
     return m;
 }
 
@@ -162,6 +170,7 @@ static bool run_block(unsigned nthreads) {
     }
     const unsigned nwaves = (nthreads + 63) / 64;
     g_or_acc = g_or_result = 0;
+    std::fill(g_slot_gen.begin(), g_slot_gen.end(), 0u);
     for (;;) {
         bool progressed = false;
         unsigned live = 0;
@@ -232,6 +241,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     g_fibers.resize(nthreads);
     const unsigned nwaves = (nthreads + 63) / 64;
     g_slots.assign((size_t)nwaves * 2 * 64, 0);
+    g_slot_gen.assign((size_t)nwaves * 2 * 64, 0);
     g_pred.assign((size_t)nwaves * 2 * 64, 0);
     g_dyn.assign(shmem + 16, 0);
     g_body = &body;

@@ -189,6 +189,8 @@ inline float km_prev16(float v) {  // row_shr:1
     memcpy(&r, &got, sizeof(float));
     return ok ? r : v;
 }
+inline float km_quad_xor1(float v) { return __shfl(v, emu::lane_id() ^ 1, 64); }  // quad_perm [1,0,3,2]
+inline float km_quad_xor2(float v) { return __shfl(v, emu::lane_id() ^ 2, 64); }  // quad_perm [2,3,0,1]
 inline uint32_t km_next64(uint32_t v) { return __shfl_down(v, 1, 64); }  // wave_shl:1
 inline float km_next64(float v) { return __shfl_down(v, 1, 64); }
 inline float km_prev64(float v) {  // wave_shr:1

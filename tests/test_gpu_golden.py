@@ -147,3 +147,61 @@ def test_headline_pipeline_vs_reference():
     y.backward(d["go"].cuda())
     assert torch.allclose(xg.grad.cpu(), d["gx"], atol=1e-5, rtol=1e-5)
     assert rel(Mg.grad.cpu(), d["gM"]) < 5e-4
+
+
+# ---- non-finite sampling coordinates (round 6): tests/golden/nonfinite_coords.npz is the REAL reference's result ----------------------------
+NONFINITE_CASES = [(api, mode, pad) for api in ("persp", "affine", "homography")
+                   for mode, pad in (("bilinear", "zeros"), ("bilinear", "fill"), ("bicubic", "zeros"), ("nearest", "zeros"))
+                   if not (api == "homography" and pad == "fill")]
+
+
+def _nonfinite_call(api, mode, pad, d):
+    import kornia_amd as K
+
+    fn = {"persp": K.warp_perspective, "affine": K.warp_affine, "homography": K.homography_warp}[api]
+    kw = dict(mode=mode, padding_mode=pad)
+    if pad == "fill":
+        kw["fill_value"] = d["fill"]
+    return lambda x, M: fn(x, M, (21, 33), **kw)
+
+
+@pytest.mark.parametrize("api,mode,pad", NONFINITE_CASES)
+def test_nonfinite_sampling_coordinates_forward_is_the_references(api, mode, pad):
+    """A singular matrix, a NaN / inf entry, a projective denominator that is exactly zero on one column of the output: the reference (ATen's
+    CPU sampler) gathers the taps of such a pixel as zeros and multiplies them by NaN weights - NaN for bilinear and bicubic, 0 for nearest
+    (the converted index is out of bounds).  The native path returns the same NaN PATTERN pixel for pixel and the same numbers elsewhere
+    (rounds 1-5 returned zeros / the fill colour there: the one known divergence of VERDICT round 5)."""
+    d = load("nonfinite_coords")
+    ref = d[f"{api}__{mode}_{pad}__out"]
+    out = _nonfinite_call(api, mode, pad, d)(d["x"].cuda(), d[f"{api}__M"].cuda()).cpu()
+    assert torch.equal(out.isnan(), ref.isnan()), (out.isnan() != ref.isnan()).sum()
+    fin = ~ref.isnan()
+    if mode == "nearest" and api == "homography":
+        assert (out[fin] != ref[fin]).float().mean() < 2e-3  # (the BLAS-dependent positions of the reference: a rounding tie flips a pixel)
+    elif mode == "bilinear" and api != "homography":
+        assert torch.equal(out[fin], ref[fin])
+    else:
+        assert torch.allclose(out[fin], ref[fin], atol=1e-5 if api == "homography" else 1e-6, rtol=0)
+    if mode != "nearest":
+        assert ref[:3].isnan().any()  # the fixture holds the case
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("api,mode,pad", NONFINITE_CASES)
+def test_nonfinite_sampling_coordinates_backward_is_the_references(api, mode, pad, fused):
+    """Backward of the same cases: nothing is scattered into grad wrt the image by a pixel with a non-finite position (the scatter IS masked in
+    ATen), and the matrix gradient is NaN in exactly the entries the reference's is - all nine after the closed-form inverse of a NaN matrix,
+    rows 1 and 2 only for homography_warp with a NaN in H[0, :], the third row for nearest (a zero grid gradient times NaN coordinates)."""
+    if not fused and mode != "bilinear":
+        pytest.skip("the one-read switch only concerns the bilinear backward")
+    from test_gpu_warp_fused import _run
+
+    d = load("nonfinite_coords")
+    gx, gM = _run(_nonfinite_call(api, mode, pad, d), d["x"], d[f"{api}__M"], d["go"], fused)
+    rgx, rgM = d[f"{api}__{mode}_{pad}__gx"], d[f"{api}__{mode}_{pad}__gM"]
+    assert torch.isfinite(rgx).all() and torch.isfinite(gx).all()
+    assert torch.allclose(gx, rgx, atol=1e-5, rtol=0), (gx - rgx).abs().max()
+    assert torch.equal(torch.isfinite(gM), torch.isfinite(rgM)), f"finite entries differ from the reference's\n{gM}\n{rgM}"
+    for b in range(gM.shape[0]):
+        if torch.isfinite(rgM[b]).all() and rgM[b].abs().max() > 0:
+            assert rel(gM[b], rgM[b]) < 5e-3, (b, gM[b], rgM[b])  # (fp32 gradient of a noise image: tests/test_gpu_warp.py::_check_grads)

@@ -37,7 +37,7 @@ def test_the_documented_binding_runs_against_the_shipped_abi(monkeypatch):
     ns = {"__name__": "kornia.core._backend_amd"}
     exec(compile(_stub_source(), "INTEGRATION.md:_backend_amd.py", "exec"), ns)
     # what the stub hard-codes is what the library and the package say
-    assert ns["lib"]().km_abi_version() == N.ABI_VERSION == 2
+    assert ns["lib"]().km_abi_version() == N.ABI_VERSION == 3
     assert {dt: N.dtype_code(dt) for dt in ns["_DT"]} == ns["_DT"]
     with pytest.raises(RuntimeError):  # a refused call surfaces the library's message through the stub's check()
         ns["check"](ns["lib"]().km_warp2d_fwd(None, None, None, 1, 1, 4, 4, 4, 4, 1, 0, 1, 1, 0, 1, None, 0, None))

@@ -26,7 +26,14 @@ pytestmark = [
     pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="host build of the kernels needs ROCm's clang++"),
 ]
 
-SECONDS = float(os.environ.get("KM_SWEEP_SECONDS", "6"))
+# In the suite every test runs a FIXED number of seeded pipelines (the same ones on every host); KM_SWEEP_SECONDS turns a test into a
+# time-bounded sweep that keeps drawing until the time is up (the recorded long runs).
+SECONDS = float(os.environ.get("KM_SWEEP_SECONDS", "0"))
+FIXED = 60
+
+
+def _more(t0, n, fixed=FIXED):
+    return (time.time() - t0 < SECONDS) if SECONDS > 0 else (n < fixed)
 
 
 def _pipeline_factory(A, rng):
@@ -51,6 +58,17 @@ def _pipeline_factory(A, rng):
     return lambda: A.AugmentationSequential(*[cls(*a, **kw) for cls, a, kw in spec], data_keys=["input"], random_apply=random_apply)
 
 
+def _close(r, a, has_nearest, what):
+    """5e-4 everywhere - except that a pipeline with a `nearest` resampling may flip single pixels (a position an ulp apart rounds to the other
+    neighbour: a difference of up to 1 at that pixel, and at the pixels a later blur spreads it over): there at most 0.5 % of the pixels may
+    differ by more."""
+    d = (r - a).abs()
+    if has_nearest:
+        assert (d > 5e-4).float().mean().item() <= 5e-3, (what, (d > 5e-4).float().mean().item())
+    else:
+        assert d.max().item() <= 5e-4, (what, d.max().item())
+
+
 def test_seeded_pipelines_reproduce_under_patch():
     K = ref_shim.import_reference()
     from mode import emulated_device
@@ -59,7 +77,7 @@ def test_seeded_pipelines_reproduce_under_patch():
 
     rng = random.Random(20250923)
     t0, n = time.time(), 0
-    while time.time() - t0 < SECONDS or n < 25:
+    while _more(t0, n):
         make = _pipeline_factory(K.augmentation, rng)
         seed, with_inverse = rng.randint(0, 10**6), rng.random() < 0.5
         x = torch.rand(rng.randint(1, 5), 3, rng.randint(12, 48), rng.randint(12, 48), generator=torch.Generator().manual_seed(seed))
@@ -81,7 +99,7 @@ def test_seeded_pipelines_reproduce_under_patch():
         names = [type(m).__name__ for m in aug.children()]
         for r, a in zip(ref, out):
             assert r.shape == a.shape and r.dtype == a.dtype, (n, seed, names)
-            assert (r - a).abs().max().item() <= 5e-4, (n, seed, names, (r - a).abs().max().item())
+            _close(r, a, any(getattr(m, "flags", {}).get("resample", None) is not None and "NEAREST" in str(m.flags["resample"]).upper() for m in aug.children()), (n, seed, names))
         n += 1
     assert n >= 25
 
@@ -109,7 +127,7 @@ def test_seeded_pipelines_gradient_then_replay_then_inverse_under_patch():
 
     rng = random.Random(777)
     t0, n = time.time(), 0
-    while time.time() - t0 < SECONDS or n < 20:
+    while _more(t0, n, 40):
         make, seed = _pipeline_factory(K.augmentation, rng), rng.randint(0, 10**6)
         x = torch.rand(rng.randint(1, 4), 3, rng.randint(12, 40), rng.randint(12, 40), generator=torch.Generator().manual_seed(seed))
         ref, names = run(make, x, seed + 2, seed, None)

@@ -2,10 +2,10 @@
 strided / channels-last / empty / 64-bit / 16-bit tensors, every error convention the reference's argument checks have, and
 NON-FINITE SAMPLING COORDINATES (a singular matrix) - against the live reference, on the host build of the kernels (tests/emu).
 
-The last group pins the one place where the native path is KNOWN to differ from the reference ("Non-finite
-sampling coordinates"): the kernels decide tap bounds in floating point, so a NaN / inf coordinate is simply outside the source
-(zeros / fill; the oracle restates the same rule), where ATen's CPU sampler multiplies its masked-out (zero) taps by NaN weights
-and returns NaN.  The tests below state both sides so the difference cannot move unnoticed."""
+The last group was, until round 6, the one place where the native path was KNOWN to differ from the reference (DESIGN.md section 2,
+"Non-finite sampling coordinates"): a NaN / inf coordinate was simply outside the source (zeros / fill), where ATen's CPU sampler
+multiplies its masked-out (zero) taps by NaN weights and returns NaN.  Kernels and oracle now follow the reference; the tests
+below assert EQUALITY with the live reference, forward and backward."""
 import os
 import sys
 
@@ -135,49 +135,66 @@ def test_error_conventions_are_the_references(env, case):
 NONFINITE_MATRICES = {
     "all_zero": lambda: torch.zeros(2, 3, 3),  # the closed-form inverse divides by a zero determinant: every coordinate NaN
     "nan_entry": lambda: torch.eye(3).repeat(2, 1, 1).index_put((torch.tensor([0, 1]), torch.tensor([0, 0]), torch.tensor([2, 2])), torch.tensor(float("nan"))),
+    "inf_entry": lambda: torch.eye(3).repeat(2, 1, 1).index_put((torch.tensor([0, 1]), torch.tensor([1, 1]), torch.tensor([1, 1])), torch.tensor(float("inf"))),
+    # denominator 0.25 (x - 11): exactly zero on the centre column of a 23-wide output, finite elsewhere
+    "zero_denominator_column": lambda: torch.linalg.inv(torch.tensor([[1.0, 0, 0], [0, 1, 0], [0.25, 0, -0.25 * 11]], dtype=torch.float64)).float().repeat(2, 1, 1),
 }
 
 
+def _same_nan_pattern_and_values(a, r, atol=0.0):
+    assert torch.equal(a.isnan(), r.isnan()), (a.isnan() != r.isnan()).sum()
+    fin = ~r.isnan()
+    if atol:
+        assert torch.allclose(a[fin], r[fin], atol=atol, rtol=0)
+    else:
+        assert torch.equal(a[fin], r[fin])
+
+
 @pytest.mark.parametrize("which", sorted(NONFINITE_MATRICES))
-def test_nonfinite_sampling_coordinates_known_difference(env, which):
-    """A singular (or NaN-carrying) matrix makes every sampling coordinate NaN.  Bilinear, zeros padding - the hot path:
-    the reference (ATen's CPU sampler) returns NaN everywhere; the native kernels, like the oracle, treat the pixel as outside
-    the source and return the padding value.  Neither raises.  Finite matrices in the same batch are unaffected (second half)."""
+def test_nonfinite_sampling_coordinates_are_the_references(env, which):
+    """A singular (or NaN / inf carrying) matrix, or a projective denominator that vanishes on a column of the output, makes sampling
+    coordinates NaN / inf.  The reference (ATen's CPU sampler) gathers the taps of such a pixel as zeros and still multiplies them by the NaN
+    weights: NaN for bilinear (zeros and fill padding) and bicubic, 0 for nearest.  Rounds 1-5 of the native path (and of the oracle) treated
+    the pixel as outside the source - zeros / the fill colour - which silently masked a diverged homography; since round 6 kernels and oracle
+    follow the reference (csrc/km_sampler.h km_bilinear_masked, oracle/ko_impl.h): equality against the LIVE reference, pixel for pixel."""
     K, AT, AF = env
     import oracle as O
 
     x, M_ok = _inputs()
     M = NONFINITE_MATRICES[which]()
-    ref = K.geometry.warp_perspective(x, M, (11, 13))
-    nat = AT.warp_perspective(x.cuda(), M.cuda(), (11, 13))
-    orc = O.warp_perspective(x, M, (11, 13))
-    assert ref.isnan().all()  # the reference's side of the difference
-    assert torch.equal(nat, torch.zeros_like(nat)) and torch.equal(orc, nat)  # the native side = the oracle's
-    nat_fill = AT.warp_perspective(x.cuda(), M.cuda(), (11, 13), padding_mode="fill", fill_value=torch.tensor([0.1, 0.2, 0.3]))
-    assert torch.equal(nat_fill, torch.tensor([0.1, 0.2, 0.3]).view(1, 3, 1, 1).expand_as(nat_fill))
-    # bicubic has no bounds decision to make on the weights: NaN on both sides
-    assert AT.warp_perspective(x.cuda(), M.cuda(), (11, 13), mode="bicubic").isnan().all()
-    assert K.geometry.warp_perspective(x, M, (11, 13), mode="bicubic").isnan().all()
+    size = (11, 23)
+    ref = K.geometry.warp_perspective(x, M, size)
+    assert ref.isnan().any()  # the case is one
+    _same_nan_pattern_and_values(AT.warp_perspective(x.cuda(), M.cuda(), size), ref)
+    _same_nan_pattern_and_values(O.warp_perspective(x, M, size), ref)
+    fill = torch.tensor([0.1, 0.2, 0.3])
+    _same_nan_pattern_and_values(AT.warp_perspective(x.cuda(), M.cuda(), size, padding_mode="fill", fill_value=fill),
+                                 K.geometry.warp_perspective(x, M, size, padding_mode="fill", fill_value=fill))
+    _same_nan_pattern_and_values(AT.warp_perspective(x.cuda(), M.cuda(), size, mode="bicubic"), K.geometry.warp_perspective(x, M, size, mode="bicubic"), atol=1e-6)
+    _same_nan_pattern_and_values(AT.warp_perspective(x.cuda(), M.cuda(), size, mode="nearest"), K.geometry.warp_perspective(x, M, size, mode="nearest"))
+    _same_nan_pattern_and_values(AT.warp_affine(x.cuda(), M[:, :2].cuda(), size), K.geometry.warp_affine(x, M[:, :2], size))
     # one bad sample does not touch its neighbour in the batch
     mixed = torch.stack([M[0], M_ok[1]])
-    nat_mixed = AT.warp_perspective(x.cuda(), mixed.cuda(), (11, 13))
-    assert torch.equal(nat_mixed[1], K.geometry.warp_perspective(x, M_ok, (11, 13))[1])
-    assert torch.equal(nat_mixed[0], torch.zeros_like(nat_mixed[0]))
+    _same_nan_pattern_and_values(AT.warp_perspective(x.cuda(), mixed.cuda(), size), K.geometry.warp_perspective(x, mixed, size))
 
 
-def test_nonfinite_coordinates_gradients_stay_finite_on_the_native_path(env):
-    """Backward of the same case: the native image gradient is zero for a sample whose coordinates are NaN (no tap is inside),
-    finite for its neighbour; the reference's is NaN for the bad sample (NaN weights times the upstream gradient)."""
+@pytest.mark.parametrize("which", sorted(NONFINITE_MATRICES))
+def test_nonfinite_sampling_coordinates_gradients_are_the_references(env, which):
+    """Backward of the same cases against the live reference: a pixel with a non-finite position scatters nothing into the image gradient
+    (ATen's scatter is masked), and the matrix gradient of its sample is NaN in the reference's entries; the neighbour in the batch is
+    untouched."""
     K, AT, AF = env
     x, M_ok = _inputs()
-    mixed = torch.stack([torch.zeros(3, 3), M_ok[1]])
-    xr = x.clone().requires_grad_(True)
-    K.geometry.warp_perspective(xr, mixed, (11, 13)).sum().backward()
-    xa = x.cuda().requires_grad_(True)
-    AT.warp_perspective(xa, mixed.cuda(), (11, 13)).sum().backward()
-    assert torch.equal(xa.grad[0], torch.zeros_like(xa.grad[0]))
-    assert torch.allclose(xa.grad[1], xr.grad[1], atol=1e-5, rtol=0)
-    assert not torch.isfinite(xr.grad[0]).all() or torch.equal(xr.grad[0], torch.zeros_like(xr.grad[0]))
+    mixed = torch.stack([NONFINITE_MATRICES[which]()[0], M_ok[1]])
+    go = torch.rand(2, 3, 11, 23, generator=torch.Generator().manual_seed(5)) - 0.5
+    xr, Mr = x.clone().requires_grad_(True), mixed.clone().requires_grad_(True)
+    K.geometry.warp_perspective(xr, Mr, (11, 23)).backward(go)
+    xa, Ma = x.cuda().requires_grad_(True), mixed.cuda().requires_grad_(True)
+    AT.warp_perspective(xa, Ma, (11, 23)).backward(go.cuda())
+    assert torch.isfinite(xr.grad).all() and torch.allclose(xa.grad, xr.grad, atol=1e-5, rtol=0)
+    assert torch.equal(torch.isfinite(Ma.grad), torch.isfinite(Mr.grad)), (Ma.grad, Mr.grad)
+    assert not torch.isfinite(Mr.grad[0]).any() and torch.isfinite(Mr.grad[1]).all()
+    assert ((Ma.grad[1] - Mr.grad[1]).abs().max() / Mr.grad[1].abs().max()).item() < 5e-3
 
 
 def _mirrored_pairs(K):
