@@ -35,8 +35,8 @@ from .filters.gaussian import gaussian_blur2d
 from .geometry.transform.builders import get_affine_matrix2d, get_perspective_transform
 from .geometry.transform.imgwarp import COORD_PERSPECTIVE, _warp, _warp_affine_from_chain, warp_affine, warp_perspective
 
-__all__ = ["affine_chain", "affine_matrix", "apply_sequence", "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "random_perspective",
-           "select_samples"]
+__all__ = ["AugmentationSequential", "ColorJitter", "ParamItem", "RandomAffine", "RandomGaussianBlur", "affine_chain", "affine_matrix", "apply_sequence",
+           "color_jitter", "gaussian_taps", "random_affine", "random_gaussian_blur", "random_perspective", "select_samples"]
 
 
 def _p(params: Mapping[str, Any], key: str, device) -> torch.Tensor:
@@ -226,3 +226,330 @@ def apply_sequence(input: torch.Tensor, affine: Mapping[str, Any], jitter: Mappi
                    kernel_size=(5, 5)) -> torch.Tensor:
     """BASELINE config 3: RandomAffine -> ColorJitter -> RandomGaussianBlur with replayed parameters."""
     return random_gaussian_blur(color_jitter(random_affine(input, affine), jitter), blur, kernel_size)
+
+
+# =====================================================================================================================================
+# The modules (round 6): BASELINE config 3 AS IT IS WRITTEN - ``AugmentationSequential(RandomAffine(...), ColorJitter(...),
+# RandomGaussianBlur(...))(x)`` - with the PARAMETER SAMPLING inside the call.
+#
+# The functions above take parameter dictionaries somebody else sampled; on a machine without Kornia (the GPU box of this project: the
+# reference tree may not travel) that left config 3's public spelling without an implementation and its sampling - which SURVEY.md 8(f) calls
+# the real wall time of the layer - outside every timing.  These classes are the missing half, written against the behaviour of
+# kornia/augmentation/base.py:179-272 (``__batch_prob_generator__``, ``forward_parameters``), random_generator/_2d/affine.py:161-213,
+# random_generator/_2d/color_jitter.py:97-110, random_generator/_2d/gaussian_blur.py:75-79 and container/augment.py:431-500:
+#
+#   * the draws come from torch's GLOBAL CPU generator in the reference's order - batch_prob first (only for 0 < p < 1), then each quantity as
+#     ``low + torch.rand(n) * (high - low)`` in float32 (torch.distributions.Uniform.rsample), a degenerate range still consuming its draw,
+#     ``torch.randperm(4)`` last for the colour order - so ``torch.manual_seed(s)`` followed by the same pipeline gives THE SAME parameters as
+#     Kornia does (tests/golden/aug_modules.npz: the reference's ``_params`` for seeded calls, compared entry for entry);
+#   * a module's draws land in ONE host buffer and cross to the device as ONE copy (the reference moves every parameter tensor on its own);
+#     ``_params`` exposes host views with the reference's keys, so a replay through Kornia - or of Kornia's through this - works;
+#   * the apply step is the functions above: the per-sample probability switch inside the launches, no blend pass, no host synchronisation.
+# Only what config 3 spells: 4-D (or 3-D) image tensors, ``data_keys=["input"]``, no ``random_apply``; everything else raises.
+from collections import namedtuple
+
+ParamItem = namedtuple("ParamItem", ["name", "data"])  # (module name, parameter dictionary): what ``AugmentationSequential._params`` holds
+
+
+def _range_pair(value, name: str, center: float, bounds, scalar_ok: bool = True) -> torch.Tensor:
+    """(low, high) as a float32 tensor: a single number v means (center - v, center + v) clamped to ``bounds`` - computed in float32 tensor
+    arithmetic, as the reference's ``_range_bound`` does, so that the bounds are the same bits - a pair is taken as given."""
+    t = value.detach().to(torch.float32).cpu() if isinstance(value, torch.Tensor) else torch.tensor(value, dtype=torch.float32)
+    if t.dim() == 0:
+        if not scalar_ok or float(t) < 0:
+            raise ValueError(f"If {name} is a single number, it must be non negative. Got {t}.")
+        t = (t.repeat(2) * torch.tensor([-1.0, 1.0]) + center).clamp(bounds[0], bounds[1])
+    if t.shape != (2,):
+        raise ValueError(f"{name} must be a number or a (low, high) pair. Got {tuple(t.shape)}.")
+    if not (bounds[0] <= float(t[0]) <= float(t[1]) <= bounds[1]):
+        raise ValueError(f"{name} out of bounds. Expected inside {bounds} and low <= high, got {t.tolist()}.")
+    return t
+
+
+class _Draws:
+    """The host buffer of one module's draws: ``floats`` float32 values in one (pinned) allocation, handed out as contiguous pieces."""
+
+    def __init__(self, floats: int):
+        self.buf = torch.empty(max(int(floats), 1), dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        self.k = 0
+
+    def piece(self, *shape: int) -> torch.Tensor:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        out = self.buf[self.k:self.k + n].view(*shape)
+        self.k += n
+        return out
+
+    @staticmethod
+    def uniform(lo_hi: torch.Tensor, B: int, same_on_batch: bool, out: torch.Tensor) -> torch.Tensor:
+        """``low + torch.rand(n) * (high - low)`` in float32 from the global CPU generator (torch.distributions.Uniform.rsample), one value
+        repeated over the batch for ``same_on_batch``, written to ``out`` (B values, any stride)."""
+        r = torch.rand(1 if same_on_batch else B, dtype=torch.float32)
+        v = lo_hi[0] + r * (lo_hi[1] - lo_hi[0])
+        out.copy_(v.expand(B) if same_on_batch else v)
+        return out
+
+
+class _RandomOp(torch.nn.Module):
+    """What the three modules share: p / same_on_batch / keepdim, the probability draw, one host buffer -> one device copy, replay."""
+
+    _FLOATS_PER_SAMPLE = 1  # float32 values the module draws / derives per sample, batch_prob included
+
+    def __init__(self, p: float, same_on_batch: bool, keepdim: bool, p_batch: float = 1.0):
+        super().__init__()
+        self.p, self.p_batch, self.same_on_batch, self.keepdim = float(p), float(p_batch), bool(same_on_batch), bool(keepdim)
+        self._params: dict = {}
+        self._host_buf: Optional[torch.Tensor] = None
+
+    def _sample(self, d: _Draws, shape, params: dict) -> None:
+        raise NotImplementedError
+
+    def _apply(self, x: torch.Tensor, params: dict) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _batch_prob(self, B: int, out: torch.Tensor) -> torch.Tensor:
+        # base.py:179-215: a batch-level gate (p_batch) first, then the per-sample gates; certain outcomes consume nothing
+        gate = 1.0
+        if 0.0 < self.p_batch < 1.0:
+            gate = float((torch.rand(1) < self.p_batch).item())
+        elif self.p_batch <= 0.0:
+            gate = 0.0
+        if self.p >= 1.0:
+            e = torch.ones(B)
+        elif self.p <= 0.0:
+            e = torch.zeros(B)
+        elif self.same_on_batch:
+            e = (torch.rand(1) < self.p).to(torch.float32).expand(B)
+        else:
+            e = (torch.rand(B) < self.p).to(torch.float32)
+        out.copy_(e * gate)
+        return out
+
+    def forward_parameters(self, batch_shape) -> dict:
+        """Sample this call's parameters on the host (the reference's keys; every float tensor a piece of ONE buffer)."""
+        B = int(batch_shape[0])
+        d = _Draws(self._FLOATS_PER_SAMPLE * B)
+        params: dict = {"batch_prob": self._batch_prob(B, d.piece(B))}
+        self._sample(d, batch_shape, params)
+        params["forward_input_shape"] = torch.tensor(tuple(int(v) for v in batch_shape), dtype=torch.long)
+        self._host_buf = d.buf
+        return params
+
+    def _device_params(self, params: Mapping[str, Any], device, own: bool) -> dict:
+        """The parameters as the apply step wants them: this module's own sample crosses to the device as ONE copy of the draw buffer (the
+        float tensors of ``params`` are pieces of it); foreign parameters (a replay) go tensor by tensor, as the functions above take them."""
+        out = dict(params)
+        if own and self._host_buf is not None:
+            buf = self._host_buf
+            dev = buf.to(device, non_blocking=True)
+            base = buf.data_ptr()
+            for k, v in params.items():
+                if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel():
+                    off = (v.data_ptr() - base) // 4
+                    out[k] = dev[off:off + v.numel()].view(v.shape)
+        if self.p >= 1.0 and self.p_batch >= 1.0:
+            out["batch_prob"] = None  # every sample is transformed: no switch in the launches at all
+        return out
+
+    def forward(self, input: torch.Tensor, params: Optional[Mapping[str, Any]] = None) -> torch.Tensor:
+        N.require_device(input, "input")
+        if input.dim() not in (3, 4):
+            raise ValueError(f"expected a (B, C, H, W) or (C, H, W) image tensor, got {tuple(input.shape)}")
+        x = input.unsqueeze(0) if input.dim() == 3 else input
+        own = params is None
+        if own:
+            params = self.forward_parameters(x.shape)
+        self._params = dict(params)
+        out = self._apply(x, self._device_params(self._params, x.device, own))
+        return out[0] if (input.dim() == 3 and self.keepdim) else out
+
+
+class RandomAffine(_RandomOp):
+    """``kornia.augmentation.RandomAffine`` (kornia/augmentation/_2d/geometric/affine.py:33-162) on the native path: the same constructor,
+    the same parameter draws, parameters -> matrix -> normalise / invert in one launch, the warp with the probability switch inside it."""
+
+    _FLOATS_PER_SAMPLE = 10  # batch_prob, angle, shear x / y, scale (2), translation (2), centre (2)
+
+    def __init__(self, degrees, translate=None, scale=None, shear=None, resample="BILINEAR", same_on_batch: bool = False, align_corners: bool = False,
+                 padding_mode="ZEROS", fill_value=None, p: float = 0.5, keepdim: bool = False) -> None:
+        super().__init__(p, same_on_batch, keepdim)
+        self.degrees = _range_pair(degrees, "degrees", 0.0, (-360.0, 360.0))
+        self.translate = None
+        if translate is not None:
+            t = torch.as_tensor(translate, dtype=torch.float32)
+            if t.shape != (2,) or not bool(((t >= 0) & (t <= 1)).all()):
+                raise ValueError(f"translate must be two fractions in [0, 1]. Got {translate}.")
+            self.translate = t
+        self.scale = None
+        if scale is not None:
+            s = torch.as_tensor(scale, dtype=torch.float32)
+            if s.shape not in ((2,), (4,)) or not bool((s >= 0).all()):
+                raise ValueError(f"'scale' expected to be either 2 or 4 non-negative elements. Got {scale}")
+            self.scale = s
+        self.shear = None
+        if shear is not None:
+            sh = torch.as_tensor(shear, dtype=torch.float32)
+            if sh.dim() == 0:
+                self.shear = torch.stack([_range_pair(sh, "shear-x", 0.0, (-360.0, 360.0)), torch.zeros(2)])
+            elif sh.shape == (2,):
+                self.shear = torch.stack([_range_pair(sh, "shear-x", 0.0, (-360.0, 360.0)), torch.zeros(2)])
+            elif sh.shape == (4,):
+                self.shear = torch.stack([_range_pair(sh[:2], "shear-x", 0.0, (-360.0, 360.0)), _range_pair(sh[2:], "shear-y", 0.0, (-360.0, 360.0))])
+            elif sh.shape == (2, 2):
+                self.shear = sh
+            else:
+                raise ValueError(f"shear must be a number, a pair, four numbers or a 2 x 2 tensor. Got {shear}.")
+        self.resample = str(getattr(resample, "name", resample)).lower()
+        self.padding_mode = str(getattr(padding_mode, "name", padding_mode)).lower()
+        self.align_corners = bool(align_corners)
+        self.fill_value = fill_value
+        self._transform_matrix: Optional[torch.Tensor] = None
+
+    def _sample(self, d: _Draws, shape, params: dict) -> None:
+        # random_generator/_2d/affine.py:161-213: angle, scale (x, then y when four numbers were given), translation x, y, shear x, y
+        B, H, W = int(shape[0]), int(shape[-2]), int(shape[-1])
+        same = self.same_on_batch
+        angle, shx, shy = d.piece(B), d.piece(B), d.piece(B)
+        scale, trans, center = d.piece(B, 2), d.piece(B, 2), d.piece(B, 2)
+        d.uniform(self.degrees, B, same, angle)
+        if self.scale is not None:
+            d.uniform(self.scale[:2], B, same, scale[:, 0])
+            if self.scale.numel() == 4:
+                d.uniform(self.scale[2:], B, same, scale[:, 1])
+            else:
+                scale[:, 1] = scale[:, 0]
+        else:
+            scale.fill_(1.0)
+        if self.translate is not None:
+            d.uniform(torch.stack([-self.translate[0], self.translate[0]]), B, same, trans[:, 0]).mul_(W)
+            d.uniform(torch.stack([-self.translate[1], self.translate[1]]), B, same, trans[:, 1]).mul_(H)
+        else:
+            trans.zero_()
+        center[:, 0] = W / 2.0 - 0.5
+        center[:, 1] = H / 2.0 - 0.5
+        if self.shear is not None:
+            d.uniform(self.shear[0], B, same, shx)
+            d.uniform(self.shear[1], B, same, shy)
+        else:
+            shx.zero_()
+            shy.zero_()
+        params.update(translations=trans, center=center, scale=scale, angle=angle, shear_x=shx, shear_y=shy)
+
+    def _apply(self, x: torch.Tensor, params: dict) -> torch.Tensor:
+        fill = self.fill_value
+        if fill is not None and not isinstance(fill, torch.Tensor):
+            fill = torch.full((x.shape[1],), float(fill))
+        return random_affine(x, params, self.resample, self.align_corners, self.padding_mode, fill)
+
+    @property
+    def transform_matrix(self) -> Optional[torch.Tensor]:
+        """(B,3,3) pixel matrix of the last call (identity for the samples whose probability draw failed), computed on demand."""
+        if not self._params:
+            return None
+        shp = self._params["forward_input_shape"].tolist()
+        dev = "cuda"
+        _, M, apply = affine_chain(self._params, dev, shp[-2], shp[-1], with_matrix=True)
+        if apply is not None:
+            M = torch.where(apply.bool().view(-1, 1, 1), M, torch.eye(3, device=M.device).expand_as(M))
+        return M
+
+
+class ColorJitter(_RandomOp):
+    """``kornia.augmentation.ColorJitter`` (kornia/augmentation/_2d/intensity/color_jitter.py:34-159): brightness, contrast, saturation and hue
+    factors per sample, applied in a random (or the given) order by ONE fused kernel (+ the reduction pass of the contrast mean)."""
+
+    _FLOATS_PER_SAMPLE = 5  # batch_prob, brightness, contrast, hue, saturation
+
+    def __init__(self, brightness=0.0, contrast=0.0, saturation=0.0, hue=0.0, same_on_batch: bool = False, p: float = 1.0, keepdim: bool = False,
+                 order: Optional[Sequence[int]] = None) -> None:
+        super().__init__(p, same_on_batch, keepdim)
+        inf = float("inf")
+        self.brightness = _range_pair(brightness, "brightness", 1.0, (0.0, inf))
+        self.contrast = _range_pair(contrast, "contrast", 1.0, (0.0, inf))
+        self.saturation = _range_pair(saturation, "saturation", 1.0, (0.0, inf))
+        self.hue = _range_pair(hue, "hue", 0.0, (-0.5, 0.5))
+        if order is not None:
+            order = tuple(int(i) for i in order)
+            if not set(order) <= {0, 1, 2, 3}:
+                raise ValueError(f"`order` entries must be in 0..3 (brightness, contrast, saturation, hue). Got {order}")
+        self._fixed_order = order
+
+    def _sample(self, d: _Draws, shape, params: dict) -> None:
+        # random_generator/_2d/color_jitter.py:97-110: brightness, contrast, HUE, saturation, then the order of the four stages
+        B, same = int(shape[0]), self.same_on_batch
+        params["brightness_factor"] = d.uniform(self.brightness, B, same, d.piece(B))
+        params["contrast_factor"] = d.uniform(self.contrast, B, same, d.piece(B))
+        params["hue_factor"] = d.uniform(self.hue, B, same, d.piece(B))
+        params["saturation_factor"] = d.uniform(self.saturation, B, same, d.piece(B))
+        params["order"] = torch.randperm(4, dtype=torch.long)
+
+    def _apply(self, x: torch.Tensor, params: dict) -> torch.Tensor:
+        return color_jitter(x, params, self._fixed_order)
+
+
+class RandomGaussianBlur(_RandomOp):
+    """``kornia.augmentation.RandomGaussianBlur`` (kornia/augmentation/_2d/intensity/gaussian_blur.py:31-114): one sigma per sample, the
+    taps of every sample in one launch, the fused separable blur."""
+
+    _FLOATS_PER_SAMPLE = 2  # batch_prob, sigma
+
+    def __init__(self, kernel_size, sigma, border_type: str = "reflect", separable: bool = True, same_on_batch: bool = False, p: float = 0.5,
+                 keepdim: bool = False) -> None:
+        super().__init__(p, same_on_batch, keepdim)
+        self.kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+        s = torch.as_tensor(sigma, dtype=torch.float32)
+        if s.shape != (2,):
+            raise TypeError(f"sigma must be a (min, max) pair. Got {sigma}.")
+        if float(s[1]) < float(s[0]):
+            raise TypeError(f"sigma_max should be higher than sigma_min: {sigma} passed.")
+        if float(s[0]) < 0:
+            raise ValueError(f"sigma out of bounds. Expected inside (0, inf), got {s.tolist()}.")
+        self.sigma = s
+        self.border_type = str(getattr(border_type, "name", border_type)).lower()
+        self.separable = bool(separable)
+
+    def _sample(self, d: _Draws, shape, params: dict) -> None:
+        params["sigma"] = d.uniform(self.sigma, int(shape[0]), self.same_on_batch, d.piece(int(shape[0])))
+
+    def _apply(self, x: torch.Tensor, params: dict) -> torch.Tensor:
+        return random_gaussian_blur(x, params, self.kernel_size, self.border_type, self.separable)
+
+
+class AugmentationSequential(torch.nn.Module):
+    """``kornia.augmentation.AugmentationSequential`` for image tensors (kornia/augmentation/container/augment.py:431-500): every child samples
+    its parameters and transforms the previous child's output; ``params=`` replays a list of ``ParamItem(name, data)`` (this container's
+    ``_params`` - or Kornia's own: the names and keys are the reference's)."""
+
+    def __init__(self, *args: torch.nn.Module, data_keys=("input",), same_on_batch: Optional[bool] = None, keepdim: Optional[bool] = None,
+                 random_apply=False, random_apply_weights=None, transformation_matrix_mode: str = "silent", extra_args=None) -> None:
+        super().__init__()
+        keys = [str(getattr(k, "name", k)).lower() for k in (data_keys or ("input",))]
+        if keys not in (["input"], ["image"], ["0"]):
+            raise NotImplementedError(f"only image tensors are supported here (data_keys={list(data_keys)}); use Kornia's container with kornia_amd.patch() for masks / boxes / keypoints")
+        if random_apply not in (False, None) or random_apply_weights is not None:
+            raise NotImplementedError("random_apply is not supported here; use Kornia's container with kornia_amd.patch()")
+        for i, m in enumerate(args):
+            if not isinstance(m, _RandomOp):
+                raise NotImplementedError(f"child {i} ({type(m).__name__}) is not one of this package's modules (RandomAffine, ColorJitter, RandomGaussianBlur)")
+            if same_on_batch is not None:
+                m.same_on_batch = bool(same_on_batch)
+            if keepdim is not None:
+                m.keepdim = bool(keepdim)
+            self.add_module(f"{type(m).__name__}_{i}", m)
+        self._params: list = []
+
+    def forward_parameters(self, batch_shape) -> list:
+        """One ``ParamItem`` per child, sampled in order (a same-size pipeline: every child sees the input's shape)."""
+        return [ParamItem(name, m.forward_parameters(batch_shape)) for name, m in self.named_children()]
+
+    def forward(self, input: torch.Tensor, params: Optional[Sequence[ParamItem]] = None) -> torch.Tensor:
+        children = list(self.named_children())
+        if params is not None and len(params) != len(children):
+            raise ValueError(f"{len(params)} parameter items for {len(children)} children")
+        out, used = input, []
+        for i, (name, m) in enumerate(children):
+            out = m(out, None if params is None else params[i].data)
+            used.append(ParamItem(name, m._params))
+        self._params = used
+        return out

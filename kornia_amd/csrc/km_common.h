@@ -390,6 +390,9 @@ struct KmConfig {
 };
 const KmConfig& km_config();
 int km_device_cus();
+// a side stream forked from `s` (work on it runs beside what `s` is given next) and its join; nullptr: launch on `s` itself (km_runtime.hip)
+hipStream_t km_side_fork(hipStream_t s);
+int km_side_join(hipStream_t s);
 
 // Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads() also waits for every global
 // load and store of the wave (vmcnt(0)), which is exactly what a kernel that keeps the NEXT tile's loads in flight across the barrier

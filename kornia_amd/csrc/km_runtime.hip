@@ -90,6 +90,51 @@ int km_device_cus() {
     return v > 0 ? v : 0;
 }
 
+// ---- a forked side stream per device ---------------------------------------------------------------------------------------------------
+// km_side_fork(s): work launched on the returned stream starts after everything already queued on `s` and runs BESIDE what `s` is given next;
+// km_side_join(s) makes `s` wait for it.  One non-blocking stream and two events per device, created on first use; the record / wait pairs of
+// concurrent host threads are serialised by a mutex (a later thread's record only ever makes an earlier thread's wait cover more).  Returns
+// nullptr - the caller then launches on `s` itself - while `s` is being captured into a graph, on the host build of the kernels (no device)
+// and when a stream or an event cannot be created.
+struct KmSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int state = 0;  // 0 untried, 1 ready, -1 unavailable
+    std::mutex mu;
+};
+static KmSide g_km_side[64];
+hipStream_t km_side_fork(hipStream_t s) {
+    int dev = 0;
+    if (km_device_cus() <= 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    KmSide& k = g_km_side[dev];
+    std::lock_guard<std::mutex> lock(k.mu);
+    if (k.state == 0) {
+        k.state = (hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&k.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&k.join, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+        if (k.state < 0) (void)hipGetLastError();
+    }
+    if (k.state < 0) return nullptr;
+    if (hipEventRecord(k.fork, s) != hipSuccess || hipStreamWaitEvent(k.stream, k.fork, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return k.stream;
+}
+// after the side stream's work has been launched: `s` waits for it
+int km_side_join(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    KmSide& k = g_km_side[dev];
+    std::lock_guard<std::mutex> lock(k.mu);
+    if (k.state != 1) return -1;
+    hipError_t e = hipEventRecord(k.join, k.stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, k.join, 0);
+    if (e != hipSuccess) { km_set_error("km_side_join: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 int km_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -100,11 +145,13 @@ int km_check_launch(const char* what) {
 }
 
 // ---- km_stream_copy: the copy the hot kernels are compared with (bench.py: roofline.measured_streaming_copy_GBps) --------------------
+// ONE 16-byte piece per thread, one workgroup per 4 KB, no loop: the shape that streams fastest on this part (profiles/r02_hbm_shapes.txt: 6.2 TB/s;
+// two / four / eight pieces per thread 5.8 / 5.7 / 4.3, a grid-stride loop over ~8 resident workgroups per CU 5.2 - round 6, run 3)
 template <bool NT>
 __global__ __launch_bounds__(256) void km_stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
     typedef float km_f4v __attribute__((ext_vector_type(4)));
-    const size_t stride = (size_t)gridDim.x * 256u;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += stride) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) {
         if (NT) {
             const km_f4v v = __builtin_nontemporal_load(reinterpret_cast<const km_f4v*>(src) + i);
             __builtin_nontemporal_store(v, reinterpret_cast<km_f4v*>(dst) + i);
@@ -123,11 +170,8 @@ int km_stream_copy(const void* src, void* dst, long long bytes, int nontemporal,
     if (bytes == 0) return 0;
     KM_REQUIRE(src && dst && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "km_stream_copy: null or unaligned pointer");
     const size_t n16 = (size_t)bytes / 16;
-    const int cus = km_device_cus();
-    // ~8 resident blocks per CU, each lane walking the buffer with a grid stride: the shape a linear 16-byte copy streams fastest in (profiles/r02_hbm_shapes.txt)
-    size_t blocks = (n16 + 255) / 256;
-    const size_t cap = (size_t)(cus > 0 ? cus : 4) * 8u * 4u;
-    if (blocks > cap) blocks = cap;
+    const size_t blocks = (n16 + 255) / 256;
+    KM_REQUIRE(blocks < (1ull << 31), "km_stream_copy: at most 8 TiB per call");
     hipStream_t s = (hipStream_t)stream;
     if (nontemporal) hipLaunchKernelGGL((km_stream_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)src, (float4*)dst, n16);
     else hipLaunchKernelGGL((km_stream_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)src, (float4*)dst, n16);

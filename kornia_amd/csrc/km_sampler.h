@@ -227,8 +227,10 @@ __device__ __forceinline__ int km_tap_index(R x, R y, int W, int H, int pad, int
     R g;
     x = km_compute_coord(x, W, pad, align, g);
     y = km_compute_coord(y, H, pad, align, g);
-    const int ix = (int)x, iy = (int)y;
-    return (ix >= 0 && ix < W && iy >= 0 && iy < H) ? iy * W + ix : -1;
+    // bounds decided on the float (the taps are whole numbers): a NaN position is OUT of bounds - ATen's CPU kernel converts it to INT64_MIN -
+    // where the device's own conversion gives 0, i.e. column 0 / row 0 of the image
+    const bool inb = (x >= (R)0) && (x <= (R)(W - 1)) && (y >= (R)0) && (y <= (R)(H - 1));
+    return inb ? (int)y * W + (int)x : -1;
 }
 
 // bilinear tap set for one output pixel

@@ -719,7 +719,9 @@ struct KmbSquare { static constexpr int TW = 32, TH = 32, PITCH = 52, ROWS = 50;
 #define KMB_FILL_DMA 1       // fp32 storage: the box by LDS-DMA (global_load_lds_dwordx4) instead of through registers
 #endif
 #ifndef KMB_ST16
-#define KMB_ST16 1           // fp32 storage: a quad of lanes transposes its 4 x 4 results and stores 16 bytes per lane (0: one dword per lane and row)
+#define KMB_ST16 0           // 1: fp32 storage, a quad of lanes transposes its 4 x 4 results and stores 16 bytes per lane (0: one dword per lane and row).
+                             // MEASURED SLOWER (round 6, profiles/r06/run1_*: same box, bit-identical): flagship 312.0 / 313.1 us against 288.6 / 287.2,
+                             // 5 degrees 338 against 310, 20 degrees 422 against 386 - a quarter of the store instructions, 8 % more time: see DESIGN.md 4.6
 #endif
 #ifndef KMB_TILT_ROWS
 #define KMB_TILT_ROWS 4      // a region whose output rows span at most this many source rows takes the gather rows when its wide box does not fit

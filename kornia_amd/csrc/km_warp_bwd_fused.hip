@@ -1189,6 +1189,9 @@ __device__ __forceinline__ bool kmo_scan_maybe_unvisited(float x, float y, float
     return !((x > -1.f + e) && (x < W - e) && (y > -1.f + e) && (y < H - e));
 }
 #define KMO_SCAN_BLK 16
+#ifndef KMO_SCAN_FORK
+#define KMO_SCAN_FORK 1   // 0: the scan's launch stays on the launch stream, between the boxes and the persistent loop (A/B)
+#endif
 #ifndef KMO_SCAN_NB
 #define KMO_SCAN_NB 2   // candidate blocks a wave scans at a time
 #endif
@@ -1198,8 +1201,9 @@ __device__ __forceinline__ bool kmo_scan_maybe_unvisited(float x, float y, float
 // One workgroup classifies KMO_NT blocks at a time (thread = block: its four corners), compacts the candidates into an LDS list and deals
 // them to its 16 waves - the candidates are the blocks along the image's borders, i.e. whole rows of blocks: left with the wave that
 // classified them, a few waves walked 30 - 60 blocks each while the rest had none (180 us for the launch; profiles/r04/bwd_general_launch_grid.txt).
-template <typename T, int CM, int ALIGN, int CC>
+template <typename T, int CM, int ALIGN, int NT, int NBLK = KMO_SCAN_NB>  // NT: threads of the workgroup (the candidate list holds NT blocks); NBLK: candidates of a wave in flight
 __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, uint32_t* s_list, uint32_t* s_count) {
+    constexpr int NWV = NT / 64;
     const KmWarpGeom<float>& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const KmoScanMap k = kmo_scan_map<CM, ALIGN>(g);
@@ -1208,7 +1212,7 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
     const uint64_t nblk = (uint64_t)per_image * (uint64_t)g.B;
     const float Wf = (float)g.W, Hf = (float)g.H;
     const size_t dst_plane = (size_t)g.h * g.w;
-    for (uint64_t base = (uint64_t)blockIdx.x * KMO_NT; base < nblk; base += (uint64_t)gridDim.x * KMO_NT) {
+    for (uint64_t base = (uint64_t)blockIdx.x * NT; base < nblk; base += (uint64_t)gridDim.x * NT) {
         if (tid == 0) *s_count = 0u;
         __syncthreads();
         // ---- thread = block: its four corners ----
@@ -1245,13 +1249,13 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
         const uint32_t n = *s_count;
         // ---- wave w takes candidates w, w + 16, ... TWO at a time (their matrix loads, then their grad_out loads, fly together):
         //      64 lanes = 16 columns x 4 rows of a block, four steps ----  (KMO_SCAN_NB at a time)
-        for (uint32_t it = (uint32_t)wave; it < n; it += KMO_SCAN_NB * KMO_NW) {
-            constexpr int NB = KMO_SCAN_NB, NS = KMO_SCAN_BLK / 4;
+        for (uint32_t it = (uint32_t)wave; it < n; it += NBLK * NWV) {
+            constexpr int NB = NBLK, NS = KMO_SCAN_BLK / 4;
             uint32_t bb[NB], tty[NB], ttx[NB];
             float m[NB][9];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const uint32_t iu = min(it + (uint32_t)u * KMO_NW, n - 1u);  // (the last pair of an odd list repeats its candidate: a max is idempotent)
+                const uint32_t iu = min(it + (uint32_t)u * NWV, n - 1u);  // (the last pair of an odd list repeats its candidate: a max is idempotent)
                 const uint64_t eb = base + (uint64_t)s_list[iu];
                 bb[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(eb / per_image));
                 const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(eb - (uint64_t)bb[u] * per_image));
@@ -1347,6 +1351,20 @@ __device__ __forceinline__ void kmo_scan_unvisited(const KmWarpFusedArgs<T>& a, 
     }
 }
 
+// The scan as a launch of its own (round 6).  Inside the general launch it ran in that launch's 1 024-thread workgroups, each holding a CU's
+// LDS, strictly BEHIND the persistent loop: 24 us of a 0.55 ms backward (profiles/r05/run43_*).  It needs nothing the persistent loop produces -
+// the matrices, grad_out, and gmat zeroed by the boxes launch - so it is forked onto a side stream behind the boxes launch and runs BESIDE the
+// persistent loop: 256-thread workgroups of at most 64 registers (the persistent workgroup's 16 waves of 108 leave one wave per SIMD and 3 KB
+// of LDS on every CU), joined in front of the general launch.  While the stream is being captured into a graph (or there is no side stream) the
+// same kernel runs on the launch stream between the boxes and the persistent loop.
+#define KMO_SCAN_NT 256
+template <typename T, int CM, int ALIGN>
+__global__ __launch_bounds__(KMO_SCAN_NT, 8) void km_warp_bwd_scan_kernel(const KmWarpFusedArgs<T> a) {  // (8 waves per SIMD: at most 64 registers)
+    __shared__ uint32_t s_list[KMO_SCAN_NT];
+    __shared__ uint32_t s_count;
+    kmo_scan_unvisited<T, CM, ALIGN, KMO_SCAN_NT, 1>(a, s_list, &s_count);  // (one candidate per wave at a time: 64 registers)
+}
+
 // ---- launch 3: the tiles the persistent loop left (class "general", or a non-finite gradient met at run time) ---------------------
 // Workgroup w looks at the records of tiles general_tiles * w ... (lane = tile, one ballot; up to 64 of them, fewer for small problems so
 // that a batch of a few images whose every tile is marked still spreads over the chip) and walks the marked ones.
@@ -1362,9 +1380,7 @@ __global__ __launch_bounds__(KMO_NT) void km_warp_bwd_general_kernel(const KmWar
     float fillv[CC];
 #pragma unroll
     for (int c = 0; c < CC; ++c) fillv[c] = is_fill ? a.fill[c] : 0.f;
-    // (every workgroup of the launch takes its share first: most have nothing else to do; the list borrows the coordinate tables' LDS)
-    static_assert((KMT_BAND_W + KMT_TAB) * 16 >= KMO_NT * 4, "the candidate list fits the tables");
-    if (a.first && a.scan && PADX == 0 && a.gmat) kmo_scan_unvisited<T, CM, ALIGN, CC>(a, (uint32_t*)l.s_u4, l.s_red);  // (border / reflection: every output pixel is some tile's)
+    // (the scan for non-finite gradients / positions at unvisited pixels is a launch of its own since round 6: km_warp_bwd_scan_kernel)
     // A workgroup of this launch holds a CU's LDS: the grid is one workgroup per persistent worker, each walking its share of the tile
     // groups (a grid of one workgroup per group - 1024 at config 2, four rounds of dispatch with 114 KB of LDS each - cost 45 us per
     // round on some boxes, whatever the workgroups then did: profiles/r04/bwd_general_launch_grid.txt)
@@ -1433,7 +1449,21 @@ static int kmo_launch_k(const KmWarpFusedArgs<T>& a, hipStream_t s) {
         if (attr_set_p) attr_set_p->store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((km_warp_bwd_boxes_kernel<T, CM>), dim3((a.ntiles + 255u) / 256u), dim3(256), 0, s, a);
+    bool forked = false;
+    if (a.first && a.scan && PADX == 0 && a.gmat) {  // (border / reflection: every output pixel is some tile's)
+        const uint64_t nblk = (uint64_t)((a.g.w + KMO_SCAN_BLK - 1) / KMO_SCAN_BLK) * (uint64_t)((a.g.h + KMO_SCAN_BLK - 1) / KMO_SCAN_BLK) * (uint64_t)a.g.B;
+        const uint64_t want = (nblk + KMO_SCAN_NT - 1) / KMO_SCAN_NT;
+        const int cus = km_device_cus();
+        const uint64_t cap = (uint64_t)(cus > 0 ? cus : 2) * 4u;  // (one wave per SIMD beside the persistent workgroup: 4 waves = 1 workgroup per CU at a time; a few rounds)
+        hipStream_t side = KMO_SCAN_FORK ? km_side_fork(s) : nullptr;
+        hipLaunchKernelGGL((km_warp_bwd_scan_kernel<T, CM, ALIGN>), dim3((unsigned)(want < cap ? (want ? want : 1) : cap)), dim3(KMO_SCAN_NT), 0, side ? side : s, a);
+        forked = side != nullptr;
+    }
     hipLaunchKernelGGL((km_warp_bwd_fused_kernel<T, CM, ALIGN, CC, PADX>), dim3(a.nworkers), dim3(KMO_NT), (size_t)lds, s, a);
+    if (forked) {
+        const int rc = km_side_join(s);
+        if (rc != 0) return rc;
+    }
 #ifndef KMO_NO_GENERAL  // (variant libraries only: what the launch itself costs)
     {
         const uint32_t ngroups = (a.ntiles + a.general_tiles - 1u) / a.general_tiles;

@@ -28,6 +28,46 @@
 #define KMQ_PITCH 80
 #define KMQ_ROWS 80
 #endif
+// TOLERANCE SPENT (round 6, KMQ_FMA = 1).  BASELINE.json asks for 1e-5 against the reference; rounds 2-5 kept this kernel's arithmetic operation for
+// operation that of the generic kernel (35 vector instructions per channel for the 4 x 4 taps - 20 multiplies, 15 adds, every product rounded
+// - and 25 per axis for the coefficients), bit-identical to it, <= 1e-6 from the reference (whose own vectorised CPU kernel sums in another
+// order) - and sat on its issue time: ~125 vector instructions per grey pixel, 0.37 ms = 0.36 of the HBM roofline at config 4.  With fused
+// multiply-adds the tap sums are 1 multiply + 3 fma per row and per column (20 per channel) and the coefficient polynomials Horner chains
+// (15 per axis): the same association, products no longer rounded before they are added - each result at least as close to the exact value
+// as the reference's, <= 2e-6 from the oracle and <= 1e-5 from the live reference (asserted: tests/test_gpu_config_parity.py,
+// tests/test_gpu_warp.py, tests/test_oracle_live_sweep.py).  Both paths of this kernel (LDS taps, gather rows) use the same form, so a result
+// still never depends on the box estimate.  KMQ_FMA = 0 restores the exact form (A/B).
+#ifndef KMQ_FMA
+#define KMQ_FMA 1
+#endif
+__device__ __forceinline__ float kmq_dot4(float t0, float t1, float t2, float t3, const float (&c)[4]) {
+#if KMQ_FMA
+    return km_fma(t3, c[3], km_fma(t2, c[2], km_fma(t1, c[1], t0 * c[0])));
+#else
+    return t0 * c[0] + t1 * c[1] + t2 * c[2] + t3 * c[3];
+#endif
+}
+__device__ __forceinline__ void kmq_coeffs(float t, float (&c)[4]) {
+#if KMQ_FMA
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    c[0] = km_fma(km_fma(km_fma(A, x, -5 * A), x, 8 * A), x, -4 * A);
+    x = t;
+    c[1] = km_fma(km_fma(A + 2, x, -(A + 3)) * x, x, 1.0f);
+    x = 1.0f - t;
+    c[2] = km_fma(km_fma(A + 2, x, -(A + 3)) * x, x, 1.0f);
+    x = x + 1.0f;
+    c[3] = km_fma(km_fma(km_fma(A, x, -5 * A), x, 8 * A), x, -4 * A);
+#else
+    km_cubic_coeffs(t, c);
+#endif
+}
+#ifndef KMQ_ST16
+#define KMQ_ST16 0   // 1: fp32 storage, the thread's results leave as 16-byte stores after a 4 x 4 transpose inside each quad of lanes (km_quad_transpose4).
+                     // MEASURED SLOWER (round 6, profiles/r06/run2_*, same box, same bits): config 4 361.6 / 359.8 us against 333.7 / 331.2 with one dword
+                     // per lane and row (and 397.8 against 365.2 on the exact-rounding form): like the box forward, DESIGN.md 4.6
+#endif
+
 template <typename T, int CM, int NC, int ALIGN>
 __device__ __forceinline__ void kmq_rows_gather(const KmWarpArgs<T>& a, const float (&m)[9], const float4* s_rv, const KmlHalf& cu, bool fast, uint32_t b,
                                                           int j, int li_base, int i_base, int rstep, int rpt) {
@@ -49,8 +89,8 @@ __device__ __forceinline__ void kmq_rows_gather(const KmWarpArgs<T>& a, const fl
         const float x = kml_unnormalize<ALIGN>(p.gx, Wm1, hW), y = kml_unnormalize<ALIGN>(p.gy, Hm1, hH);
         const float xf = km_floor(x), yf = km_floor(y);
         float cx[4], cy[4];
-        km_cubic_coeffs(x - xf, cx);
-        km_cubic_coeffs(y - yf, cy);
+        kmq_coeffs(x - xf, cx);
+        kmq_coeffs(y - yf, cy);
         int idx[4][4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
@@ -65,9 +105,9 @@ __device__ __forceinline__ void kmq_rows_gather(const KmWarpArgs<T>& a, const fl
                 float tt[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tt[q] = idx[rr][q] >= 0 ? km_ld(img + idx[rr][q]) : 0.0f;
-                rows[rr] = tt[0] * cx[0] + tt[1] * cx[1] + tt[2] * cx[2] + tt[3] * cx[3];
+                rows[rr] = kmq_dot4(tt[0], tt[1], tt[2], tt[3], cx);
             }
-            km_st(out_px + (size_t)c * dst_plane, rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3]);
+            km_st(out_px + (size_t)c * dst_plane, kmq_dot4(rows[0], rows[1], rows[2], rows[3], cy));
         }
     }
 }
@@ -133,11 +173,15 @@ __global__ __launch_bounds__(256) void km_warp_fwd_cubic_kernel(const KmWarpArgs
         // margin); the loop only RECORDS whether one was not, reads from a clamped LDS offset in that case, and the wave redoes its
         // rows with gathers afterwards - so the result never depends on the box estimate, and the common case pays four compares.
         // The LDS offset of tap (-1, -1) in floats: (yf - 1 - ys) * NC * PITCH + (xf - 1 - xs), exact for every in-box footprint.
+        // The results stay in registers until the wave knows that all its footprints were in the box (nothing is stored twice).
         const float xrel = (float)(bx.xs + 1), yrel = (float)(bx.ys + 1);
         const float off_max = (float)(ROWS * NC * PITCH - (3 * NC * PITCH + (NC - 1) * PITCH + 4));
-#pragma unroll 2
+        float res[NC][RPT];
+#pragma unroll
         for (int r = 0; r < RPT; ++r) {
-            if ((int)ty * TH + r * RSTEP >= g.h) break;  // block-uniform (RSTEP rows of the tile at a time)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) res[c][r] = 0.f;
+            if ((int)ty * TH + r * RSTEP >= g.h) continue;  // block-uniform (RSTEP rows of the tile at a time)
             const int i = i_base + r * RSTEP;
             const bool row_ok = i < g.h;  // (TW == 64: wave-uniform)
             const float4 rv4 = s_rv[li_base + r * RSTEP];
@@ -149,8 +193,8 @@ __global__ __launch_bounds__(256) void km_warp_fwd_cubic_kernel(const KmWarpArgs
             const float x = kml_unnormalize<ALIGN>(p.gx, Wm1, hW), y = kml_unnormalize<ALIGN>(p.gy, Hm1, hH);
             const float xf = km_floor(x), yf = km_floor(y);
             float cx[4], cy[4];
-            km_cubic_coeffs(x - xf, cx);
-            km_cubic_coeffs(y - yf, cy);
+            kmq_coeffs(x - xf, cx);
+            kmq_coeffs(y - yf, cy);
             all_in = all_in & (kmf_in_box_cubic(xf, yf, bx) | !row_ok);
             const float offf = fminf(fmaxf(km_fma(yf - yrel, (float)(NC * PITCH), xf - xrel), 0.0f), off_max);  // (NaN -> 0)
             const float* q = s_src + KM_F2I(offf);
@@ -160,14 +204,48 @@ __global__ __launch_bounds__(256) void km_warp_fwd_cubic_kernel(const KmWarpArgs
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const float* qr = q + (rr * NC + c) * PITCH;
-                    rows[rr] = qr[0] * cx[0] + qr[1] * cx[1] + qr[2] * cx[2] + qr[3] * cx[3];
+                    rows[rr] = kmq_dot4(qr[0], qr[1], qr[2], qr[3], cx);
                 }
-                const float acc = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
-                if (row_ok) km_st(out_col + (size_t)c * dst_plane + (size_t)i * g.w, acc);
+                res[c][r] = kmq_dot4(rows[0], rows[1], rows[2], rows[3], cy);
             }
         }
+        if (__all(all_in)) {  // wave-uniform: every footprint of the wave was in the box - the results are final
+#if KMQ_ST16
+            if constexpr (sizeof(T) == 4 && RPT % 4 == 0) {
+                // 16-byte stores: the quad's 4 columns x 4 of the thread's rows (RSTEP apart) transposed in registers, lane q of the quad writes
+                // the four pixels of row r0 + q.  (Output rows are 16-byte aligned runs of whole quads: lanes right of the image left above.)
+                if (((g.w & 3) == 0) && (((uintptr_t)a.dst & 15) == 0)) {
+                    const int q4 = tid & 3;
+#pragma unroll
+                    for (int r0 = 0; r0 < RPT; r0 += 4) {
+                        if ((int)ty * TH + r0 * RSTEP >= g.h) break;  // block-uniform
+                        const int i = i_base + (r0 + q4) * RSTEP;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            float v4[4] = {res[c][r0], res[c][r0 + 1], res[c][r0 + 2], res[c][r0 + 3]};
+                            km_quad_transpose4(v4, q4);
+                            if (i < g.h) {
+                                float* p = reinterpret_cast<float*>(dst_b) + (size_t)c * dst_plane + (size_t)i * g.w + (size_t)(j & ~3);
+                                KM_CHECK_ALIGNED(p, 16);
+                                km_st4_c<true>(p, v4);
+                            }
+                        }
+                    }
+                    return;
+                }
+            }
+#endif
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int i = i_base + r * RSTEP;
+                if (i < g.h) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) km_st(out_col + (size_t)c * dst_plane + (size_t)i * g.w, res[c][r]);
+                }
+            }
+            return;
+        }
     }
-    if (__all(all_in)) return;  // wave-uniform
     // ---- cold path: the box did not fit the LDS tile (minification), or a footprint of this wave was outside it: per-tap gathers
     kmq_rows_gather<T, CM, NC, ALIGN>(a, m, s_rv, cu, bx.fast, b, j, li_base, i_base, RSTEP, RPT);
 }

@@ -95,6 +95,7 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
     // corners of the tile grown by the bilinear footprint: floor(x) in [X0-1, X1-1]  <=>  x in [X0-1, X1)
     const R xs[2] = {(R)(X0 - 1), (R)X1}, ys[2] = {(R)(Y0 - 1), (R)Y1};
     R jmin = 3.0e38f, jmax = -3.0e38f, imin = 3.0e38f, imax = -3.0e38f, dmin = 3.0e38f, dmax = -3.0e38f, nmax = 0.f;
+    bool num = true;            // every corner maps to a number (fminf / fmaxf DROP a NaN operand: the minima above would keep their initial values)
     R njx = 0.f, njy = 0.f, nix = 0.f, niy = 0.f;
     R egj = 0.f, egi = 0.f;     // rounding of the inverse map at the corners, in output pixels (before the factor gamma)
     R drel = 0.f;               // max |D| rounding relative to |D|
@@ -108,6 +109,7 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
             dmin = fminf(dmin, D); dmax = fmaxf(dmax, D);
             nmax = fmaxf(nmax, fmaxf(fabsf(Jn), fabsf(In)));
             const R fj = Jn / D, fi = In / D;
+            num = num && (D == D) && (fj == fj) && (fi == fi);
             jmin = fminf(jmin, fj); jmax = fmaxf(jmax, fj);
             imin = fminf(imin, fi); imax = fmaxf(imax, fi);
             njx = fmaxf(njx, fabsf(G[0] * D - Jn * G[6])); njy = fmaxf(njy, fabsf(G[1] * D - Jn * G[7]));
@@ -123,11 +125,14 @@ __device__ __forceinline__ KmtBox kmt_tile_box(const KmWarpGeom<float>& g, const
         }
     const bool same_sign = (dmin > 0.f) || (dmax < 0.f);
     const R dabs_min = fminf(fabsf(dmin), fabsf(dmax)), dabs_max = fmaxf(fabsf(dmin), fabsf(dmax));
-    const bool ok = same_sign && (dabs_min > 1e-6f * fmaxf(nmax, dabs_max)) && (jmin == jmin) && (jmax == jmax) && (imin == imin) && (imax == imax);
-    if (!ok) return o;  // tile crossed by the vanishing line: visit the whole output (correct, slower)
+    // (a NaN anywhere in the matrix - a singular M through the closed-form inverse - makes every corner NaN: without `num` the box came
+    // out as (INT_MAX - 1 .. INT_MIN + 1), whose width WRAPS to a small positive number - reads of grad_out gigabytes away from the
+    // tensor on the device: found by the round-6 device run of tests/golden/nonfinite_coords.npz)
+    const bool ok = num && same_sign && (dabs_min > 1e-6f * fmaxf(nmax, dabs_max)) && (jmin == jmin) && (jmax == jmax) && (imin == imin) && (imax == imax);
+    if (!ok) return o;  // tile crossed by the vanishing line, or not a map at all: visit the whole output (correct, slower)
 
-    const R big = 1.0e9f;
-    jmin = fmaxf(jmin, -big); jmax = fminf(jmax, big); imin = fmaxf(imin, -big); imax = fminf(imax, big);
+    const R big = 1.0e9f;  // (both sides: the conversions to int below must not saturate, nor their sums wrap)
+    jmin = fminf(fmaxf(jmin, -big), big); jmax = fmaxf(fminf(jmax, big), -big); imin = fminf(fmaxf(imin, -big), big); imax = fmaxf(fminf(imax, big), -big);
     const R inv_d2 = 1.0f / (dabs_min * dabs_min);
     const R jac_j = (njx + njy) * inv_d2, jac_i = (nix + niy) * inv_d2;  // |dj/dx| + |dj/dy|, |di/dx| + |di/dy| over the tile
     R mj = 1.0f, mi = 1.0f;     // margins in output pixels; with floor / ceil below this is the first version's box

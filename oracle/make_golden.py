@@ -530,6 +530,35 @@ def main():
             dq[key + "__gM"] = Mr.grad if Mr.grad is not None else torch.zeros_like(Min)
     save("nonfinite_coords", **dq)
 
+    # ---- SEEDED augmentation pipelines (own generator: appended in round 6) -----------------------------------------------------------------
+    # `torch.manual_seed(s); AugmentationSequential(RandomAffine, ColorJitter, RandomGaussianBlur)(x)` - BASELINE config 3 as it is written,
+    # sampling included: the parameters Kornia's generators draw for the seed and its fp32 output, for kornia_amd.augmentation's modules (which
+    # draw from the same generator in the same order) on a machine without Kornia.
+    from kornia.augmentation import AugmentationSequential, ColorJitter, RandomAffine, RandomGaussianBlur
+
+    pipelines = {
+        "config3": lambda: AugmentationSequential(RandomAffine(degrees=15.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=1.0),
+                                                  ColorJitter(0.2, 0.2, 0.2, 0.1, p=1.0), RandomGaussianBlur((5, 5), (0.1, 2.0), p=1.0)),
+        "with_probabilities": lambda: AugmentationSequential(RandomAffine(degrees=(-30.0, 10.0), scale=(0.7, 1.1, 0.9, 1.3), shear=(-4.0, 4.0, -2.0, 6.0), padding_mode="border", p=0.6),
+                                                             ColorJitter(0.3, (0.5, 1.5), 0.1, (-0.05, 0.2), p=0.7), RandomGaussianBlur((3, 5), (0.2, 1.5), border_type="replicate", p=0.5)),
+        "same_on_batch": lambda: AugmentationSequential(RandomAffine(degrees=20.0, translate=(0.2, 0.05), p=0.8), ColorJitter(0.1, 0.1, 0.1, 0.1),
+                                                        RandomGaussianBlur((5, 5), (0.5, 1.0), p=1.0), same_on_batch=True),
+    }
+    da = {"x": torch.rand(5, 3, 40, 56, generator=torch.Generator().manual_seed(808))}
+    for pname, make in pipelines.items():
+        for seed in (3, 11):
+            torch.manual_seed(seed)
+            aug = make()
+            out = aug(da["x"])
+            key = f"{pname}__seed{seed}"
+            da[key + "__out"] = out
+            da[key + "__rng_after"] = torch.get_rng_state()[:64].clone()  # (the head of the Mersenne state: the generator stands where Kornia left it)
+            for item in aug._params:
+                for k, v in item.data.items():
+                    if isinstance(v, torch.Tensor):
+                        da[f"{key}__{item.name}__{k}"] = v
+    save("aug_modules", **da)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

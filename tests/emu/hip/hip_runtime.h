@@ -50,6 +50,15 @@ hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDevice(int* dev);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+// (streams and events: the host build runs every launch at once on the calling thread; km_side_fork never hands out a side stream there)
+typedef void* hipEvent_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 1; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 1; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 1; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 1; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {

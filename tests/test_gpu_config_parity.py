@@ -8,7 +8,7 @@ Tolerances (BASELINE.json north_star: 1e-5 fp32, 1e-2 bf16):
   forward fp32                       bit-identical to the oracle (torch.equal)
   grad wrt the image                 |d| <= 1e-5 (fixed-point accumulation, <= 2e-6 * max|grad_out| per DESIGN 4.1)
   grad wrt the matrix                relative to the largest entry: <= 5e-5 vs the fp32 oracle (same sampling positions)
-  bicubic                            <= 1e-6 (cubic coefficient chain, different accumulation order of 16 taps)
+  bicubic                            <= 2e-6 (round 6: taps and coefficients as fused multiply-adds, csrc/km_warp_cubic.hip KMQ_FMA; 1e-6 before)
   homography_warp / warp_grid        <= 1e-5 (the reference's bmm is BLAS-kernel dependent)
 """
 import math
@@ -204,7 +204,7 @@ def test_config3_whole_share_256_bf16_replays_the_reference_fixture_at_full_size
 
 def test_config4_whole_batch_64_frames_against_the_oracle_at_full_size(oracle):
     """BASELINE configs[3] at its batch: 64 x 1 x 1080 x 1920 - SpatialGradient(sobel) and Sobel bit-identical to the oracle on every frame,
-    bicubic warp_affine (2 degrees about the centre + (3, -2) px) <= 1e-6."""
+    bicubic warp_affine (2 degrees about the centre + (3, -2) px) <= 2e-6."""
     import kornia_amd as K
 
     B, H, W = 64, 1080, 1920
@@ -219,7 +219,7 @@ def test_config4_whole_batch_64_frames_against_the_oracle_at_full_size(oracle):
     A = torch.tensor([[[ca, sa, (1 - ca) * cx - sa * cy + 3.0], [-sa, ca, sa * cx + (1 - ca) * cy - 2.0]]]).repeat(B, 1, 1)
     got = K.warp_affine(xd, A.cuda(), (H, W), mode="bicubic").cpu()
     err = (got - oracle.warp_affine(x, A, (H, W), mode="bicubic")).abs().max().item()
-    assert err <= 1e-6, f"bicubic: {err:.2e}"
+    assert err <= 2e-6, f"bicubic: {err:.2e}"
 
 
 def test_config5_whole_share_128_learned_homography_grad_at_full_size(oracle):
@@ -253,7 +253,7 @@ def test_config5_whole_share_128_learned_homography_grad_at_full_size(oracle):
 
 
 def test_config4_1080p_sobel_and_bicubic_match_oracle(oracle):
-    """SpatialGradient(sobel) bit-identical and bicubic warp_affine <= 1e-6 on 1080x1920 frames (rotation 2 deg about the
+    """SpatialGradient(sobel) bit-identical and bicubic warp_affine <= 2e-6 on 1080x1920 frames (rotation 2 deg about the
     centre + (3, -2) px)."""
     import kornia_amd as K
 
@@ -266,7 +266,7 @@ def test_config4_1080p_sobel_and_bicubic_match_oracle(oracle):
     cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
     ca, sa = math.cos(a), math.sin(a)
     A = torch.tensor([[[ca, sa, (1 - ca) * cx - sa * cy + 3.0], [-sa, ca, sa * cx + (1 - ca) * cy - 2.0]]]).repeat(2, 1, 1)
-    for mode, tol in (("bicubic", 1e-6), ("bilinear", 0.0)):
+    for mode, tol in (("bicubic", 2e-6), ("bilinear", 0.0)):
         got = K.warp_affine(x.cuda(), A.cuda(), (H, W), mode=mode).cpu()
         exp = oracle.warp_affine(x, A, (H, W), mode=mode)
         err = (got - exp).abs().max().item()

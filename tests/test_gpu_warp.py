@@ -343,10 +343,20 @@ def test_tiled_backward_nonfinite_gradients_propagate(oracle):
 @pytest.mark.parametrize("C", [1, 3])
 def test_bicubic_lds_staged_kernel_is_bit_identical(oracle, C, dtype):
     """The LDS-staged bicubic forward (km_warp_fwd_cubic_kernel: zeros padding, C in {1, 3}, W % 4 == 0, 16-byte aligned source)
-    against (a) the oracle, bit for bit in fp32, and (b) the per-pixel gather kernel, reached by handing the same image over at an
-    address that is not 16-byte aligned: small and large rotations, minification (source box larger than the LDS tile -> the
-    gather path inside the staged kernel), magnification, a projective map, a map that leaves the image."""
+    against (a) the oracle and (b) the per-pixel gather kernel, reached by handing the same image over at an address that is not 16-byte
+    aligned: small and large rotations, minification (source box larger than the LDS tile -> the gather path inside the staged kernel),
+    magnification, a projective map, a map that leaves the image.
+    Round 6: the staged kernel spends part of the tolerance BASELINE.json grants (1e-5): its taps and coefficients are fused multiply-adds
+    (csrc/km_warp_cubic.hip, KMQ_FMA) - <= 2e-6 from the oracle and from the gather kernel, which keeps the reference's roundings and stays
+    bit-identical to the oracle (the name of the test is from the rounds in which both were)."""
     import kornia_amd as K
+
+    def same(a, b, what):
+        if dtype == torch.float32:
+            assert (a - b).abs().max().item() <= 2e-6, (what, (a - b).abs().max().item())
+        else:  # 16-bit storage: two fp32 results 2e-6 apart round to the same 16-bit value except next to a rounding boundary
+            d = (a.float() - b.float()).abs()
+            assert d.max().item() <= 8e-3 and (d > 0).float().mean().item() <= 2e-3, (what, d.max().item(), (d > 0).float().mean().item())
 
     g = torch.Generator().manual_seed(41)
     B, H, W = 7, 72, 96
@@ -367,15 +377,19 @@ def test_bicubic_lds_staged_kernel_is_bit_identical(oracle, C, dtype):
     for ds in ((H, W), (50, 64), (33, 130)):
         for align in (True, False):
             got = K.warp_affine(xd, A.cuda(), ds, "bicubic", "zeros", align)
-            assert torch.equal(got, K.warp_affine(off, A.cuda(), ds, "bicubic", "zeros", align)), (ds, align, "affine")
+            gen = K.warp_affine(off, A.cuda(), ds, "bicubic", "zeros", align)
+            same(got, gen, (ds, align, "affine"))
             gotp = K.warp_perspective(xd, M.cuda(), ds, "bicubic", "zeros", align)
-            assert torch.equal(gotp, K.warp_perspective(off, M.cuda(), ds, "bicubic", "zeros", align)), (ds, align, "perspective")
+            genp = K.warp_perspective(off, M.cuda(), ds, "bicubic", "zeros", align)
+            same(gotp, genp, (ds, align, "perspective"))
             if dtype == torch.float32:
-                assert torch.equal(got.cpu(), oracle.warp_affine(x, A, ds, "bicubic", "zeros", align, None)), (ds, align)
-                assert torch.equal(gotp.cpu(), oracle.warp_perspective(x, M, ds, "bicubic", "zeros", align, None)), (ds, align)
+                oa, op = oracle.warp_affine(x, A, ds, "bicubic", "zeros", align, None), oracle.warp_perspective(x, M, ds, "bicubic", "zeros", align, None)
+                assert torch.equal(gen.cpu(), oa) and torch.equal(genp.cpu(), op), (ds, align)  # the gather kernel: the reference's roundings
+                same(got.cpu(), oa, (ds, align, "oracle"))
+                same(gotp.cpu(), op, (ds, align, "oracle"))
     Hn = torch.eye(3)[None].repeat(B, 1, 1) + 0.05 * torch.randn(B, 3, 3, generator=g)
     goth = K.homography_warp(xd, Hn.cuda(), (H, W), "bicubic", "zeros", True)
-    assert torch.equal(goth, K.homography_warp(off, Hn.cuda(), (H, W), "bicubic", "zeros", True))
+    same(goth, K.homography_warp(off, Hn.cuda(), (H, W), "bicubic", "zeros", True), "homography")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
