@@ -401,6 +401,31 @@ def other_configs(dev):
                                 "timed": "the faster of HIP-graph replay and eager", "eager_ms": out["cfg3_bf16_256x3x224_eager_ms"]}
     except Exception as e:  # informational only
         out["error_cfg3"] = f"{type(e).__name__}: {e}"
+    try:  # config 3 AS BASELINE WRITES IT: AugmentationSequential(RandomAffine, ColorJitter, RandomGaussianBlur)(x), the parameter sampling INSIDE the call
+        with torch.no_grad():
+            x = torch.rand(256, 3, 224, 224, device=dev).bfloat16()
+            aug = A.AugmentationSequential(A.RandomAffine(degrees=15.0, translate=(0.1, 0.1), scale=(0.8, 1.2), shear=5.0, p=1.0),
+                                           A.ColorJitter(0.2, 0.2, 0.2, 0.1, p=1.0), A.RandomGaussianBlur((5, 5), (0.1, 2.0), p=1.0))
+            torch.manual_seed(0)
+            ms_mod = t(lambda: aug(x), "cfg3_as_written_modules_with_sampling")
+            # the host's share alone: the three modules' draws (torch's CPU generator, the reference's order) and their three H2D copies
+            t0 = time.perf_counter()
+            for _ in range(200):
+                aug.forward_parameters(x.shape)
+            host_ms = (time.perf_counter() - t0) / 200 * 1e3
+            rep = aug._params
+            ms_replay = t(lambda: aug(x, params=rep), "cfg3_as_written_modules_replay")
+        out["cfg3_as_written"] = {
+            "call": "kornia_amd.augmentation.AugmentationSequential(RandomAffine(15, (0.1, 0.1), (0.8, 1.2), 5, p=1), ColorJitter(0.2, 0.2, 0.2, 0.1, p=1), RandomGaussianBlur((5, 5), (0.1, 2.0), p=1))(x)",
+            "input": "256x3x224x224 bf16 (the per-GPU share of configs[2])",
+            "ms_per_call_with_sampling": ms_mod, "ms_per_call_replayed_parameters": ms_replay, "host_sampling_ms_alone": round(host_ms, 4),
+            "roofline": roof(ms_mod, 3 * 2 * 2 * x.numel()),
+            "note": "the draws are Kornia's own (torch's global CPU generator, same order: tests/test_gpu_aug_modules.py compares them entry for entry with the "
+                    "reference's for the same seed); one host buffer and ONE device copy per module; the host works ahead of the device, so the call is "
+                    "host-bound only while the host's share per call exceeds the kernels' time",
+        }
+    except Exception as e:  # informational only
+        out["error_cfg3_as_written"] = f"{type(e).__name__}: {e}"
     try:
         with torch.no_grad():
             x = torch.rand(64, 1, 1080, 1920, device=dev)

@@ -282,6 +282,17 @@ class _Draws:
         return out
 
     @staticmethod
+    def uniforms(lo: torch.Tensor, span: torch.Tensor, B: int, same_on_batch: bool) -> torch.Tensor:
+        """k consecutive draws at once, (k, B): ``lo[i] + torch.rand(B) * span[i]`` for i = 0 .. k-1 IN THAT ORDER.  ONE call of the generator
+        for what the reference draws in k calls: torch's CPU generator fills a float32 tensor element by element, so ``torch.rand(k * B)`` is
+        the concatenation of k ``torch.rand(B)`` (tests/test_gpu_aug_modules.py::test_one_call_of_the_generator_is_k_calls pins that) - and the
+        host's share of a call is what bounds config 3 as it is written."""
+        k = lo.numel()
+        r = torch.rand(k * (1 if same_on_batch else B), dtype=torch.float32).view(k, -1)
+        v = lo.view(k, 1) + r * span.view(k, 1)
+        return v.expand(k, B) if same_on_batch else v
+
+    @staticmethod
     def uniform(lo_hi: torch.Tensor, B: int, same_on_batch: bool, out: torch.Tensor) -> torch.Tensor:
         """``low + torch.rand(n) * (high - low)`` in float32 from the global CPU generator (torch.distributions.Uniform.rsample), one value
         repeated over the batch for ``same_on_batch``, written to ``out`` (B values, any stride)."""
@@ -299,8 +310,24 @@ class _RandomOp(torch.nn.Module):
     def __init__(self, p: float, same_on_batch: bool, keepdim: bool, p_batch: float = 1.0):
         super().__init__()
         self.p, self.p_batch, self.same_on_batch, self.keepdim = float(p), float(p_batch), bool(same_on_batch), bool(keepdim)
-        self._params: dict = {}
-        self._host_buf: Optional[torch.Tensor] = None
+        # (per-call state lives in a plain dict: torch.nn.Module.__setattr__ costs ~10 us per assignment, and the host's share bounds the call)
+        object.__setattr__(self, "_st", {"params": {}, "host_buf": None, "dev_buf": None})
+
+    @property
+    def _params(self) -> dict:
+        return self._st["params"]
+
+    @property
+    def _host_buf(self):
+        return self._st["host_buf"]
+
+    @property
+    def _dev_buf(self):
+        return self._st["dev_buf"]
+
+    @_dev_buf.setter
+    def _dev_buf(self, v):
+        self._st["dev_buf"] = v
 
     def _sample(self, d: _Draws, shape, params: dict) -> None:
         raise NotImplementedError
@@ -326,14 +353,15 @@ class _RandomOp(torch.nn.Module):
         out.copy_(e * gate)
         return out
 
-    def forward_parameters(self, batch_shape) -> dict:
-        """Sample this call's parameters on the host (the reference's keys; every float tensor a piece of ONE buffer)."""
+    def forward_parameters(self, batch_shape, draws: Optional[_Draws] = None) -> dict:
+        """Sample this call's parameters on the host (the reference's keys; every float tensor a piece of ONE buffer - the container's,
+        when it hands one in: then the whole pipeline's draws cross to the device as one copy)."""
         B = int(batch_shape[0])
-        d = _Draws(self._FLOATS_PER_SAMPLE * B)
+        d = draws if draws is not None else _Draws(self._FLOATS_PER_SAMPLE * B)
         params: dict = {"batch_prob": self._batch_prob(B, d.piece(B))}
         self._sample(d, batch_shape, params)
         params["forward_input_shape"] = torch.tensor(tuple(int(v) for v in batch_shape), dtype=torch.long)
-        self._host_buf = d.buf
+        self._st["host_buf"], self._st["dev_buf"] = d.buf, None
         return params
 
     def _device_params(self, params: Mapping[str, Any], device, own: bool) -> dict:
@@ -342,7 +370,7 @@ class _RandomOp(torch.nn.Module):
         out = dict(params)
         if own and self._host_buf is not None:
             buf = self._host_buf
-            dev = buf.to(device, non_blocking=True)
+            dev = self._dev_buf if self._dev_buf is not None else buf.to(device, non_blocking=True)
             base = buf.data_ptr()
             for k, v in params.items():
                 if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel():
@@ -352,16 +380,18 @@ class _RandomOp(torch.nn.Module):
             out["batch_prob"] = None  # every sample is transformed: no switch in the launches at all
         return out
 
-    def forward(self, input: torch.Tensor, params: Optional[Mapping[str, Any]] = None) -> torch.Tensor:
+    def forward(self, input: torch.Tensor, params: Optional[Mapping[str, Any]] = None, _own: bool = False) -> torch.Tensor:
         N.require_device(input, "input")
         if input.dim() not in (3, 4):
             raise ValueError(f"expected a (B, C, H, W) or (C, H, W) image tensor, got {tuple(input.shape)}")
         x = input.unsqueeze(0) if input.dim() == 3 else input
-        own = params is None
-        if own:
+        own = params is None or _own  # (_own: the container sampled these through this module's forward_parameters a moment ago)
+        if params is None:
             params = self.forward_parameters(x.shape)
-        self._params = dict(params)
-        out = self._apply(x, self._device_params(self._params, x.device, own))
+        elif not _own:
+            self._st["host_buf"] = None
+        self._st["params"] = dict(params)
+        out = self._apply(x, self._device_params(self._st["params"], x.device, own))
         return out[0] if (input.dim() == 3 and self.keepdim) else out
 
 
@@ -404,33 +434,55 @@ class RandomAffine(_RandomOp):
         self.padding_mode = str(getattr(padding_mode, "name", padding_mode)).lower()
         self.align_corners = bool(align_corners)
         self.fill_value = fill_value
-        self._transform_matrix: Optional[torch.Tensor] = None
+        self._lo = self._span = None
+
+    def _ranges(self):
+        """(lo, span) of the module's draws in the reference's order - angle, scale x (, scale y), translation x, y, shear x, y - as float32 vectors,
+        formed once (``high - low`` in float32, as torch.distributions.Uniform does)."""
+        if getattr(self, "_lo", None) is None:
+            pairs = [self.degrees]
+            if self.scale is not None:
+                pairs.append(self.scale[:2])
+                if self.scale.numel() == 4:
+                    pairs.append(self.scale[2:])
+            if self.translate is not None:
+                pairs += [torch.stack([-self.translate[0], self.translate[0]]), torch.stack([-self.translate[1], self.translate[1]])]
+            if self.shear is not None:
+                pairs += [self.shear[0], self.shear[1]]
+            p = torch.stack(pairs).to(torch.float32)
+            self._lo, self._span = p[:, 0].contiguous(), (p[:, 1] - p[:, 0]).contiguous()
+        return self._lo, self._span
 
     def _sample(self, d: _Draws, shape, params: dict) -> None:
         # random_generator/_2d/affine.py:161-213: angle, scale (x, then y when four numbers were given), translation x, y, shear x, y
         B, H, W = int(shape[0]), int(shape[-2]), int(shape[-1])
-        same = self.same_on_batch
         angle, shx, shy = d.piece(B), d.piece(B), d.piece(B)
         scale, trans, center = d.piece(B, 2), d.piece(B, 2), d.piece(B, 2)
-        d.uniform(self.degrees, B, same, angle)
+        lo, span = self._ranges()
+        v = d.uniforms(lo, span, B, self.same_on_batch)  # (k, B): every draw of the module from ONE call of the generator
+        angle.copy_(v[0])
+        k = 1
         if self.scale is not None:
-            d.uniform(self.scale[:2], B, same, scale[:, 0])
             if self.scale.numel() == 4:
-                d.uniform(self.scale[2:], B, same, scale[:, 1])
+                scale.copy_(v[k:k + 2].t())
+                k += 2
             else:
-                scale[:, 1] = scale[:, 0]
+                scale.copy_(v[k:k + 1].t().expand(B, 2))
+                k += 1
         else:
             scale.fill_(1.0)
         if self.translate is not None:
-            d.uniform(torch.stack([-self.translate[0], self.translate[0]]), B, same, trans[:, 0]).mul_(W)
-            d.uniform(torch.stack([-self.translate[1], self.translate[1]]), B, same, trans[:, 1]).mul_(H)
+            trans.copy_(v[k:k + 2].t())
+            trans[:, 0] *= W
+            trans[:, 1] *= H
+            k += 2
         else:
             trans.zero_()
         center[:, 0] = W / 2.0 - 0.5
         center[:, 1] = H / 2.0 - 0.5
         if self.shear is not None:
-            d.uniform(self.shear[0], B, same, shx)
-            d.uniform(self.shear[1], B, same, shy)
+            shx.copy_(v[k])
+            shy.copy_(v[k + 1])
         else:
             shx.zero_()
             shy.zero_()
@@ -477,11 +529,13 @@ class ColorJitter(_RandomOp):
 
     def _sample(self, d: _Draws, shape, params: dict) -> None:
         # random_generator/_2d/color_jitter.py:97-110: brightness, contrast, HUE, saturation, then the order of the four stages
-        B, same = int(shape[0]), self.same_on_batch
-        params["brightness_factor"] = d.uniform(self.brightness, B, same, d.piece(B))
-        params["contrast_factor"] = d.uniform(self.contrast, B, same, d.piece(B))
-        params["hue_factor"] = d.uniform(self.hue, B, same, d.piece(B))
-        params["saturation_factor"] = d.uniform(self.saturation, B, same, d.piece(B))
+        B = int(shape[0])
+        if getattr(self, "_lo", None) is None:
+            p = torch.stack([self.brightness, self.contrast, self.hue, self.saturation])
+            self._lo, self._span = p[:, 0].contiguous(), (p[:, 1] - p[:, 0]).contiguous()
+        out = d.piece(4, B)
+        out.copy_(d.uniforms(self._lo, self._span, B, self.same_on_batch))
+        params["brightness_factor"], params["contrast_factor"], params["hue_factor"], params["saturation_factor"] = out[0], out[1], out[2], out[3]
         params["order"] = torch.randperm(4, dtype=torch.long)
 
     def _apply(self, x: torch.Tensor, params: dict) -> torch.Tensor:
@@ -540,16 +594,29 @@ class AugmentationSequential(torch.nn.Module):
         self._params: list = []
 
     def forward_parameters(self, batch_shape) -> list:
-        """One ``ParamItem`` per child, sampled in order (a same-size pipeline: every child sees the input's shape)."""
-        return [ParamItem(name, m.forward_parameters(batch_shape)) for name, m in self.named_children()]
+        """One ``ParamItem`` per child, sampled in order (a same-size pipeline: every child sees the input's shape); the draws of ALL children
+        in one host buffer."""
+        B = int(batch_shape[0])
+        children = list(self.named_children())
+        d = _Draws(sum(m._FLOATS_PER_SAMPLE for _, m in children) * B)
+        items = [ParamItem(name, m.forward_parameters(batch_shape, d)) for name, m in children]
+        self._draws = d
+        return items
 
     def forward(self, input: torch.Tensor, params: Optional[Sequence[ParamItem]] = None) -> torch.Tensor:
         children = list(self.named_children())
         if params is not None and len(params) != len(children):
             raise ValueError(f"{len(params)} parameter items for {len(children)} children")
+        own = params is None
+        if own:
+            shape = input.shape if input.dim() == 4 else (1, *input.shape)
+            params = self.forward_parameters(shape)
+            dev = self._draws.buf.to(input.device, non_blocking=True)  # the whole pipeline's draws: ONE copy
+            for _, m in children:
+                m._dev_buf = dev
         out, used = input, []
         for i, (name, m) in enumerate(children):
-            out = m(out, None if params is None else params[i].data)
+            out = m(out, params[i].data, _own=own)
             used.append(ParamItem(name, m._params))
         self._params = used
         return out

@@ -80,7 +80,42 @@ __device__ __forceinline__ void kmc_hue(float& r, float& g, float& b, float shif
     b = (k == 0) ? p : (k == 1) ? p : (k == 2) ? t : (k == 3) ? v : (k == 4) ? v : q;
 }
 
-// applies stages [first, last) to one pixel; `mean` is used by the contrast stage
+// ---- 16-bit storage: the hue round trip WITHIN THE TOLERANCE THE STORAGE TYPE HAS (round 6) ------------------------------------------
+// kmc_hue above is the reference's operation sequence rounding for rounding (two IEEE divisions, three remainders with their exact fmod
+// paths, a 15-way select): ~120 vector instructions of the ~200 a pixel costs, for a result that a bf16 / f16 image then rounds to 8 / 11
+// bits and that BASELINE.json compares at 1e-2 - config 3's colour pass sat on its issue time (58 us of the sequence's 213, 2.6 TB/s).
+// The same function of (r, g, b, shift) with the arithmetic a GPU wants: v_rcp_f32 for the two quotients (1 ulp), hue kept in TURNS so
+// that both reductions are x - floor(x), and the standard branch-free HSV -> RGB  c_n = v - v s clamp(min(k, 4 - k), 0, 1),
+// k = (n + 6 h) mod 6, n = 5 / 3 / 1 for r / g / b.  ~45 instructions; within ~1e-6 of kmc_hue before the storage rounding (a different
+// 16-bit neighbour at ties: tests/test_gpu_color.py compares at the storage type's 1e-2).  fp32 storage keeps kmc_hue.
+#ifndef KMC_FAST16
+#define KMC_FAST16 1
+#endif
+__device__ __forceinline__ float kmc_rcp(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(v);
+#else
+    return 1.0f / v;
+#endif
+}
+__device__ __forceinline__ void kmc_hue_fast(float& r, float& g, float& b, float shift) {
+    const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+    const float delta = mx - mn, v = mx;
+    const float vs = v * (delta * kmc_rcp(mx + 1e-8f));             // v * s
+    const float id = kmc_rcp(delta == 0.0f ? 1.0f : delta);
+    const float rc = mx - r, gc = mx - g, bc = mx - b;
+    float h6 = ((r >= g) && (r >= b)) ? (bc - gc) * id : ((g >= b) ? km_fma(rc - bc, id, 2.0f) : km_fma(gc - rc, id, 4.0f));  // [-1, 5]
+    float ht = km_fma(h6, 1.0f / 6.0f, shift * 0.15915494309189535f);  // hue + shift in turns
+    ht = ht - floorf(ht);                                              // [0, 1)
+    h6 = ht * 6.0f;
+    float k, m;
+    k = h6 + 5.0f; k = k >= 6.0f ? k - 6.0f : k; m = kmc_clamp01(fminf(k, 4.0f - k)); r = km_fma(-vs, m, v);
+    k = h6 + 3.0f; k = k >= 6.0f ? k - 6.0f : k; m = kmc_clamp01(fminf(k, 4.0f - k)); g = km_fma(-vs, m, v);
+    k = h6 + 1.0f; k = k >= 6.0f ? k - 6.0f : k; m = kmc_clamp01(fminf(k, 4.0f - k)); b = km_fma(-vs, m, v);
+}
+
+// applies stages [first, last) to one pixel; `mean` is used by the contrast stage.  FAST: kmc_hue_fast (16-bit storage)
+template <bool FAST = false>
 __device__ __forceinline__ void kmc_apply(float& r, float& g, float& b, const int (&stages)[KMC_MAX_STAGES], int first, int last,
                                           const float (&f)[4], float mean, uint32_t enable_mask) {
     for (int s = first; s < last; ++s) {
@@ -95,7 +130,8 @@ __device__ __forceinline__ void kmc_apply(float& r, float& g, float& b, const in
             const float gr = kmc_gray(r, g, b), a = (1.0f - f[2]) * gr;
             r = kmc_clamp01(a + f[2] * r); g = kmc_clamp01(a + f[2] * g); b = kmc_clamp01(a + f[2] * b);
         } else {
-            kmc_hue(r, g, b, f[3]);
+            if (FAST) kmc_hue_fast(r, g, b, f[3]);
+            else kmc_hue(r, g, b, f[3]);
         }
     }
 }
@@ -163,7 +199,7 @@ __global__ __launch_bounds__(256) void km_color_jitter_kernel(const KmColorArgs<
         }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            kmc_apply(r[q], g[q], bl[q], a.stages, first, last, f, mean, enable_mask);
+            kmc_apply<(KMC_FAST16 && sizeof(T) == 2)>(r[q], g[q], bl[q], a.stages, first, last, f, mean, enable_mask);
             if (MODE == 0) {
                 if (ci > 0) {  // the gray sum is taken of the values the apply pass will read back: the stored ones
                     r[q] = kmc_storage_round<T>(r[q]); g[q] = kmc_storage_round<T>(g[q]); bl[q] = kmc_storage_round<T>(bl[q]);

@@ -81,3 +81,21 @@ def test_replay_and_bf16_and_errors():
         A.RandomAffine(degrees=-3.0)
     with pytest.raises(TypeError):
         A.RandomGaussianBlur((3, 3), (2.0, 1.0))
+
+
+def test_one_call_of_the_generator_is_k_calls():
+    """What the modules' vectorised draws rest on: torch's CPU generator fills a float32 tensor element by element, so one ``torch.rand(k * B)`` is the
+    concatenation of k ``torch.rand(B)`` - the k calls the reference makes - for the sizes of every BASELINE config (and for the single draws of
+    ``same_on_batch``)."""
+    for B in (1, 5, 16, 17, 256, 2048):
+        for k in (2, 6):
+            torch.manual_seed(B + k)
+            a = torch.cat([torch.rand(B) for _ in range(k)])
+            torch.manual_seed(B + k)
+            b = torch.rand(k * B)
+            st = torch.get_rng_state()
+            assert torch.equal(a, b), (B, k)
+            torch.manual_seed(B + k)
+            for _ in range(k):
+                torch.rand(B)
+            assert torch.equal(torch.get_rng_state(), st), (B, k)  # ... and the generator stands at the same place afterwards
