@@ -29,6 +29,8 @@ def lib() -> ctypes.CDLL:
         h.emu_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
         h.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
         h.emu_set_schedule.restype = None
+        h.emu_set_glds.argtypes = [ctypes.c_int]
+        h.emu_set_glds.restype = None
         _lib = h
     return _lib
 
@@ -50,3 +52,8 @@ SCHEDULES = {"forward": 0, "reverse": 1, "random": 2, "lanes": 3}
 def set_schedule(mode: str, seed: int = 1) -> None:
     """Order in which ready work-items resume: 'forward', 'reverse' (waves), 'random' (waves shuffled), 'lanes' (everything shuffled)."""
     lib().emu_set_schedule(SCHEDULES[mode], seed)
+
+
+def set_glds(deferred: bool) -> None:
+    """LDS-DMA model: False = the piece lands at the request (earliest legal), True = at the requesting lane's KM_VMCNT0(), shuffled (latest legal)."""
+    lib().emu_set_glds(1 if deferred else 0)

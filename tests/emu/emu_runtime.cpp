@@ -46,6 +46,34 @@ static unsigned long long g_stat_dead_reads = 0, g_stat_launches = 0, g_stat_blo
 
 static void yield_to_scheduler() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); }
 
+// ---- LDS-DMA: immediate or deferred landing (hip/hip_runtime.h) ----------------------------------------------------------------------
+struct GldsReq { void* dst; const void* src; int bytes; };
+static std::vector<std::vector<GldsReq>> g_glds;  // [work-item] requests in flight
+static int g_glds_mode = -1;                       // 0 immediate, 1 deferred
+static unsigned long long g_glds_rand = 88172645463325252ull, g_stat_glds_unwaited = 0;
+static void glds_init() {
+    if (g_glds_mode >= 0) return;
+    const char* e = getenv("KM_EMU_GLDS");
+    g_glds_mode = (e && e[0] == 'd') ? 1 : 0;
+}
+void glds_issue(void* dst, const void* src, int bytes) {
+    glds_init();
+    if (g_glds_mode == 0) { memcpy(dst, src, (size_t)bytes); return; }
+    if ((size_t)g_cur >= g_glds.size()) g_glds.resize((size_t)g_cur + 1);
+    g_glds[(size_t)g_cur].push_back({dst, src, bytes});
+}
+void glds_wait() {
+    if (g_glds_mode != 1 || (size_t)g_cur >= g_glds.size()) return;
+    std::vector<GldsReq>& q = g_glds[(size_t)g_cur];
+    for (size_t n = q.size(); n > 0; --n) {  // in shuffled order (the pieces of one wave do not overlap: any order is legal)
+        g_glds_rand ^= g_glds_rand << 13; g_glds_rand ^= g_glds_rand >> 7; g_glds_rand ^= g_glds_rand << 17;
+        const size_t k = (size_t)(g_glds_rand % n);
+        memcpy(q[k].dst, q[k].src, (size_t)q[k].bytes);
+        q[k] = q[n - 1];
+    }
+    q.clear();
+}
+
 static void fiber_entry() {
     (*g_body)();
     g_fibers[g_cur].state = DONE;
@@ -146,6 +174,7 @@ static void sched_init() {
     }
 }
 extern "C" void emu_set_schedule(int mode, unsigned long long seed) { g_sched_mode = mode; g_sched_state = seed ? seed : 1; }
+extern "C" void emu_set_glds(int deferred) { g_glds_mode = deferred ? 1 : 0; }
 static unsigned sched_rand(unsigned n) {  // xorshift64*
     g_sched_state ^= g_sched_state >> 12; g_sched_state ^= g_sched_state << 25; g_sched_state ^= g_sched_state >> 27;
     return (unsigned)((g_sched_state * 2685821657736338717ull) >> 33) % n;
@@ -171,6 +200,7 @@ static bool run_block(unsigned nthreads) {
     const unsigned nwaves = (nthreads + 63) / 64;
     g_or_acc = g_or_result = 0;
     std::fill(g_slot_gen.begin(), g_slot_gen.end(), 0u);
+    for (auto& q : g_glds) { g_stat_glds_unwaited += q.size(); q.clear(); }  // (requests of the previous workgroup that nobody waited for: they never land)
     for (;;) {
         bool progressed = false;
         unsigned live = 0;

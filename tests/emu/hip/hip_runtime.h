@@ -129,11 +129,18 @@ inline int emu_cvt_i32_f32(float v) {
 #define KM_LDS_BARRIER() __syncthreads()
 #define KM_SCHED_FENCE() ((void)0)
 #define KM_OPAQUE(v) ((void)0)
-// LDS-DMA (km_common.h KM_GLDS16 / KM_GLDS4): the lane's piece lands at lds_wave_base + lane * size.  On the host the copy is immediate
-// (what the device's vmcnt wait + barrier discipline guarantees is therefore NOT checked here: the -m gpu run does that)
-#define KM_GLDS16(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gsrc), 16)
-#define KM_GLDS4(gsrc, lds_wave_base) memcpy((char*)(lds_wave_base) + 4 * emu::lane_id(), (const void*)(gsrc), 4)
-#define KM_VMCNT0() ((void)0)
+// LDS-DMA (km_common.h KM_GLDS16 / KM_GLDS4): the lane's piece lands at lds_wave_base + lane * size - on the device at SOME time between
+// the request and the wave's `s_waitcnt vmcnt(0)` (KM_VMCNT0).  Two models bracket that (emu_set_glds / KM_EMU_GLDS):
+//   immediate (default)  the copy happens at the request: the earliest the hardware could land it - a request into a buffer that another
+//                        wave is still reading shows as a wrong result;
+//   deferred             the copy happens at the requesting lane's KM_VMCNT0(), in shuffled order, from the source as it is THEN: the latest
+//                        the hardware may land it - a missing wait (or a missing barrier behind it) leaves stale LDS and shows as a wrong result;
+//                        a request that is never waited for never lands.
+// (What neither model checks: that the device's inline assembly is well-formed and that M0-relative LDS addresses above 64 KB work - the -m gpu run.)
+namespace emu { void glds_issue(void* dst, const void* src, int bytes); void glds_wait(); }
+#define KM_GLDS16(gsrc, lds_wave_base) emu::glds_issue((char*)(lds_wave_base) + 16 * emu::lane_id(), (const void*)(gsrc), 16)
+#define KM_GLDS4(gsrc, lds_wave_base) emu::glds_issue((char*)(lds_wave_base) + 4 * emu::lane_id(), (const void*)(gsrc), 4)
+#define KM_VMCNT0() emu::glds_wait()
 #define KM_TID_PINNED 1
 inline int km_tid_pinned() { return (int)threadIdx.x; }
 inline float emu_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }

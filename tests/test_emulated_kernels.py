@@ -80,6 +80,14 @@ def test_emulator_schedules_expose_a_missing_barrier():
     assert h.selftest_handoff(out, 2, 0) == 0
     assert list(out) != in_launch_order, "reversing the wave order must change the result of the racy kernel"
     assert h.selftest_divergent_wave_op(out) != 0
+    # LDS-DMA models: a request lands at once (immediate) or at the requesting lane's KM_VMCNT0 (deferred) - one that is never waited for never lands
+    fo = (ctypes.c_float * 2)()
+    h.emu_set_schedule(0, 1)
+    h.emu_set_glds(0)
+    assert h.selftest_glds(fo) == 0 and list(fo) == [1.0, 1.0]
+    h.emu_set_glds(1)
+    assert h.selftest_glds(fo) == 0 and list(fo) == [1.0, 0.0]
+    h.emu_set_glds(0)
 
 
 @pytest.mark.parametrize("schedule", ["reverse", "random", "lanes"])
@@ -102,6 +110,30 @@ def test_lds_kernels_do_not_depend_on_wave_order(oracle, schedule):
         if schedule != "lanes":  # (its gather rows exchange registers between lanes - wave_shl / wave_shr - which only means something in wave order)
             test_gpu_warp.test_box_forward_is_bit_identical(oracle, 1, torch.float32)  # fill -> barrier -> sample through LDS, three tile attempts per block
     finally:
+        emu_lib.set_schedule("forward")
+
+
+@pytest.mark.parametrize("schedule", ["forward", "reverse"])
+def test_lds_dma_kernels_under_the_latest_legal_landing(oracle, schedule):
+    """The three kernels that fill LDS by LDS-DMA (global_load_lds: one-read backward - the NEXT tile's source tile into the second buffer while the
+    current one is read -, box forward, bicubic forward) with every request landing as LATE as the hardware may land it: at the requesting lane's
+    own `s_waitcnt vmcnt(0)`, in shuffled order (the default model lands it at the request: the earliest).  A missing wait, or a missing barrier
+    between the wait and another wave's read, is stale LDS - a wrong result - here (test_emulator_schedules_expose_a_missing_barrier shows that the model bites)."""
+    import emu_lib
+    import test_gpu_warp
+    import test_gpu_warp_fused as wf
+
+    emu_lib.set_glds(True)
+    emu_lib.set_schedule(schedule, 3)
+    try:
+        wf.test_source_tile_staging_does_not_depend_on_the_address_or_the_tile_shape(oracle, "zeros")
+        wf.test_source_tile_staging_does_not_depend_on_the_address_or_the_tile_shape(oracle, "fill")
+        wf.test_both_gradients_from_one_read_match_the_oracle(oracle, (3, 200, 130, 150, 170), "zeros", 3)
+        wf.test_both_gradients_from_one_read_match_the_oracle(oracle, (2, 128, 192, 128, 192), "fill", 3)
+        test_gpu_warp.test_box_forward_is_bit_identical(oracle, 3, torch.float32)
+        test_gpu_warp.test_bicubic_lds_staged_kernel_is_bit_identical(oracle, 1, torch.float32)
+    finally:
+        emu_lib.set_glds(False)
         emu_lib.set_schedule("forward")
 
 
