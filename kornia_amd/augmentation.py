@@ -368,14 +368,23 @@ class _RandomOp(torch.nn.Module):
         """The parameters as the apply step wants them: this module's own sample crosses to the device as ONE copy of the draw buffer (the
         float tensors of ``params`` are pieces of it); foreign parameters (a replay) go tensor by tensor, as the functions above take them."""
         out = dict(params)
-        if own and self._host_buf is not None:
-            buf = self._host_buf
-            dev = self._dev_buf if self._dev_buf is not None else buf.to(device, non_blocking=True)
+        buf = self._host_buf if own else None
+        dev = self._dev_buf if own else None
+        if buf is None:
+            # a replay: host float tensors that are pieces of ONE allocation (this package's own `_params` are) cross as one copy too
+            fl = [v for v in params.values() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel() and v.device.type == "cpu" and v.is_contiguous()]
+            if len(fl) > 1 and all(v.untyped_storage().data_ptr() == fl[0].untyped_storage().data_ptr() for v in fl):
+                buf = torch.empty(0, dtype=torch.float32).set_(fl[0].untyped_storage())
+                dev = None
+        if buf is not None:
+            if dev is None:
+                dev = buf.to(device, non_blocking=True)
             base = buf.data_ptr()
             for k, v in params.items():
-                if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel():
+                if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel() and v.device.type == "cpu" and v.is_contiguous():
                     off = (v.data_ptr() - base) // 4
-                    out[k] = dev[off:off + v.numel()].view(v.shape)
+                    if 0 <= off and off + v.numel() <= buf.numel():
+                        out[k] = dev[off:off + v.numel()].view(v.shape)
         if self.p >= 1.0 and self.p_batch >= 1.0:
             out["batch_prob"] = None  # every sample is transformed: no switch in the launches at all
         return out
