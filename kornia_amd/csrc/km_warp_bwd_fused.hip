@@ -67,6 +67,11 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #define KMO_PROF_ARGS
 #endif
 
+#ifndef KMO_ABL
+#define KMO_ABL 0  // timing experiments only (wrong results): 1 no matrix-gradient work, 2 no LDS atomics, 4 no per-pixel work; round 6 - what the phases OUTSIDE the
+                   // scatter cost when they are simply gone (the upper bound of overlapping them): 8 no flush, 16 no image-end sums, 32 no barrier B1, 64 no barrier B2,
+                   // 128 no maximum of |grad_out| in the stage (profiles/r06/run6_*)
+#endif
 #ifndef KMO_NT
 #define KMO_NT 1024        // threads per workgroup (one workgroup per CU: 16 waves)
 #endif
@@ -473,9 +478,6 @@ __device__ __forceinline__ void kmo_pix(const KmtPix& q, const float (&go)[CC], 
     const float wy0s = FIXED ? t.wy0 * scale : t.wy0, wy1s = FIXED ? t.wy1 * scale : t.wy1;
     const float w00 = t.wx1 * wy1s, w01 = t.wx0 * wy1s, w10 = t.wx1 * wy0s, w11 = t.wx0 * wy0s;
     float gix = 0.f, giy = 0.f;
-#ifndef KMO_ABL
-#define KMO_ABL 0  // timing experiments only (wrong results): 1 no matrix-gradient work, 2 no LDS atomics, 4 no per-pixel work
-#endif
     const int l00 = (int)(uy * (uint32_t)KMT_TW + ux);
 #define KMO_TAP(pred, OFF, W, SX, WX, SY, WY)                                                        \
     if (pred) {                                                                                       \
@@ -747,6 +749,7 @@ __device__ __forceinline__ void kmo_general_tile(const KmWarpFusedArgs<T>& a, co
 // convert and write the tile, leaving the accumulators zeroed for the next one
 template <typename T, int CC>
 __device__ __forceinline__ void kmo_flush(const KmWarpFusedArgs<T>& a, const KmoTile& d, int* s_acc, bool finite, float inv_scale, bool discard = false) {
+    if (KMO_ABL & 8) return;
     const KmWarpGeom<float>& g = a.g;
     const int tid = threadIdx.x;
     const size_t src_plane = (size_t)g.H * g.W;
@@ -885,7 +888,10 @@ __device__ __forceinline__ void kmo_stage(const KmWarpFusedArgs<T>& a, const Kmo
     for (int s = 0; s < KMO_SLOTS; ++s)
 #pragma unroll
         for (int c = 0; c < CC; ++c) mb = max(mb, __float_as_uint(G[s][c]) & 0x7fffffffu);
-#if KMO_RED_ATOMIC
+#if KMO_ABL & 128
+    { int keep = (int)mb; KM_OPAQUE(keep); }  // (the slots are still consumed here: the compiler's waits for them stay where they are)
+    if (lane == 63 && wave == 0) l.s_red[par] = 0x3f800000u;
+#elif KMO_RED_ATOMIC
     // one word per work item (two, alternating): sixteen partials that every wave reads back become one atomic per wave here and one read
     // after the barrier; the wave's maximum through DPP instead of six LDS round trips.  (All 64 lanes ATOMICALLY on the one word: + 12 %
     // on the whole kernel - same-address lanes serialise; profiles/r04/bwd_fused_per_pixel_variants.txt, run 28.)
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
         KMO_T(2)  // flush
         const bool last_pass = cur.p + 1 >= cur.npass;
         if (wave == 0 && last_pass && (q + 1u) % KMO_RUN == 0u) kmo_fetch_boxes(a, q + 1u, lane, l.s_box);  // (into the half of the ring tile q is not in)
-        KM_LDS_BARRIER();  // B1: source tile, maxima, tables in LDS, accumulators zero (first pass)
+        if (!(KMO_ABL & 32)) KM_LDS_BARRIER();  // B1: source tile, maxima, tables in LDS, accumulators zero (first pass)
         KMO_T(3)  // barrier B1
 
         // ---- the NEXT item: the next pass of this box, or the first pass of the next tile (whose source tile is requested after the
@@ -1070,14 +1076,18 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
             kmo_process<T, CM, ALIGN, CC, true, true, PADX>(m, cur, kc, G, l.s_u4, l.s_v4, l.s_acc, s_src_cur, scale, A, g.w, wn, gout_n, mine, a, nxt, S, s_src_nxt);
         }
         KMO_T(5)  // scatter
-        KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
+        if (!(KMO_ABL & 64)) KM_LDS_BARRIER();  // B2: every contribution of the pass is in the accumulators; the tables, s_red and (last pass) the source tile are free
         KMO_T(6)  // barrier B2
         // (this item's maximum has been read by every wave; the word's next writers - the item after the next - are behind the next B1)
         if (KMO_RED_ATOMIC && tid == 0) l.s_red[item & 1u] = 0u;
 
         if (last_pass) {
             // ---- an image that ends here publishes its matrix-gradient partials ----
-            if (nxt.t < 0 || nxt.b != cur.b) {  // (per (image, group): the groups of an image meet in gmat's atomics)
+            if ((KMO_ABL & 16) && (nxt.t < 0 || nxt.b != cur.b)) {  // (ablation: the partials are consumed - their arithmetic stays - and dropped)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { KM_OPAQUE(A[k]); A[k] = 0.f; }
+            }
+            if (!(KMO_ABL & 16) && (nxt.t < 0 || nxt.b != cur.b)) {  // (per (image, group): the groups of an image meet in gmat's atomics)
                 if (KMO_GM_LDS && CC * KMO_PLANE >= 9 * KMO_NT) {
                     // Nine 64-lane fp64 reductions per wave are 108 ds_bpermute + 54 v_add_f64 for each of the 16 waves - 2 000 cycles per tile on
                     // average (profiles/r03_bwd_phases.txt: "loop tail").  The source tile is dead after the last pass of its tile: the 1024
