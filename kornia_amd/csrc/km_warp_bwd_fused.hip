@@ -110,6 +110,9 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #ifndef KMO_TAB_AHEAD
 #define KMO_TAB_AHEAD 0    // the coordinate-table entries of a slot read one slot ahead of its arithmetic
 #endif
+#ifndef KMO_WALK_COLS
+#define KMO_WALK_COLS 1    // the box is walked with a FIXED column per thread (thread = (row tid / bw, column tid % bw) of a slab of KMO_NT / bw rows; slot s is the pixel s slabs below): see KmoWalk
+#endif
 #ifndef KMO_FENCE_EVERY
 #define KMO_FENCE_EVERY 1  // slots of the scatter between two scheduling fences (1: one pixel at a time)
 #endif
@@ -263,7 +266,11 @@ __device__ __forceinline__ void kmo_describe(const KmWarpFusedArgs<T>& a, int t,
 #endif
     d.nq = (bw > 0 && bh > 0) ? bw * bh : 0;
     d.p = 0;
+#if KMO_WALK_COLS
+    d.npass = d.regular ? max(1, (bh + KMO_SLOTS * max(d.di, 1) - 1) / (KMO_SLOTS * max(d.di, 1))) : 1;  // (a pass = KMO_SLOTS slabs of di rows)
+#else
     d.npass = d.regular ? max(1, (d.nq + KMO_CAP - 1) / KMO_CAP) : 1;  // (a tile of the general launch is ONE item of the persistent loop, whatever its box)
+#endif
     // 16-byte rows of the source tile / of the tile flush
     d.svec = (sizeof(T) == 4) && d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.src & 15) == 0;
     d.fvec = d.TWc == KMT_TW && (g.W & 3) == 0 && ((uintptr_t)a.gsrc & 15) == 0;
@@ -514,28 +521,77 @@ struct KmoConsts {
     float Wm1, Hm1, hW, hH, mx, my;
 };
 
-// Walk of a box as a linear list of pixels, KMO_NT apart: element e = s * KMO_NT + tid sits at (qi, qj) of the box
+// Walk of a box.
+// KMO_WALK_COLS (round 6): thread tid sits at (row tid / bw, column tid % bw) of a SLAB of P = KMO_NT / bw whole rows of the box (threads beyond
+// P * bw idle: 44 of 1 024 on a 70-column box) and slot s is the pixel s slabs further down, in the SAME column.  Nothing of the walk is per-lane
+// arithmetic any more: the column-table entry is read once per tile, the row index and the element offset advance by block-uniform steps (P,
+// P * w), a slot is valid while s P + row < rows of the pass.  The linear list it replaces (element e = s * KMO_NT + tid, both coordinates
+// advanced with carry for the current AND the next tile's box, a 32-bit multiply per request) was 29 of the 151 vector issue slots of a
+// visited pixel; a 70 x 70 box is 5 slabs of 14 rows = 80 wave-slots where the list had 77.  A pass of a box larger than the registers hold
+// is KMO_SLOTS slabs.
+// Otherwise: a linear list of pixels, KMO_NT apart: element e = s * KMO_NT + tid sits at (qi, qj) of the box
 struct KmoWalk {
+#if KMO_WALK_COLS
+    int trow;       // this thread's row in a slab (0x10000 for the idle threads beyond the slab)
+    int nrows;      // rows of this pass (0: nothing to request)
+    int P;          // rows of a slab
+    uint32_t off;   // element offset of this thread's slot-0 pixel in a grad_out plane
+    uint32_t step;  // ... from one slot to the next: P * w
+#else
     int qi, qj, di, dj, bw, nq;
     uint32_t row0;  // element offset of the box's first pixel in a grad_out plane
+#endif
 };
+#if KMO_WALK_COLS
+// rows of pass d.p of a regular tile's box
+__device__ __forceinline__ int kmo_pass_rows(const KmoTile& d) {
+    const int P = max(d.di, 1);
+    return (d.regular && d.nq > 0) ? min((d.i1 - d.i0 + 1) - d.p * KMO_SLOTS * P, KMO_SLOTS * P) : 0;
+}
+#endif
 template <typename T>
 __device__ __forceinline__ void kmo_walk_init(const KmWarpFusedArgs<T>& a, const KmoTile& d, KmoWalk& wk) {
+#if KMO_WALK_COLS
+    const int P = max(d.di, 1);
+    int trow, tcol;
+    kmo_first((int)threadIdx.x, max(d.bw, 1), trow, tcol);
+    wk.P = P;
+    wk.nrows = kmo_pass_rows(d);
+    wk.off = (uint32_t)(d.i0 + d.p * KMO_SLOTS * P + trow) * (uint32_t)a.g.w + (uint32_t)(d.j0 + tcol);
+    wk.trow = trow < P ? trow : 0x10000;
+    wk.step = (uint32_t)P * (uint32_t)a.g.w;
+#else
     wk.bw = max(d.bw, 1);
     wk.nq = d.regular ? min(d.nq - d.p * KMO_CAP, KMO_CAP) : 0;  // pixels of this pass (a tile of the general path loads its pixels itself)
     wk.di = d.di;
     wk.dj = d.dj;
     kmo_first(d.p * KMO_CAP + (int)threadIdx.x, wk.bw, wk.qi, wk.qj);
     wk.row0 = (uint32_t)d.i0 * (uint32_t)a.g.w + (uint32_t)d.j0;
+#endif
+}
+__device__ __forceinline__ void kmo_walk_none(KmoWalk& wk) {  // nothing to request (the end of the sequence, a tile of the general launch)
+#if KMO_WALK_COLS
+    wk.nrows = 0;
+#else
+    wk.nq = 0;
+#endif
 }
 // request slot s of the walk's tile (zeros beyond the end of the box) and advance
 template <typename T, int CC>
 __device__ __forceinline__ void kmo_request_slot(const T* const (&gout_c)[CC], int w, int s, KmoWalk& wk, float (&Gs)[CC]) {
+#if KMO_WALK_COLS
+    (void)w;
+    const bool valid = wk.trow < wk.nrows - s * wk.P;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) Gs[c] = 0.f;
+    if (valid) kmt_load_go<T, CC>(gout_c, wk.off + (uint32_t)s * wk.step, Gs);
+#else
     const bool valid = s * KMO_NT + (int)threadIdx.x < wk.nq;
 #pragma unroll
     for (int c = 0; c < CC; ++c) Gs[c] = 0.f;
     if (valid) kmt_load_go<T, CC>(gout_c, wk.row0 + (uint32_t)wk.qi * (uint32_t)w + (uint32_t)wk.qj, Gs);
     kmt_advance(wk.qi, wk.qj, wk.di, wk.dj, wk.bw);
+#endif
 }
 
 // The pixels a thread holds in registers (regular tiles): element e = s * KMO_NT + tid of the box walked as a linear list.  As soon
@@ -548,6 +604,26 @@ __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& 
                                             float (&S)[CC * KMO_PLANE / KMO_NT], float* s_src_next) {
     const int tid = threadIdx.x;
     const int bw = max(d.bw, 1);
+#if KMO_WALK_COLS
+    static_assert(!KMO_TAB_AHEAD, "KMO_TAB_AHEAD belongs to the linear walk");
+    const int P = max(d.di, 1);
+    const int nrows = kmo_pass_rows(d);  // rows of this pass
+    int trow, tcol;
+    kmo_first(tid, bw, trow, tcol);
+    const int rbase = d.p * KMO_SLOTS * P + trow;  // row-table index of this thread's slot-0 pixel
+    trow = trow < P ? trow : 0x10000;
+    const float4 c0 = s_u4[min(tcol, KMT_BAND_W - 1)];  // (the same column for every slot; a tile of the general launch may be wider than the table: nothing of it is used)
+#pragma unroll
+    for (int s = 0; s < KMO_SLOTS; ++s) {
+        if (mine && s * P < nrows && !(KMO_ABL & 4)) {  // block-uniform
+            const bool valid = trow < nrows - s * P;
+            const float4 r0 = s_v4[valid ? rbase + s * P : 0];
+            KmtPix q;
+            float gdx, gdy;
+            kmt_pix_position_pad<CM, ALIGN, FAST, PADX>(m, kmt_half(c0), kmt_half(r0), valid, k.Wm1, k.hW, k.Hm1, k.hH, (uint32_t)d.X0, (uint32_t)d.Y0, a.g.W, a.g.H, q, gdx, gdy);
+            kmo_pix<CM, CC, FAST, FIXED>(q, G[s], s_acc, s_src, scale, (uint32_t)d.TWc, (uint32_t)d.THc, c0.w, r0.w, PADX ? k.mx * gdx : k.mx, PADX ? k.my * gdy : k.my, A);
+        }
+#else
     const int di = d.di, dj = d.dj;
     const int nqp = min(d.nq - d.p * KMO_CAP, KMO_CAP);  // pixels of this pass
     int qi, qj;
@@ -589,6 +665,7 @@ __device__ __forceinline__ void kmo_process(const float (&m)[9], const KmoTile& 
             kmt_advance(qi, qj, di, dj, bw);
 #endif
         }
+#endif
         kmo_request_slot<T, CC>(gout_n, w, s, wn, G[s]);
         // the next tile's source tile is requested here, not before the loop: registers that are live across the whole loop get
         // moved by the register allocator at its entry, and a move of a register with a load in flight is a wait for that load
@@ -955,7 +1032,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
             if constexpr (DMA) kmo_dma_src<T, CC>(a, cur, l.s_src);  // (tile q uses source buffer q & 1)
             else kmo_issue_src<T, CC>(a, cur, S);
         } else {
-            w0.nq = 0;
+            kmo_walk_none(w0);
         }
 #pragma unroll
         for (int s = 0; s < KMO_SLOTS; ++s) kmo_request_slot<T, CC>(gout_c, g.w, s, w0, G[s]);
@@ -1023,7 +1100,7 @@ __global__ __launch_bounds__(KMO_NT, KMO_WG_PER_CU * KMO_NT / 256) void km_warp_
 #pragma unroll
             for (int c = 0; c < CC; ++c) gout_n[c] = a.gout + ((size_t)nxt.plane0 + (size_t)c) * dst_plane;
         } else {
-            wn.nq = 0;  // (the end of the sequence, or a tile of the general launch: nothing to request)
+            kmo_walk_none(wn);  // (the end of the sequence, or a tile of the general launch: nothing to request)
         }
         KMO_T(12)  // description: walk of the next box, plane pointers
         // matrix-gradient partials of the image finished before this tile
