@@ -33,7 +33,7 @@ HIPCC_FLAGS = [
 
 
 # per-file additions to HIPCC_FLAGS (the reason is in the header of each file)
-FILE_FLAGS = {"km_warp_cubic.hip": ["-fno-slp-vectorize"], "km_warp_bwd_fused.hip": ["-fno-slp-vectorize"], "km_warp_blur.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"km_warp_cubic.hip": ["-fno-slp-vectorize"], "km_warp_gm_box.hip": ["-fno-slp-vectorize"], "km_warp_bwd_fused.hip": ["-fno-slp-vectorize"], "km_warp_blur.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

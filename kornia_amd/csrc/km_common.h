@@ -86,6 +86,21 @@ __device__ __forceinline__ uint32_t km_wave_umax_last(uint32_t v) {
 #undef KM_UMAX_STEP
     return (uint32_t)x;
 }
+// Sum of an fp64 value over the wave, valid in LANE 63 only: the same ladder on the two halves of the value (a lane without a source, a row
+// outside the step's row mask adds 0.0) - 12 DPP moves and 6 fp64 adds, no LDS traffic, where a __shfl_down ladder is 12 dependent
+// ds_bpermute round trips (nine such sums per wave were 18 % of the matrix-gradient kernel: profiles/r06/run13_*).  All 64 lanes must be active.
+__device__ __forceinline__ double km_wave_sum_last(double v) {
+#define KM_DSUM_STEP(ctrl, rows)                                                                                  \
+    {                                                                                                             \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rows, 0xf, false);                \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rows, 0xf, false);                \
+        v += __hiloint2double(hi_, lo_);                                                                          \
+    }
+    KM_DSUM_STEP(0x111, 0xf) KM_DSUM_STEP(0x112, 0xf) KM_DSUM_STEP(0x114, 0xf) KM_DSUM_STEP(0x118, 0xf)
+    KM_DSUM_STEP(0x142, 0xa) KM_DSUM_STEP(0x143, 0xc)
+#undef KM_DSUM_STEP
+    return v;
+}
 #endif
 
 // 4 x 4 transpose inside a quad of lanes: lane q (= lane & 3) enters with a[r] = element (row r, column q) of a 4 x 4 block and leaves with
@@ -379,7 +394,7 @@ uint32_t km_traversal_next(hipStream_t s);
 struct KmConfig {
     int traversal_fixed;    // KM_TRAVERSAL=fixed
     int warp_fwd_algo;      // KM_WARP_FWD_ALGO: 0 default, 1 generic, 3 box (km_warp_fwd_box_kernel), 4 rows (the gather kernel)
-    int warp_gm_algo;       // KM_WARP_GM_ALGO: 0 default, 1 generic, 2 lds
+    int warp_gm_algo;       // KM_WARP_GM_ALGO: 0 default (box form where it applies), 1 generic, 2 lds, 3 rows (the gather kernel)
     int warp_bwd_generic;   // KM_WARP_BWD_ALGO=generic
     int warp_bwd_fused;     // KM_WARP_BWD_FUSED=0 turns the one-read backward off (two launches)
     int sep_lds;            // KM_SEP_ALGO=lds

@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void km_filter2d_tapgrad_reg_kernel(const KmF2
     for (int p = 0; p < K; ++p)
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-            const double sm = km_wave_sum((double)acc[p][q]);
-            if (lane == 0) red[wave][p * K + q] = sm;
+            const double sm = km_wave_sum_last((double)acc[p][q]);  // (DPP ladder: valid in lane 63; every thread of the block is here)
+            if (lane == 63) red[wave][p * K + q] = sm;
         }
     __syncthreads();
     if (threadIdx.x < K * K) {

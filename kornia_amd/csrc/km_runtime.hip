@@ -36,7 +36,8 @@ static void km_config_init() {
     c.traversal_fixed = km_env_first("KM_TRAVERSAL", 'f');
     c.warp_fwd_algo = km_env_first("KM_WARP_FWD_ALGO", 'g');        // 1 generic, 3 box, 4 rows (the gather kernel)
     if (!c.warp_fwd_algo) c.warp_fwd_algo = km_env_first("KM_WARP_FWD_ALGO", 'b') ? 3 : (km_env_first("KM_WARP_FWD_ALGO", 'r') ? 4 : 0);
-    c.warp_gm_algo = km_env_first("KM_WARP_GM_ALGO", 'g', 'l');     // 1 generic, 2 lds
+    c.warp_gm_algo = km_env_first("KM_WARP_GM_ALGO", 'g', 'l');     // 1 generic, 2 lds, 3 rows (the gather kernel where the box form would run)
+    if (!c.warp_gm_algo && km_env_first("KM_WARP_GM_ALGO", 'r')) c.warp_gm_algo = 3;
     c.warp_bwd_generic = km_env_first("KM_WARP_BWD_ALGO", 'g');
     c.warp_bwd_fused = km_env_first("KM_WARP_BWD_FUSED", '0') ? 0 : 1;
     c.sep_lds = km_env_first("KM_SEP_ALGO", 'l');

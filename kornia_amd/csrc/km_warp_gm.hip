@@ -209,6 +209,9 @@ static int kmg_launch(const KmWarpGmArgs<T>& a, hipStream_t s) {
     return km_check_launch("km_warp2d_bwd(matrix gradient)");
 }
 
+// the box form (km_warp_gm_box.hip): launches and returns 1 when it takes the case, 0 otherwise
+int km_warp_gm_box_try(const void* args, int coord_mode, hipStream_t s);
+
 template <typename T>
 static int kmg_run(const void* gout, const void* src, const void* mat, double* gmat, int B, int C, int H, int W, int h, int w, int B_M,
                    int coord_mode, int norm_coords, int pad, int align, const void* fill, hipStream_t s) {
@@ -223,6 +226,9 @@ static int kmg_run(const void* gout, const void* src, const void* mat, double* g
     a.nblocks = (uint32_t)nb;
     if (nb == 0) return 0;
     a.reverse = km_traversal_next(s);
+    if constexpr (sizeof(T) == 4) {  // fp32 storage, zeros padding, RGB / grey: the box form unless KM_WARP_GM_ALGO says otherwise
+        if (km_config().warp_gm_algo == 0 && km_warp_gm_box_try(&a, coord_mode, s)) return km_check_launch("km_warp2d_bwd(matrix gradient, box)");
+    }
     switch (coord_mode) {
         case KM_COORD_PERSPECTIVE: return kmg_launch<T, KM_COORD_PERSPECTIVE>(a, s);
         case KM_COORD_AFFINE: return kmg_launch<T, KM_COORD_AFFINE>(a, s);

@@ -191,8 +191,8 @@ __device__ __forceinline__ void kmg_block_reduce(const float (&S)[3], const floa
     if (CM == KM_COORD_AFFINE) gm[6] = gm[7] = gm[8] = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        const double s = km_wave_sum((double)gm[k]);
-        if (lane == 0) red[wave][k] = s;
+        const double s = km_wave_sum_last((double)gm[k]);  // (DPP: valid in lane 63)
+        if (lane == 63) red[wave][k] = s;
     }
     __syncthreads();
     if (tid < 9) {

@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void km_warp_loss_kernel(const KmWarpLossArgs<
     if (CM == KM_COORD_AFFINE) out[8] = out[9] = out[10] = 0;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-        const double s = km_wave_sum((double)out[k]);
-        if (lane == 0) red[wave][k] = s;
+        const double s = km_wave_sum_last((double)out[k]);  // (DPP ladder: valid in lane 63; every thread of the block is here)
+        if (lane == 63) red[wave][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < 11) {

@@ -1,4 +1,5 @@
-"""The matrix gradient alone (grad wrt H / M only: km_warp_gm_kernel, or the LDS-staged km_warp_gm_lds_kernel under warp_gm_algo = 2) of one
+"""The matrix gradient alone (grad wrt H / M only: the box form km_warp_gm_box_kernel by default since round 6, the gather kernel km_warp_gm_kernel
+under warp_gm_algo = 3, the first LDS-staged km_warp_gm_lds_kernel under warp_gm_algo = 2) of one
 library (KORNIA_AMD_LIB): config 5's shape through homography_warp, config 2's through warp_perspective.  Prints the time of both kernels and
 their relative difference.   python profiles/time_gm_ab.py [iters]"""
 import os, sys
@@ -23,13 +24,13 @@ for name, B, S, homog in (("cfg5 128x3x256^2 homography_warp", 128, 256, True), 
         M = bench.flagship_homographies(B, S, S, g).to(dev).requires_grad_()
         y = T.warp_perspective(x, M, (S, S))
     res, grads = {}, {}
-    for algo, tag in ((0, "gather"), (2, "lds")):
+    for algo, tag in ((3, "gather"), (2, "lds"), (0, "box")):
         N.lib().km_config_set(b"warp_gm_algo", algo)
         fn = lambda: torch.autograd.grad(y, M, go, retain_graph=True)
         res[tag] = min(bench.event_time_ms(fn, iters) for _ in range(3))
         grads[tag] = fn()[0].double()
     N.lib().km_config_set(b"warp_gm_algo", 0)
-    rel = ((grads["gather"] - grads["lds"]).abs().max() / grads["gather"].abs().max()).item()
-    out.append(f"{name}: gather {res['gather'] * 1e3:.1f} us  lds {res['lds'] * 1e3:.1f} us  rel diff {rel:.1e}")
+    rel = ((grads["gather"] - grads["box"]).abs().max() / grads["gather"].abs().max()).item()
+    out.append(f"{name}: gather {res['gather'] * 1e3:.1f} us  lds {res['lds'] * 1e3:.1f} us  box {res['box'] * 1e3:.1f} us  rel diff box / gather {rel:.1e}")
     del x, go, y, M
 print(f"lib={os.path.basename(os.environ.get('KORNIA_AMD_LIB', 'default'))}  " + "   ".join(out), flush=True)

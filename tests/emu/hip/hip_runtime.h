@@ -223,6 +223,10 @@ inline uint32_t km_wave_umax_last(uint32_t v) {  // (km_common.h: valid in lane 
     for (unsigned off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_down(v, off, 64); v = o > v ? o : v; }
     return __shfl(v, 0, 64);
 }
+inline double km_wave_sum_last(double v) {  // (km_common.h: valid in lane 63; here every lane gets the sum)
+    for (unsigned off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return __shfl(v, 0, 64);
+}
 inline int emu_readfirstlane(int v) {
     bool ok = false;
     return (int)(uint32_t)emu::wave_exchange((uint64_t)(uint32_t)v, -1, &ok);

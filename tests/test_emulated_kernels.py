@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu
 
 # GPU test modules whose cases are small enough for the emulator (full-size configs and HIP-graph capture stay
 # device-only)
-MODULES = os.environ.get("KM_EMU_MODULES", "test_gpu_golden test_gpu_aug_modules test_gpu_config_parity test_gpu_warp test_gpu_warp_fused test_gpu_warp_blur test_gpu_augmentation test_gpu_filters test_gpu_edge_cases test_gpu_grid_sample test_gpu_color test_gpu_fuzz test_gpu_pyramid test_zz_gpu_registration test_zz_gpu_canny test_zz_gpu_fuzz_pyramid test_zz_gpu_nonfinite_paths").split()
+MODULES = os.environ.get("KM_EMU_MODULES", "test_gpu_golden test_gpu_aug_modules test_gpu_config_parity test_gpu_warp test_gpu_warp_fused test_gpu_warp_gm_box test_gpu_warp_blur test_gpu_augmentation test_gpu_filters test_gpu_edge_cases test_gpu_grid_sample test_gpu_color test_gpu_fuzz test_gpu_pyramid test_zz_gpu_registration test_zz_gpu_canny test_zz_gpu_fuzz_pyramid test_zz_gpu_nonfinite_paths").split()
 # cases that are about the device itself, not about kernel arithmetic
 SKIP = {
     ("test_gpu_warp", "test_identity_is_exact_and_errors"),      # asserts that host tensors are refused
