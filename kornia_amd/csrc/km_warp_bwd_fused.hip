@@ -113,6 +113,9 @@ __device__ unsigned long long kmo_prof_rt[512 * 4];  // per worker: start, end o
 #ifndef KMO_WALK_COLS
 #define KMO_WALK_COLS 1    // the box is walked with a FIXED column per thread (thread = (row tid / bw, column tid % bw) of a slab of KMO_NT / bw rows; slot s is the pixel s slabs below): see KmoWalk
 #endif
+#ifndef KMO_READS_FIRST
+#define KMO_READS_FIRST 1  // 1: tap by tap, a tap's three source reads in front of its three atomics (step 1.4395 -> 1.4364 ms, op 0.554 -> 0.545: profiles/r06/run18_*); 0: interleaved atomic, read, atomic, read, ...; 2: ALL twelve reads of a pixel in front of all its atomics, unconditional - measured 9 % SLOWER (op 0.593 against 0.545, run19: every pixel then issues the reads of taps it does not own)
+#endif
 #ifndef KMO_FENCE_EVERY
 #define KMO_FENCE_EVERY 1  // slots of the scatter between two scheduling fences (1: one pixel at a time)
 #endif
@@ -486,6 +489,64 @@ __device__ __forceinline__ void kmo_pix(const KmtPix& q, const float (&go)[CC], 
     const float w00 = t.wx1 * wy1s, w01 = t.wx0 * wy1s, w10 = t.wx1 * wy0s, w11 = t.wx0 * wy0s;
     float gix = 0.f, giy = 0.f;
     const int l00 = (int)(uy * (uint32_t)KMT_TW + ux);
+#if KMO_READS_FIRST == 2
+    if (FIXED) {
+        // ALL twelve source reads of the pixel in front of ALL its atomics, unconditional (a tap another tile owns reads the plane's first cell and
+        // its product is dropped): LDS operations of a wave complete in order, so the pixel's critical path - position -> source values -> terms -
+        // waits for ONE round trip, not for four that each queue behind the previous tap's atomics.  The sums are the same fma chains in the same
+        // order (a dropped tap adds +-w * 0 = 0 to a finite sum: FIXED tiles have finite positions).
+        const int b00 = t00 ? l00 : 0, b01 = t01 ? l00 : -1, b10 = t10 ? l00 : -KMT_TW, b11 = t11 ? l00 : -(KMT_TW + 1);
+        float sv_[4][CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            sv_[0][c] = (KMO_ABL & 1) ? 0.f : s_src[b00 + c * KMO_PLANE];
+            sv_[1][c] = (KMO_ABL & 1) ? 0.f : s_src[b01 + c * KMO_PLANE + 1];
+            sv_[2][c] = (KMO_ABL & 1) ? 0.f : s_src[b10 + c * KMO_PLANE + KMT_TW];
+            sv_[3][c] = (KMO_ABL & 1) ? 0.f : s_src[b11 + c * KMO_PLANE + KMT_TW + 1];
+        }
+#define KMO_TAP_ADD(pred, OFF, W)                                                                                     \
+        if ((pred) && !(KMO_ABL & 2)) {                                                                               \
+            _Pragma("unroll") for (int c = 0; c < CC; ++c) atomicAdd(s_acc + l00 + c * KMO_PLANE + (OFF), kmt_quant((W) * go[c])); \
+        }
+        KMO_TAP_ADD(t00, 0, w00)
+        KMO_TAP_ADD(t01, 1, w01)
+        KMO_TAP_ADD(t10, KMT_TW, w10)
+        KMO_TAP_ADD(t11, KMT_TW + 1, w11)
+#undef KMO_TAP_ADD
+        float dot_[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) d = (c == 0) ? go[c] * sv_[k][c] : km_fma(go[c], sv_[k][c], d);
+            dot_[k] = d;
+        }
+        dot_[0] = t00 ? dot_[0] : 0.f; dot_[1] = t01 ? dot_[1] : 0.f; dot_[2] = t10 ? dot_[2] : 0.f; dot_[3] = t11 ? dot_[3] : 0.f;
+        gix = km_fma(-t.wy1, dot_[0], gix); giy = km_fma(-t.wx1, dot_[0], giy);
+        gix = km_fma(+t.wy1, dot_[1], gix); giy = km_fma(-t.wx0, dot_[1], giy);
+        gix = km_fma(-t.wy0, dot_[2], gix); giy = km_fma(+t.wx1, dot_[2], giy);
+        gix = km_fma(+t.wy0, dot_[3], gix); giy = km_fma(+t.wx0, dot_[3], giy);
+    } else {
+#endif
+#if KMO_READS_FIRST
+    // the tap's source values are REQUESTED IN FRONT of its atomics: LDS operations of a wave complete in order, so a read queued behind the
+    // atomics waits for them as well - and the wait for the reads is on the wave's critical path (position -> taps -> terms), the atomics are not
+#define KMO_TAP(pred, OFF, W, SX, WX, SY, WY)                                                        \
+    if (pred) {                                                                                       \
+        float sv_[CC];                                                                                \
+        _Pragma("unroll") for (int c = 0; c < CC; ++c) sv_[c] = (KMO_ABL & 1) ? 0.f : s_src[l00 + c * KMO_PLANE + (OFF)]; \
+        _Pragma("unroll") for (int c = 0; c < CC; ++c) {                                              \
+            if (!(KMO_ABL & 2)) {                                                                     \
+                if (FIXED) atomicAdd(s_acc + l00 + c * KMO_PLANE + (OFF), kmt_quant((W) * go[c]));    \
+                else atomicAdd((float*)s_acc + l00 + c * KMO_PLANE + (OFF), (W) * go[c]);             \
+            }                                                                                         \
+        }                                                                                             \
+        float dot = 0.f;                                                                              \
+        _Pragma("unroll") for (int c = 0; c < CC; ++c) dot = (c == 0) ? go[c] * sv_[c] : km_fma(go[c], sv_[c], dot); \
+        gix = km_fma(SX (WX), dot, gix);                                                              \
+        giy = km_fma(SY (WY), dot, giy);                                                              \
+    }
+#else
 #define KMO_TAP(pred, OFF, W, SX, WX, SY, WY)                                                        \
     if (pred) {                                                                                       \
         float dot = 0.f;                                                                              \
@@ -502,11 +563,15 @@ __device__ __forceinline__ void kmo_pix(const KmtPix& q, const float (&go)[CC], 
         gix = km_fma(SX (WX), dot, gix);                                                              \
         giy = km_fma(SY (WY), dot, giy);                                                              \
     }
+#endif
     KMO_TAP(t00, 0, w00, -, t.wy1, -, t.wx1)
     KMO_TAP(t01, 1, w01, +, t.wy1, -, t.wx0)
     KMO_TAP(t10, KMT_TW, w10, -, t.wy0, +, t.wx1)
     KMO_TAP(t11, KMT_TW + 1, w11, +, t.wy0, +, t.wx0)
 #undef KMO_TAP
+#if KMO_READS_FIRST == 2
+    }
+#endif
     // this tile's share of the pixel's terms (zero when it owns none of the taps: no 0 * inf from a degenerate position)
     const bool any = t00 | t01 | t10 | t11;
     float ax, ay, az;
