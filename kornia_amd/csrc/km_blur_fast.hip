@@ -100,8 +100,11 @@ __device__ __forceinline__ void kmb_adjoint_taps(const float (&k)[K], int p, int
     }
 }
 
+#ifndef KMB_BWD_WAVES
+#define KMB_BWD_WAVES 1   // minimum waves per SIMD asked of the adjoint's register allocation (8: at most 64 registers)
+#endif
 template <typename T, int K, bool BWD, int ROWS = KMB_ROWS>
-__global__ __launch_bounds__(256) void km_blur_reg_kernel(const KmBlurArgs<T> a) {
+__global__ __launch_bounds__(256, (BWD ? KMB_BWD_WAVES : 1)) void km_blur_reg_kernel(const KmBlurArgs<T> a) {
     constexpr int L = (K - 1) / 2, R = K - 1 - L;
     uint32_t bid = km_xcd_remap(blockIdx.x, a.nblocks, a.reverse);
     const uint32_t tbx = bid % a.bx;
