@@ -26,3 +26,4 @@ with torch.no_grad():
     for _ in range(300): aug(x)
     pr.disable(); torch.cuda.synchronize()
     st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(40)
