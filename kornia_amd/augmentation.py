@@ -277,7 +277,9 @@ class _Draws:
         n = 1
         for v in shape:
             n *= int(v)
-        out = self.buf[self.k:self.k + n].view(*shape)
+        out = self.buf[self.k:self.k + n]
+        if len(shape) > 1:
+            out = out.view(*shape)
         self.k += n
         return out
 
@@ -342,10 +344,9 @@ class _RandomOp(torch.nn.Module):
             gate = float((torch.rand(1) < self.p_batch).item())
         elif self.p_batch <= 0.0:
             gate = 0.0
-        if self.p >= 1.0:
-            e = torch.ones(B)
-        elif self.p <= 0.0:
-            e = torch.zeros(B)
+        if self.p >= 1.0 or self.p <= 0.0:  # (certain outcomes: one fill of the piece, no draw)
+            out.fill_(gate if self.p >= 1.0 else 0.0)
+            return out
         elif self.same_on_batch:
             e = (torch.rand(1) < self.p).to(torch.float32).expand(B)
         else:
@@ -360,7 +361,11 @@ class _RandomOp(torch.nn.Module):
         d = draws if draws is not None else _Draws(self._FLOATS_PER_SAMPLE * B)
         params: dict = {"batch_prob": self._batch_prob(B, d.piece(B))}
         self._sample(d, batch_shape, params)
-        params["forward_input_shape"] = torch.tensor(tuple(int(v) for v in batch_shape), dtype=torch.long)
+        shp = tuple(int(v) for v in batch_shape)
+        st = self._st.get("shape_t")
+        if st is None or st[0] != shp:  # (the same small tensor for every call at this shape: torch.tensor(...) is 4 us a time)
+            st = self._st["shape_t"] = (shp, torch.tensor(shp, dtype=torch.long))
+        params["forward_input_shape"] = st[1]
         self._st["host_buf"], self._st["dev_buf"] = d.buf, None
         return params
 
@@ -380,11 +385,30 @@ class _RandomOp(torch.nn.Module):
             if dev is None:
                 dev = buf.to(device, non_blocking=True)
             base = buf.data_ptr()
-            for k, v in params.items():
-                if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel() and v.device.type == "cpu" and v.is_contiguous():
-                    off = (v.data_ptr() - base) // 4
-                    if 0 <= off and off + v.numel() <= buf.numel():
-                        out[k] = dev[off:off + v.numel()].view(v.shape)
+            # where the float tensors of `params` sit in the buffer: the same for every call of this module at this batch size (the pieces are
+            # handed out in a fixed order) - found once, checked by (key, address offset) since, and each device-side view made by ONE as_strided
+            # (a slice + a view per tensor were 30 us of a call whose host share bounds it: profiles/r06/run20_*)
+            lay = self._st.get("layout") if own else None
+            if lay is not None and (lay[0] != buf.numel() or len(lay[1]) > len(params)):
+                lay = None
+            if lay is not None:
+                for k, off, shape, strides in lay[1]:
+                    v = params.get(k)
+                    if v is None or v.data_ptr() - base != 4 * off or v.shape != shape:
+                        lay = None
+                        break
+            if lay is None:
+                found = []
+                for k, v in params.items():
+                    if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel() and v.device.type == "cpu" and v.is_contiguous():
+                        off = (v.data_ptr() - base) // 4
+                        if 0 <= off and off + v.numel() <= buf.numel():
+                            found.append((k, off, v.shape, v.stride()))
+                lay = (buf.numel(), found)
+                if own:
+                    self._st["layout"] = lay
+            for k, off, shape, strides in lay[1]:
+                out[k] = dev.as_strided(shape, strides, off)
         if self.p >= 1.0 and self.p_batch >= 1.0:
             out["batch_prob"] = None  # every sample is transformed: no switch in the launches at all
         return out
@@ -468,6 +492,9 @@ class RandomAffine(_RandomOp):
         angle, shx, shy = d.piece(B), d.piece(B), d.piece(B)
         scale, trans, center = d.piece(B, 2), d.piece(B, 2), d.piece(B, 2)
         lo, span = self._ranges()
+        geo = self._st.get("geo")
+        if geo is None or geo[2] != (H, W):  # ((W, H) and the centre (W / 2 - 0.5, H / 2 - 0.5) as float32 rows, formed once per image size)
+            geo = self._st["geo"] = (torch.tensor([float(W), float(H)], dtype=torch.float32), torch.tensor([W / 2.0 - 0.5, H / 2.0 - 0.5], dtype=torch.float32), (H, W))
         v = d.uniforms(lo, span, B, self.same_on_batch)  # (k, B): every draw of the module from ONE call of the generator
         angle.copy_(v[0])
         k = 1
@@ -482,13 +509,11 @@ class RandomAffine(_RandomOp):
             scale.fill_(1.0)
         if self.translate is not None:
             trans.copy_(v[k:k + 2].t())
-            trans[:, 0] *= W
-            trans[:, 1] *= H
+            trans.mul_(geo[0])  # (x by W, y by H: the same float32 products as two column-wise multiplications)
             k += 2
         else:
             trans.zero_()
-        center[:, 0] = W / 2.0 - 0.5
-        center[:, 1] = H / 2.0 - 0.5
+        center.copy_(geo[1])
         if self.shear is not None:
             shx.copy_(v[k])
             shy.copy_(v[k + 1])
@@ -600,20 +625,23 @@ class AugmentationSequential(torch.nn.Module):
             if keepdim is not None:
                 m.keepdim = bool(keepdim)
             self.add_module(f"{type(m).__name__}_{i}", m)
-        self._params: list = []
+        # (per-call state as plain attributes: torch.nn.Module.__setattr__ costs ~5 us per assignment; the children are fixed after construction)
+        object.__setattr__(self, "_params", [])
+        object.__setattr__(self, "_draws", None)
+        object.__setattr__(self, "_kids", list(self.named_children()))
 
     def forward_parameters(self, batch_shape) -> list:
         """One ``ParamItem`` per child, sampled in order (a same-size pipeline: every child sees the input's shape); the draws of ALL children
         in one host buffer."""
         B = int(batch_shape[0])
-        children = list(self.named_children())
+        children = self._kids
         d = _Draws(sum(m._FLOATS_PER_SAMPLE for _, m in children) * B)
         items = [ParamItem(name, m.forward_parameters(batch_shape, d)) for name, m in children]
-        self._draws = d
+        object.__setattr__(self, "_draws", d)
         return items
 
     def forward(self, input: torch.Tensor, params: Optional[Sequence[ParamItem]] = None) -> torch.Tensor:
-        children = list(self.named_children())
+        children = self._kids
         if params is not None and len(params) != len(children):
             raise ValueError(f"{len(params)} parameter items for {len(children)} children")
         own = params is None
@@ -627,5 +655,5 @@ class AugmentationSequential(torch.nn.Module):
         for i, (name, m) in enumerate(children):
             out = m(out, params[i].data, _own=own)
             used.append(ParamItem(name, m._params))
-        self._params = used
+        object.__setattr__(self, "_params", used)
         return out
