@@ -40,7 +40,10 @@ __all__ = ["AugmentationSequential", "ColorJitter", "ParamItem", "RandomAffine",
 
 
 def _p(params: Mapping[str, Any], key: str, device) -> torch.Tensor:
-    return torch.as_tensor(params[key], dtype=torch.float32).to(device=device, dtype=torch.float32)
+    v = params[key]
+    if type(v) is torch.Tensor and v.dtype is torch.float32 and v.device == device:  # (the modules' own device views: nothing to convert)
+        return v
+    return torch.as_tensor(v, dtype=torch.float32).to(device=device, dtype=torch.float32)
 
 
 def _apply_mask(params: Mapping[str, Any], device) -> Optional[torch.Tensor]:
@@ -54,7 +57,9 @@ def _prob(params: Mapping[str, Any], device, B: int) -> Optional[torch.Tensor]:
     """``batch_prob`` as a contiguous (B,) float32 device tensor for the parameter kernels (which threshold it), or None."""
     if "batch_prob" not in params or params["batch_prob"] is None:
         return None
-    p = torch.as_tensor(params["batch_prob"]).to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    p = params["batch_prob"]
+    if not (type(p) is torch.Tensor and p.dtype is torch.float32 and p.device == device and p.dim() == 1 and p.is_contiguous()):
+        p = torch.as_tensor(p).to(device=device, dtype=torch.float32).reshape(-1).contiguous()
     if p.numel() != B:
         raise ValueError(f"batch_prob has {p.numel()} entries, expected the batch size {B}")
     return p
