@@ -393,7 +393,8 @@ class _RandomOp(torch.nn.Module):
             # where the float tensors of `params` sit in the buffer: the same for every call of this module at this batch size (the pieces are
             # handed out in a fixed order) - found once, checked by (key, address offset) since, and each device-side view made by ONE as_strided
             # (a slice + a view per tensor were 30 us of a call whose host share bounds it: profiles/r06/run20_*)
-            lay = self._st.get("layout") if own else None
+            lkey = "layout" if own else "layout_replay"
+            lay = self._st.get(lkey)
             if lay is not None and (lay[0] != buf.numel() or len(lay[1]) > len(params)):
                 lay = None
             if lay is not None:
@@ -409,9 +410,7 @@ class _RandomOp(torch.nn.Module):
                         off = (v.data_ptr() - base) // 4
                         if 0 <= off and off + v.numel() <= buf.numel():
                             found.append((k, off, v.shape, v.stride()))
-                lay = (buf.numel(), found)
-                if own:
-                    self._st["layout"] = lay
+                lay = self._st[lkey] = (buf.numel(), found)
             for k, off, shape, strides in lay[1]:
                 out[k] = dev.as_strided(shape, strides, off)
         if self.p >= 1.0 and self.p_batch >= 1.0:
