@@ -51,27 +51,34 @@ def _factor_column(f: Factor, B: int, device, neutral: float) -> torch.Tensor:
     return f
 
 
+def _color_launch(x: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor], stages: tuple,
+                  gray_ws: Optional[torch.Tensor] = None):
+    """The forward launch of the fused colour kernel: ``(out, x, params, gray_sum)`` (the contiguous operands it read, for a backward)."""
+    B, _, H, W = x.shape
+    dev = x.device
+    x = x.contiguous()
+    params = params.contiguous()
+    out = torch.empty_like(x)
+    # (gray_ws: a (B,) float64 workspace that the launch which made `params` has ALREADY zeroed - km_color_params_ws_fwd - instead of a fill launch here)
+    gray_sum = (gray_ws if gray_ws is not None else torch.zeros(B, device=dev, dtype=torch.float64)) if CONTRAST in stages else None
+    arr = (ctypes.c_int * max(len(stages), 1))(*stages)
+    with N.device_guard(dev):
+        if apply is None:
+            N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
+                                                N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
+        else:
+            N.check(N.lib().km_color_jitter_fwd_masked(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), apply.data_ptr(), arr,
+                                                       len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd_masked")
+    return out, x, params, gray_sum
+
+
 class _ColorJitterFunction(torch.autograd.Function):
     """``km_color_jitter_fwd(_masked)`` / ``km_color_jitter_bwd``: gradients wrt the image and the (B,4) parameter table."""
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, params: torch.Tensor, enable: Optional[torch.Tensor], apply: Optional[torch.Tensor], stages: tuple,
                 gray_ws: Optional[torch.Tensor] = None):
-        B, _, H, W = x.shape
-        dev = x.device
-        x = x.contiguous()
-        params = params.contiguous()
-        out = torch.empty_like(x)
-        # (gray_ws: a (B,) float64 workspace that the launch which made `params` has ALREADY zeroed - km_color_params_ws_fwd - instead of a fill launch here)
-        gray_sum = (gray_ws if gray_ws is not None else torch.zeros(B, device=dev, dtype=torch.float64)) if CONTRAST in stages else None
-        arr = (ctypes.c_int * max(len(stages), 1))(*stages)
-        with N.device_guard(dev):
-            if apply is None:
-                N.check(N.lib().km_color_jitter_fwd(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), arr, len(stages), B, H, W,
-                                                    N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd")
-            else:
-                N.check(N.lib().km_color_jitter_fwd_masked(x.data_ptr(), out.data_ptr(), params.data_ptr(), N.ptr(gray_sum), N.ptr(enable), apply.data_ptr(), arr,
-                                                           len(stages), B, H, W, N.dtype_code(x.dtype), N.stream_ptr(dev)), "km_color_jitter_fwd_masked")
+        out, x, params, gray_sum = _color_launch(x, params, enable, apply, stages, gray_ws)
         ctx.stages = stages
         ctx.save_for_backward(x, params, gray_sum, enable, apply)
         return out
@@ -133,6 +140,8 @@ def color_jitter_from_table(image: torch.Tensor, params: torch.Tensor, enable: O
         raise ValueError("params must be (B,4) float32")
     if gray_ws is not None and (gray_ws.dtype != torch.float64 or gray_ws.numel() != image.shape[0] or gray_ws.device != image.device or not gray_ws.is_contiguous()):
         raise ValueError("gray_ws must be a contiguous (B,) float64 tensor on the image's device")
+    if not (torch.is_grad_enabled() and (image.requires_grad or params.requires_grad)):
+        return _color_launch(image.detach(), params.detach(), enable, apply, stages, gray_ws)[0]  # (no autograd node to build: ~8 us of host per call)
     return _ColorJitterFunction.apply(image, params, enable, apply, stages, gray_ws)
 
 
