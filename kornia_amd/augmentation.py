@@ -655,6 +655,28 @@ class AugmentationSequential(torch.nn.Module):
             dev = self._draws.buf.to(input.device, non_blocking=True)  # the whole pipeline's draws: ONE copy
             for _, m in children:
                 m._dev_buf = dev
+        else:
+            # a replay of parameters whose float tensors are pieces of ONE host allocation (this container's own `_params` are): one copy for the
+            # whole pipeline here too, handed to the children the way their own draws are
+            st_ptr, store = None, None
+            for it in params:
+                for v in it.data.values():
+                    if type(v) is torch.Tensor and v.dtype is torch.float32 and v.device.type == "cpu" and v.numel():
+                        sp = v.untyped_storage().data_ptr()
+                        if st_ptr is None:
+                            st_ptr, store = sp, v.untyped_storage()
+                        elif sp != st_ptr:
+                            st_ptr = 0
+                            break
+                if st_ptr == 0:
+                    break
+            if st_ptr:
+                buf = torch.empty(0, dtype=torch.float32).set_(store)
+                dev = buf.to(input.device, non_blocking=True)
+                for _, m in children:
+                    m._st["host_buf"] = buf
+                    m._dev_buf = dev
+                own = True
         out, used = input, []
         for i, (name, m) in enumerate(children):
             out = m(out, params[i].data, _own=own)
